@@ -1,0 +1,101 @@
+"""ctypes binding of csrc/libcnrma_hip.so (the C-ABI declared in include/cnrma.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this module raises.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcnrma_hip.so")
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); mirrors include/cnrma.h one to one
+SIGNATURES = {
+    "cnrma_abi_version": (c_int, []),
+    "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
+    "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P]),
+    "cnrma_backproject_index_f32": (c_int, [P, I, I, I, I, I, F, F, F, F, P, P, P, P]),
+    "cnrma_ray_params_f32": (c_int, [P, I, I, I, P, P, P]),
+    "cnrma_rma_neus_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P]),
+    "cnrma_rma_neus_emit_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, F, F, F,
+                                        P, I, P, I, P, I, P, P]),
+    "cnrma_rma_depth_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P]),
+    "cnrma_rma_depth_emit_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P, F, F, F,
+                                         P, I, P, I, P, I, P]),
+    "cnrma_rma_mean_weight": (c_int, [P, P, P, P]),
+    "cnrma_scan_workspace_bytes": (c_size_t, [L]),
+    "cnrma_exclusive_scan_i32": (c_int, [P, P, L, P, P]),
+    "cnrma_sum_f64": (c_int, [P, P, L, P, P]),
+    "cnrma_mask_to_index": (c_int, [P, P, P, L, P, P]),
+    "cnrma_select_rows_f32": (c_int, [P, L, I, P, F, F, F, P, P, P]),
+    "cnrma_voxelize_workspace_bytes": (c_size_t, [L]),
+    "cnrma_voxelize_f32": (c_int, [P, P, L, I, F, I, P, P, L, P, P, P, P, P, P]),
+    "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, P]),
+    "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, P, P, P]),
+    "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
+    "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P]),
+    "cnrma_sparse_convtr_gen_f32": (c_int, [P, P, L, P, I, I, P, I, P, P, I, P, P, P]),
+    "cnrma_sparse_maxpool_f32": (c_int, [P, I, P, I, P, L, P, P]),
+    "cnrma_instnorm_workspace_bytes": (c_size_t, [I]),
+    "cnrma_sparse_instnorm_f32": (c_int, [P, L, P, I, P, P, F, I, P, P, P]),
+    "cnrma_union_workspace_bytes": (c_size_t, [L]),
+    "cnrma_sparse_union_add_f32": (c_int, [P, P, L, P, P, P, L, P, I, P, P, L, P, P, P, P, P]),
+    "cnrma_sparse_interp_f32": (c_int, [P, L, P, P, P, P, L, I, P, P]),
+    "cnrma_sparse_prune_f32": (c_int, [P, P, L, P, I, P, P, P, P]),
+    "cnrma_rowmax_f32": (c_int, [P, L, P, I, P, P]),
+    "cnrma_fcaf3d_decode_f32": (c_int, [P, P, I, L, I, P, P]),
+    "cnrma_fcaf3d_scores_f32": (c_int, [P, P, L, I, P, P, P]),
+}
+
+_lib = None
+
+
+class CnrmaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly when it is not built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CnrmaError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+                         f"(or `make -C cn-rma_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cnrma_abi_version() != 1:
+        raise CnrmaError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C-ABI buffers must be contiguous"
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise CnrmaError(f"{name} failed with code {rc}" + (" (invalid argument)" if rc == -22 else " (-hipError_t)"))
+    return rc
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise CnrmaError("cn-rma_amd needs a HIP device (MI355X); the product path has no CPU implementation")

@@ -1,0 +1,97 @@
+// Shared device/host helpers for libcnrma_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cnrma.h"
+
+#define CNRMA_LAUNCH_CHECK()                      \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return -(int)e__;      \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// live row count of a device-counted tensor: min(capacity, *n_dev) (n_dev may be NULL)
+__device__ __forceinline__ int64_t live_rows(int64_t cap, const int32_t* n_dev) {
+  if (n_dev == nullptr) return cap;
+  int64_t n = (int64_t)__builtin_nontemporal_load(n_dev);
+  return n < cap ? n : cap;
+}
+
+// ---- wave / block scans (wave64) --------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d, 64);
+    if ((int)(threadIdx.x & 63) >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over a block of BLOCK threads (BLOCK multiple of 64, <= 1024); returns exclusive prefix and
+// writes the block total to *total. smem: BLOCK/64 ints.
+template <int BLOCK>
+__device__ __forceinline__ int block_excl_scan(int v, int* smem, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int incl = wave_incl_scan(v);
+  if (lane == 63) smem[wid] = incl;
+  __syncthreads();
+  if (wid == 0) {
+    int w = lane < BLOCK / 64 ? smem[lane] : 0;
+    int wi = wave_incl_scan(w);
+    if (lane < BLOCK / 64) smem[lane] = wi - w;  // exclusive wave offsets
+    if (lane == BLOCK / 64 - 1) smem[BLOCK / 64] = wi;
+  }
+  __syncthreads();
+  int res = incl - v + smem[wid];
+  *total = smem[BLOCK / 64];
+  __syncthreads();
+  return res;
+}
+
+// ---- 64-bit coordinate key: (b, x, y, z) with 16 / 16 / 16 / 16 bits, biased so that negatives order correctly
+__device__ __forceinline__ uint64_t coord_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)(x + 32768) << 32) |
+         ((uint64_t)(uint16_t)(y + 32768) << 16) | (uint64_t)(uint16_t)(z + 32768);
+}
+#define CNRMA_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint32_t hash_u64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// find slot of key (or the empty slot where it would go). cap is a power of two.
+__device__ __forceinline__ int64_t hash_find(const uint64_t* keys, int64_t cap, uint64_t key) {
+  int64_t slot = hash_u64(key) & (cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    uint64_t k = keys[slot];
+    if (k == key) return slot;
+    if (k == CNRMA_EMPTY_KEY) return -1;
+    slot = (slot + 1) & (cap - 1);
+  }
+  return -1;
+}
+
+// insert key; returns its slot (claims an empty slot with CAS when absent)
+__device__ __forceinline__ int64_t hash_insert(uint64_t* keys, int64_t cap, uint64_t key) {
+  int64_t slot = hash_u64(key) & (cap - 1);
+  for (int64_t probe = 0; probe < cap; ++probe) {
+    uint64_t k = keys[slot];
+    if (k == key) return slot;
+    if (k == CNRMA_EMPTY_KEY) {
+      unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&keys[slot]),
+                                          (unsigned long long)CNRMA_EMPTY_KEY, (unsigned long long)key);
+      if (prev == CNRMA_EMPTY_KEY || prev == key) return slot;
+    }
+    slot = (slot + 1) & (cap - 1);
+  }
+  return -1;
+}

@@ -1,0 +1,141 @@
+// Dense unprojection + accumulate + mean in ONE pass over the voxel grid.
+//
+// The reference makes V full passes: zero-fill + scatter a C x G volume per view, add it to a running sum,
+// and finally divides by the view count (ray_marching.py:21-69, :220-257) -- 15 GB of writes per scene at the
+// ScanNet shape.  Here each lane owns one voxel, loops over the V views with the accumulators in registers and
+// writes the mean volume exactly once (compulsory traffic: read the feature planes, write C x G floats).
+//
+// Lane -> voxel mapping: linear index with z fastest, so the stores of one channel are coalesced; the gathers hit
+// channels-last pixels (one 128-B line per pixel at C = 32).
+// Bit-exactness: world = fl(fl(i*vs)+o); cam = fma chain (MKL bmm); px,py = rint(cam0/cam2) (IEEE division);
+// sum in view order; mean = sum / (float)count.  Compiled with -ffp-contract=off.
+#include "common.h"
+
+namespace {
+
+struct DenseParams {
+  int V, C, H, W, X, Y, Z;
+  float vs, ox, oy, oz;
+};
+
+__device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, float* wx, float* wy, float* wz) {
+  const int z = (int)(g % p.Z);
+  const int64_t t = g / p.Z;
+  const int y = (int)(t % p.Y);
+  const int x = (int)(t / p.Y);
+  *wx = (float)x * p.vs + p.ox;  // ray_marching.py:48  (two roundings)
+  *wy = (float)y * p.vs + p.oy;
+  *wz = (float)z * p.vs + p.oz;
+}
+
+// project one voxel into one view: returns validity, pixel in (*px,*py) (ray_marching.py:51-58)
+__device__ __forceinline__ bool project(const float* __restrict__ P, float wx, float wy, float wz, int H, int W,
+                                        float* rx, float* ry) {
+  float cam[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = P[r * 4 + 0] * wx;
+    acc = fmaf(P[r * 4 + 1], wy, acc);
+    acc = fmaf(P[r * 4 + 2], wz, acc);
+    acc = fmaf(P[r * 4 + 3], 1.0f, acc);
+    cam[r] = acc;
+  }
+  *rx = rintf(cam[0] / cam[2]);
+  *ry = rintf(cam[1] / cam[2]);
+  // comparisons in float are equivalent to the reference's int64 ones: NaN / out-of-range casts land on
+  // INT64_MIN there (negative -> invalid), and are rejected here as well
+  return (*rx >= 0.0f) && (*ry >= 0.0f) && (*rx < (float)W) && (*ry < (float)H) && (cam[2] > 0.0f);
+}
+
+// CT channels per lane kept in registers; grid.y walks channel chunks
+template <int CT>
+__global__ __launch_bounds__(256) void backproject_accum_kernel(DenseParams p, const float* __restrict__ feat,
+                                                                const float* __restrict__ proj,
+                                                                float* __restrict__ volume,
+                                                                int32_t* __restrict__ count) {
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const int c0 = blockIdx.y * CT;
+  float wx, wy, wz;
+  voxel_world(p, g, &wx, &wy, &wz);
+  float acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = 0.0f;
+  int cnt = 0;
+  const int64_t plane = (int64_t)p.H * p.W * p.C;
+  for (int v = 0; v < p.V; ++v) {
+    float rx, ry;
+    if (!project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry)) continue;
+    ++cnt;
+    const float* f = feat + v * plane + ((int64_t)(int)ry * p.W + (int)rx) * p.C + c0;
+    if constexpr (CT % 4 == 0) {
+#pragma unroll
+      for (int c = 0; c < CT; c += 4) {
+        float4 q = *reinterpret_cast<const float4*>(f + c);
+        acc[c] += q.x; acc[c + 1] += q.y; acc[c + 2] += q.z; acc[c + 3] += q.w;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[c] += f[c];
+    }
+  }
+  const float denom = (float)cnt;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    if (c0 + c < p.C) volume[(int64_t)(c0 + c) * G + g] = cnt > 0 ? acc[c] / denom : 0.0f;
+  }
+  if (blockIdx.y == 0) count[g] = cnt;
+}
+
+__global__ __launch_bounds__(256) void backproject_index_kernel(DenseParams p, const float* __restrict__ proj,
+                                                                int32_t* __restrict__ px, int32_t* __restrict__ py,
+                                                                uint8_t* __restrict__ valid) {
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  float wx, wy, wz, rx, ry;
+  voxel_world(p, g, &wx, &wy, &wz);
+  bool ok = project(proj, wx, wy, wz, p.H, p.W, &rx, &ry);
+  const float lim = 2147483000.0f;
+  px[g] = (rx > -lim && rx < lim) ? (int32_t)rx : INT32_MIN;
+  py[g] = (ry > -lim && ry < lim) ? (int32_t)ry : INT32_MIN;
+  valid[g] = ok ? 1 : 0;
+}
+
+template <int CT>
+int launch_accum(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
+                 hipStream_t st) {
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  dim3 grid((unsigned)ceil_div(G, 256), (unsigned)ceil_div(p.C, CT));
+  hipLaunchKernelGGL((backproject_accum_kernel<CT>), grid, dim3(256), 0, st, p, feat, proj, volume, count);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
+                                           int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                           float* volume, int32_t* count, void* stream) {
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
+  DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
+  hipStream_t st = as_stream(stream);
+  if (C % 32 == 0) return launch_accum<32>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 16 == 0) return launch_accum<16>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 8 == 0) return launch_accum<8>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 4 == 0) return launch_accum<4>(p, feat_nhwc, proj, volume, count, st);
+  return launch_accum<1>(p, feat_nhwc, proj, volume, count, st);
+}
+
+extern "C" int cnrma_backproject_index_f32(const float* proj_view, int H, int W, int X, int Y, int Z, float voxel_size,
+                                           float ox, float oy, float oz, int32_t* px, int32_t* py, uint8_t* valid,
+                                           void* stream) {
+  if (H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
+  DenseParams p{1, 1, H, W, X, Y, Z, voxel_size, ox, oy, oz};
+  const int64_t G = (int64_t)X * Y * Z;
+  hipLaunchKernelGGL(backproject_index_kernel, dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, as_stream(stream), p,
+                     proj_view, px, py, valid);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}

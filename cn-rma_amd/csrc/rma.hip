@@ -1,0 +1,410 @@
+// Ray-marching aggregation (RMA) kernels: ray parameters, NeuS march (count + emit), depth variant.
+//
+// Arithmetic contract (bit-level, see DESIGN.md "numerics"): this file is compiled with -ffp-contract=off and
+// every fused multiply-add below is an explicit fmaf(), because the reference's CPU path mixes MKL matrix
+// products (FMA chains in k order) with un-fused elementwise torch ops.  sigmoid() is
+// the exact operation sequence of torch's vectorised CPU kernel (Sleef expf_u10 with FMA, then 1/(1+e)), the
+// running transmittance is an fp64 sequential product like the CPU cumprod (Appendix B.13).
+//
+// One lane per ray; all V views in one launch.  A ray marches only the step interval that can touch the grid
+// (conservative slab clip; outside it every sample reads TSDF = 1 and contributes alpha = 0 exactly,
+// Appendix B.4) and stops as soon as the transmittance drops below the weight threshold (w = T*alpha <= T).
+#include "common.h"
+
+namespace {
+
+struct MarchParams {
+  int V, H, W, X, Y, Z, N;
+  float vs, ox, oy, oz, t_one, thr;
+};
+
+struct Ray {
+  float ox, oy, oz, dx, dy, dz;
+};
+
+// get_ray_parameter (ray_marching.py:71-111) for pixel (u = column, v = row) of one view.
+__device__ __forceinline__ Ray make_ray(const float* __restrict__ Pi, float u, float v) {
+  float far_[3], o[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    // bmm(Pinv, [u, v, 1, 1]) : fma chain in k order (MKL sgemm on this shape)
+    float acc = Pi[r * 4 + 0] * u;
+    acc = fmaf(Pi[r * 4 + 1], v, acc);
+    acc = fmaf(Pi[r * 4 + 2], 1.0f, acc);
+    acc = fmaf(Pi[r * 4 + 3], 1.0f, acc);
+    far_[r] = acc;
+    o[r] = Pi[r * 4 + 3];  // bmm(Pinv, [0,0,0,1]) is exactly column 3
+  }
+  float dx = far_[0] - o[0], dy = far_[1] - o[1], dz = far_[2] - o[2];
+  // F.normalize(p=2, dim=1): sqrt(fma(z,z,fma(y,y,x*x))) clamped at eps = 1e-12, then true division
+  float n2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  float nrm = fmaxf(sqrtf(n2), 1e-12f);
+  Ray ray;
+  ray.ox = o[0]; ray.oy = o[1]; ray.oz = o[2];
+  ray.dx = dx / nrm; ray.dy = dy / nrm; ray.dz = dz / nrm;
+  return ray;
+}
+
+// Sleef_expf_u10 (FMA flavour): the exp used by torch's vectorised CPU sigmoid.
+__device__ __forceinline__ float sleef_expf_u10(float d) {
+  float qf = rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+  int q = (int)qf;
+  float s = fmaf(qf, -0.693145751953125f, d);
+  s = fmaf(qf, -1.428606765330187045e-06f, s);
+  float u = 0.000198527617612853646278381f;
+  u = fmaf(u, s, 0.00139304355252534151077271f);
+  u = fmaf(u, s, 0.00833336077630519866943359f);
+  u = fmaf(u, s, 0.0416664853692054748535156f);
+  u = fmaf(u, s, 0.166666671633720397949219f);
+  u = fmaf(u, s, 0.5f);
+  u = 1.0f + fmaf(s * s, u, s);
+  int q1 = q >> 1, q2 = q - q1;
+  u = u * __int_as_float((q1 + 127) << 23) * __int_as_float((q2 + 127) << 23);
+  if (d < -104.0f) u = 0.0f;
+  if (d > 104.0f) u = __int_as_float(0x7f800000);
+  return u;
+}
+
+// torch.sigmoid(-sdf) on CPU: a = 0 - (-sdf); a = exp(a); a = 1 + a; a = 1 / a
+__device__ __forceinline__ float sigmoid_neg(float sdf) {
+  float a = 0.0f - (-sdf);
+  a = sleef_expf_u10(a);
+  a = 1.0f + a;
+  return 1.0f / a;
+}
+
+struct Sample {
+  float x, y, z, s;
+  bool valid;
+};
+
+// one step of the march (ray_marching.py:713-745): place, rounded voxel, validity, sigmoid(-tsdf)
+__device__ __forceinline__ Sample eval_step(const Ray& r, int n, const MarchParams& p, const float* __restrict__ tsdf) {
+  Sample sm;
+  float t = (float)n * p.t_one;
+  sm.x = r.ox + r.dx * t;
+  sm.y = r.oy + r.dy * t;
+  sm.z = r.oz + r.dz * t;
+  float fx = rintf((sm.x - p.ox) / p.vs);
+  float fy = rintf((sm.y - p.oy) / p.vs);
+  float fz = rintf((sm.z - p.oz) / p.vs);
+  sm.valid = (fx >= 0.0f) && (fx < (float)p.X) && (fy >= 0.0f) && (fy < (float)p.Y) && (fz >= 0.0f) && (fz < (float)p.Z);
+  float sdf = 1.0f;
+  if (sm.valid) sdf = tsdf[((int64_t)(int)fx * p.Y + (int)fy) * p.Z + (int)fz];
+  sm.s = sigmoid_neg(sdf);
+  return sm;
+}
+
+// conservative step interval [a, b] outside which every sample is out of the grid; returns false when empty
+__device__ __forceinline__ bool clip_steps(const Ray& r, const MarchParams& p, int* a, int* b) {
+  float t0 = 0.0f, t1 = (float)(p.N - 1) * p.t_one;
+  const float o[3] = {r.ox - p.ox, r.oy - p.oy, r.oz - p.oz};
+  const float d[3] = {r.dx, r.dy, r.dz};
+  const float hi[3] = {((float)p.X + 0.5f) * p.vs, ((float)p.Y + 0.5f) * p.vs, ((float)p.Z + 0.5f) * p.vs};
+  const float lo = -1.5f * p.vs;
+  bool any = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (!(fabsf(d[k]) > 1e-7f)) {
+      if (!(o[k] >= lo && o[k] <= hi[k])) any = false;  // also rejects NaN
+    } else {
+      float ta = (lo - o[k]) / d[k], tb = (hi[k] - o[k]) / d[k];
+      float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
+      t0 = fmaxf(t0, tn);
+      t1 = fminf(t1, tf);
+    }
+  }
+  if (!any || !(t0 <= t1)) return false;
+  int ia = (int)floorf(t0 / p.t_one) - 2;
+  int ib = (int)ceilf(t1 / p.t_one) + 2;
+  *a = ia < 0 ? 0 : ia;
+  *b = ib > p.N - 1 ? p.N - 1 : ib;
+  return *a <= *b;
+}
+
+// Generic NeuS march over one ray; calls keep(n, sample, w) for every kept sample in step order.
+template <typename Keep>
+__device__ __forceinline__ void neus_march(const Ray& r, const MarchParams& p, const float* __restrict__ tsdf,
+                                           float s_out, Keep keep) {
+  int a, b;
+  if (!clip_steps(r, p, &a, &b)) return;
+  double acc = 1.0;  // running product of (1 - alpha): fp64 like the CPU cumprod
+  Sample cur = eval_step(r, a, p, tsdf);
+  for (int n = a; n <= b; ++n) {
+    Sample nxt;
+    if (n + 1 <= b) {
+      nxt = eval_step(r, n + 1, p, tsdf);
+    } else {
+      nxt = cur;                                  // n == N-1: s_next repeats the last sample (:758)
+      if (n + 1 <= p.N - 1) { nxt.s = s_out; nxt.valid = false; }
+    }
+    float alpha = fmaxf((cur.s - nxt.s) / cur.s, 0.0f);          // :759
+    float T = (float)acc;                                         // :760-762 exclusive product
+    float w = T * alpha;                                          // :763
+    if (cur.valid && w >= p.thr) keep(n, cur, w);                 // :765-767
+    acc *= (double)(1.0f - alpha);
+    if ((float)acc < p.thr) break;                                // every later w = T*alpha <= T < thr
+    cur = nxt;
+  }
+}
+
+__device__ __forceinline__ bool ray_setup(const MarchParams& p, const float* __restrict__ proj_inv, int64_t r, Ray* ray,
+                                          int* view, int* pix) {
+  const int64_t HW = (int64_t)p.H * p.W;
+  if (r >= (int64_t)p.V * HW) return false;
+  *view = (int)(r / HW);
+  *pix = (int)(r - (int64_t)(*view) * HW);
+  int v = *pix / p.W, u = *pix - v * p.W;
+  *ray = make_ray(proj_inv + (int64_t)(*view) * 16, (float)u, (float)v);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void neus_count_kernel(MarchParams p, const float* __restrict__ proj_inv,
+                                                         const float* __restrict__ tsdf, int32_t* __restrict__ count,
+                                                         double* __restrict__ wsum) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Ray ray; int view, pix;
+  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
+  const float s_out = sigmoid_neg(1.0f);
+  int c = 0;
+  double ws = 0.0;
+  neus_march(ray, p, tsdf, s_out, [&](int, const Sample&, float w) { ++c; ws += (double)w; });
+  count[r] = c;
+  wsum[r] = ws;
+}
+
+struct EmitDst {
+  float* xyz; int xyz_stride;
+  float* w; int w_stride;
+  float* feat; int feat_stride;
+  int32_t* sample;       // [M][2] = (ray, step) debug / alignment aid, may be NULL
+  const int32_t* sel;    // may be NULL
+  const float* w_div;    // device scalar, may be NULL
+  float ax, ay, az;
+};
+
+__device__ __forceinline__ void emit_row(const EmitDst& d, int64_t m, float x, float y, float z, float w,
+                                         const float* __restrict__ f, int C, int64_t ray, int step) {
+  int64_t j = m;
+  if (d.sel) {
+    j = d.sel[m];
+    if (j < 0) return;
+  }
+  if (d.xyz) {
+    float* q = d.xyz + j * d.xyz_stride;
+    q[0] = x + d.ax; q[1] = y + d.ay; q[2] = z + d.az;
+  }
+  if (d.w) d.w[j * d.w_stride] = w;
+  if (d.sample) { d.sample[2 * j] = (int32_t)ray; d.sample[2 * j + 1] = step; }
+  if (d.feat) {
+    float* q = d.feat + j * d.feat_stride;
+    float scale = 1.0f;
+    const bool scaled = d.w_div != nullptr;
+    if (scaled) scale = w / d.w_div[0];                           // weights / mean(weights)  (:303)
+    if (((C | d.feat_stride) & 3) == 0 && ((((uintptr_t)d.feat) | ((uintptr_t)f)) & 15) == 0) {
+      for (int c = 0; c < C; c += 4) {
+        float4 v = *reinterpret_cast<const float4*>(f + c);
+        if (scaled) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }   // point_features * weights (:304)
+        *reinterpret_cast<float4*>(q + c) = v;
+      }
+    } else {
+      for (int c = 0; c < C; ++c) q[c] = scaled ? f[c] * scale : f[c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void neus_emit_kernel(MarchParams p, int C, const float* __restrict__ proj_inv,
+                                                        const float* __restrict__ tsdf,
+                                                        const float* __restrict__ feat,
+                                                        const int32_t* __restrict__ row_offset, EmitDst dst) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Ray ray; int view, pix;
+  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
+  const int64_t m0 = row_offset[r];
+  if (row_offset[r + 1] == m0) return;  // nothing kept on this ray
+  const float s_out = sigmoid_neg(1.0f);
+  const float* f = feat + ((int64_t)view * p.H * p.W + pix) * C;
+  int64_t m = m0;
+  neus_march(ray, p, tsdf, s_out, [&](int n, const Sample& sm, float w) {
+    emit_row(dst, m, sm.x, sm.y, sm.z, w, f, C, r, n);
+    ++m;
+  });
+}
+
+// ---- depth variant (ray_marching.py:809-956) -------------------------------------------------------------------
+// first step n* with sdf[n]*sdf[n+1] <= 0 (the product with the appended 1 at n = N-1 is never <= 0)
+__device__ __forceinline__ bool depth_first_change(const Ray& r, const MarchParams& p, const float* __restrict__ tsdf,
+                                                   int* best) {
+  int a, b;
+  if (!clip_steps(r, p, &a, &b)) return false;
+  auto sdf_at = [&](int n) -> float {
+    float t = (float)n * p.t_one;
+    float fx = rintf(((r.ox + r.dx * t) - p.ox) / p.vs);
+    float fy = rintf(((r.oy + r.dy * t) - p.oy) / p.vs);
+    float fz = rintf(((r.oz + r.dz * t) - p.oz) / p.vs);
+    bool valid = (fx >= 0.0f) && (fx < (float)p.X) && (fy >= 0.0f) && (fy < (float)p.Y) && (fz >= 0.0f) && (fz < (float)p.Z);
+    return valid ? tsdf[((int64_t)(int)fx * p.Y + (int)fy) * p.Z + (int)fz] : 1.0f;
+  };
+  float cur = sdf_at(a);
+  for (int n = a; n <= b && n < p.N - 1; ++n) {
+    float nxt = (n + 1 <= b) ? sdf_at(n + 1) : 1.0f;
+    if (cur * nxt <= 0.0f) { *best = n; return true; }
+    cur = nxt;
+  }
+  return false;
+}
+
+template <typename Slot>
+__device__ __forceinline__ void depth_slots(const Ray& r, const MarchParams& p, int k, int best, Slot slot) {
+  if (k == 0) {
+    float idx = (float)best + 0.5f;                                                   // :912
+    slot(r.ox + (r.dx * idx) * p.t_one, r.oy + (r.dy * idx) * p.t_one, r.oz + (r.dz * idx) * p.t_one, 1.0f, 0);
+    return;
+  }
+  for (int j = 0; j < 2 * k; ++j) {
+    int sel = best + (j - k + 1);                                                     // :889,:897
+    float tri = (float)(j < k ? j + 1 : 2 * k - j) / (float)k;                        // :891-894
+    if (sel < 0 || sel >= p.N) continue;                                              // :899-900 (weight 0 -> dropped)
+    float idx = (float)sel;
+    slot(r.ox + (r.dx * idx) * p.t_one, r.oy + (r.dy * idx) * p.t_one, r.oz + (r.dz * idx) * p.t_one, tri, j);
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_count_kernel(MarchParams p, int k, const float* __restrict__ proj_inv,
+                                                          const float* __restrict__ tsdf, int32_t* __restrict__ count,
+                                                          double* __restrict__ wsum) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Ray ray; int view, pix;
+  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
+  int best, c = 0;
+  double ws = 0.0;
+  if (depth_first_change(ray, p, tsdf, &best))
+    depth_slots(ray, p, k, best, [&](float, float, float, float w, int) { ++c; ws += (double)w; });
+  count[r] = c;
+  wsum[r] = ws;
+}
+
+__global__ __launch_bounds__(256) void depth_emit_kernel(MarchParams p, int k, int C, const float* __restrict__ proj_inv,
+                                                         const float* __restrict__ tsdf,
+                                                         const float* __restrict__ feat,
+                                                         const int32_t* __restrict__ row_offset, EmitDst dst) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Ray ray; int view, pix;
+  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
+  const int64_t m0 = row_offset[r];
+  if (row_offset[r + 1] == m0) return;
+  int best;
+  if (!depth_first_change(ray, p, tsdf, &best)) return;
+  const float* f = feat + ((int64_t)view * p.H * p.W + pix) * C;
+  int64_t m = m0;
+  depth_slots(ray, p, k, best, [&](float x, float y, float z, float w, int j) {
+    emit_row(dst, m, x, y, z, w, f, C, r, j);
+    ++m;
+  });
+}
+
+__global__ void ray_params_kernel(const float* __restrict__ proj_inv, int V, int H, int W, float* __restrict__ o,
+                                  float* __restrict__ d) {
+  const int64_t HW = (int64_t)H * W;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= (int64_t)V * HW) return;
+  int view = (int)(r / HW);
+  int pix = (int)(r - view * HW);
+  int v = pix / W, u = pix - v * W;
+  Ray ray = make_ray(proj_inv + (int64_t)view * 16, (float)u, (float)v);
+  float* dv = d + (int64_t)view * 3 * HW;
+  dv[pix] = ray.dx; dv[HW + pix] = ray.dy; dv[2 * HW + pix] = ray.dz;
+  if (pix == 0) { o[view * 3] = ray.ox; o[view * 3 + 1] = ray.oy; o[view * 3 + 2] = ray.oz; }
+}
+
+__global__ void mean_weight_kernel(const double* __restrict__ wsum_total, const int32_t* __restrict__ m_total,
+                                   float* __restrict__ mean_w) {
+  // torch.mean(weights) (:303): fp64 sum of the fp32 weights / M, rounded once to fp32
+  mean_w[0] = (float)(wsum_total[0] / (double)m_total[0]);
+}
+
+MarchParams make_params(int V, int H, int W, int X, int Y, int Z, float vs, float ox, float oy, float oz, int N,
+                        float t_one, float thr) {
+  MarchParams p;
+  p.V = V; p.H = H; p.W = W; p.X = X; p.Y = Y; p.Z = Z; p.N = N;
+  p.vs = vs; p.ox = ox; p.oy = oy; p.oz = oz; p.t_one = t_one; p.thr = thr;
+  return p;
+}
+
+bool bad_dims(int V, int H, int W, int X, int Y, int Z, int N) {
+  return V <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0 || N <= 0 ||
+         (int64_t)V * H * W >= (int64_t)1 << 31;
+}
+
+}  // namespace
+
+extern "C" int cnrma_ray_params_f32(const float* proj_inv, int V, int H, int W, float* o, float* d, void* stream) {
+  if (V <= 0 || H <= 0 || W <= 0) return CNRMA_EINVAL;
+  int64_t R = (int64_t)V * H * W;
+  hipLaunchKernelGGL(ray_params_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), proj_inv,
+                     V, H, W, o, d);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_neus_count_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y,
+                                        int Z, float voxel_size, float ox, float oy, float oz, int n_steps,
+                                        float t_one, float thr, int32_t* count, double* wsum, void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps)) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
+  int64_t R = (int64_t)V * H * W;
+  hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
+                     proj_inv, tsdf, count, wsum);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const float* feat_nhwc, int V, int C,
+                                       int H, int W, int X, int Y, int Z, float voxel_size, float ox, float oy,
+                                       float oz, int n_steps, float t_one, float thr, const int32_t* row_offset,
+                                       const int32_t* sel_index, const float* w_div, float addx, float addy,
+                                       float addz, float* out_xyz, int xyz_stride, float* out_w, int w_stride,
+                                       float* out_feat, int feat_stride, int32_t* out_sample, void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps) || C <= 0) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
+  EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, out_sample, sel_index, w_div, addx, addy, addz};
+  int64_t R = (int64_t)V * H * W;
+  hipLaunchKernelGGL(neus_emit_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p, C,
+                     proj_inv, tsdf, feat_nhwc, row_offset, d);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_depth_count_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y,
+                                         int Z, float voxel_size, float ox, float oy, float oz, int n_steps,
+                                         float t_one, int select_grids, int32_t* count, double* wsum, void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps) || select_grids < 0) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, 0.0f);
+  int64_t R = (int64_t)V * H * W;
+  hipLaunchKernelGGL(depth_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
+                     select_grids, proj_inv, tsdf, count, wsum);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_depth_emit_f32(const float* proj_inv, const float* tsdf, const float* feat_nhwc, int V, int C,
+                                        int H, int W, int X, int Y, int Z, float voxel_size, float ox, float oy,
+                                        float oz, int n_steps, float t_one, int select_grids,
+                                        const int32_t* row_offset, const int32_t* sel_index, const float* w_div,
+                                        float addx, float addy, float addz, float* out_xyz, int xyz_stride,
+                                        float* out_w, int w_stride, float* out_feat, int feat_stride, void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps) || C <= 0 || select_grids < 0) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, 0.0f);
+  EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, nullptr, sel_index, w_div, addx, addy, addz};
+  int64_t R = (int64_t)V * H * W;
+  hipLaunchKernelGGL(depth_emit_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
+                     select_grids, C, proj_inv, tsdf, feat_nhwc, row_offset, d);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_mean_weight(const double* wsum_total, const int32_t* m_total, float* mean_w, void* stream) {
+  hipLaunchKernelGGL(mean_weight_kernel, dim3(1), dim3(1), 0, as_stream(stream), wsum_total, m_total, mean_w);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}

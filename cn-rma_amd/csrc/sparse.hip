@@ -1,0 +1,695 @@
+// Sparse-voxel engine: voxelisation, coordinate maps, kernel maps, fused sparse convolution on fp32 MFMA,
+// generative transposed convolution, pooling, instance norm, union-add, interpolation, pruning.
+// Replaces the MinkowskiEngine v0.5.4 surface used by the reference.
+//
+// Data model: coordinates int32 [N][4] = (batch, x, y, z); features fp32 [N][C] row-major (one or more full
+// 128-B lines per row for C >= 32); a coordinate map is an open-addressing hash table (uint64 keys, int32
+// row values, power-of-two capacity >= 2N) that lives next to the tensor.  Convolutions are OUTPUT-STATIONARY:
+// a neighbour table nbr[No][K] (input row or -1) is built once per (coordinate set, kernel) pair and the
+// convolution is a gather-GEMM with no atomics -- deterministic, and the BatchNorm / bias / residual /
+// activation epilogue is fused into the store.
+#include "common.h"
+
+namespace {
+
+// ================================================================================================================
+// unique (first occurrence wins, output in first-occurrence order) -- shared by voxelise and strided coords
+// ================================================================================================================
+struct UniqueWs {
+  int32_t* slot;    // [n] hash slot of row i
+  int32_t* idx;     // [n] output row of i or -1
+  uint8_t* flag;    // [n] 1 when row i is the representative of its voxel
+  void* scan;       // scan workspace
+};
+
+__host__ UniqueWs carve_unique_ws(void* workspace, int64_t n) {
+  UniqueWs w;
+  char* p = reinterpret_cast<char*>(workspace);
+  int64_t n4 = (n + 3) / 4 * 4;
+  w.slot = reinterpret_cast<int32_t*>(p); p += n4 * 4;
+  w.idx = reinterpret_cast<int32_t*>(p); p += n4 * 4;
+  w.flag = reinterpret_cast<uint8_t*>(p); p += n4;
+  w.scan = p;
+  return w;
+}
+
+// MODE 0: float coords / voxel_size -> floor (voxelise); MODE 1: int coords -> floor(p / s) * s (stride)
+template <int MODE>
+__device__ __forceinline__ void quantise(const void* src, int64_t i, float vs, int new_stride, int batch_id, int* b,
+                                         int* x, int* y, int* z) {
+  if (MODE == 0) {
+    const float* c = reinterpret_cast<const float*>(src) + i * 3;
+    *b = batch_id;
+    *x = (int)floorf(c[0] / vs);   // ME batch_sparse_collate: floor then int32 (true fp32 division, :329)
+    *y = (int)floorf(c[1] / vs);
+    *z = (int)floorf(c[2] / vs);
+  } else {
+    const int32_t* c = reinterpret_cast<const int32_t*>(src) + i * 4;
+    auto fl = [new_stride](int p) {
+      int q = p / new_stride;
+      if ((p % new_stride != 0) && (p < 0)) --q;  // floor toward -inf
+      return q * new_stride;
+    };
+    *b = c[0]; *x = fl(c[1]); *y = fl(c[2]); *z = fl(c[3]);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void uniq_insert_kernel(const void* __restrict__ src, int64_t n_cap,
+                                                          const int32_t* __restrict__ n_dev, float vs, int new_stride,
+                                                          int batch_id, uint64_t* __restrict__ keys,
+                                                          int32_t* __restrict__ vals, int64_t cap,
+                                                          int32_t* __restrict__ slot_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= live_rows(n_cap, n_dev)) return;
+  int b, x, y, z;
+  quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
+  int64_t s = hash_insert(keys, cap, coord_key(b, x, y, z));
+  slot_out[i] = (int32_t)s;
+  if (s >= 0) atomicMin(&vals[s], (int32_t)i);
+}
+
+__global__ __launch_bounds__(256) void uniq_flag_kernel(int64_t n_cap, const int32_t* __restrict__ n_dev,
+                                                        const int32_t* __restrict__ vals,
+                                                        const int32_t* __restrict__ slot, uint8_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cap) return;
+  uint8_t f = 0;
+  if (i < live_rows(n_cap, n_dev)) {
+    int32_t s = slot[i];
+    f = (s >= 0 && vals[s] == (int32_t)i) ? 1 : 0;
+  }
+  flag[i] = f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void uniq_write_kernel(const void* __restrict__ src, int64_t n_cap,
+                                                         const int32_t* __restrict__ n_dev, float vs, int new_stride,
+                                                         int batch_id, const int32_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ slot, int32_t* __restrict__ vals,
+                                                         int32_t* __restrict__ out_coords,
+                                                         int32_t* __restrict__ out_src) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= live_rows(n_cap, n_dev)) return;
+  const int32_t j = idx[i];
+  if (j < 0) return;
+  int b, x, y, z;
+  quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
+  reinterpret_cast<int4*>(out_coords)[j] = make_int4(b, x, y, z);
+  if (out_src) out_src[j] = (int32_t)i;
+  vals[slot[i]] = j;  // the table now maps voxel key -> output row
+}
+
+// out[j][:] = in[src[j]][:]   (lanes across channels: coalesced row copies)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ src,
+                                                          int64_t n_cap, const int32_t* __restrict__ n_dev, int C,
+                                                          float* __restrict__ out) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  if ((C & 3) == 0) {
+    const int c4 = C >> 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * c4; t += (int64_t)gridDim.x * blockDim.x) {
+      int64_t j = t / c4;
+      int c = (int)(t - j * c4);
+      reinterpret_cast<float4*>(out)[j * c4 + c] = reinterpret_cast<const float4*>(in)[(int64_t)src[j] * c4 + c];
+    }
+  } else {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
+      int64_t j = t / C;
+      int c = (int)(t - j * C);
+      out[j * C + c] = in[(int64_t)src[j] * C + c];
+    }
+  }
+}
+
+template <int MODE>
+int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, int new_stride, int batch_id,
+               uint64_t* keys, int32_t* vals, int64_t cap, int32_t* out_coords, int32_t* out_src, int32_t* n_out,
+               void* workspace, hipStream_t st) {
+  if (n_cap <= 0 || cap < 2 || (cap & (cap - 1)) != 0 || cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
+  UniqueWs w = carve_unique_ws(workspace, n_cap);
+  hipError_t e = hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint64_t), st);
+  if (e != hipSuccess) return -(int)e;
+  e = hipMemsetAsync(vals, 0x7F, (size_t)cap * sizeof(int32_t), st);
+  if (e != hipSuccess) return -(int)e;
+  const unsigned nb = (unsigned)ceil_div(n_cap, 256);
+  hipLaunchKernelGGL((uniq_insert_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
+                     batch_id, keys, vals, cap, w.slot);
+  hipLaunchKernelGGL(uniq_flag_kernel, dim3(nb), dim3(256), 0, st, n_cap, n_dev, vals, w.slot, w.flag);
+  int rc = cnrma_mask_to_index(w.flag, w.idx, n_out, n_cap, w.scan, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL((uniq_write_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
+                     batch_id, w.idx, w.slot, vals, out_coords, out_src);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ================================================================================================================
+// coordinate map / kernel map
+// ================================================================================================================
+__global__ __launch_bounds__(256) void build_map_kernel(const int32_t* __restrict__ coords, int64_t n_cap,
+                                                        const int32_t* __restrict__ n_dev, uint64_t* __restrict__ keys,
+                                                        int32_t* __restrict__ vals, int64_t cap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= live_rows(n_cap, n_dev)) return;
+  int4 c = reinterpret_cast<const int4*>(coords)[i];
+  int64_t s = hash_insert(keys, cap, coord_key(c.x, c.y, c.z, c.w));
+  if (s >= 0) vals[s] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restrict__ out_coords, int64_t no_cap,
+                                                         const int32_t* __restrict__ no_dev,
+                                                         const uint64_t* __restrict__ keys,
+                                                         const int32_t* __restrict__ vals, int64_t cap,
+                                                         const int32_t* __restrict__ offsets, int K,
+                                                         int32_t* __restrict__ nbr) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = live_rows(no_cap, no_dev);
+  if (t >= n * K) return;
+  const int64_t o = t / K;
+  const int k = (int)(t - o * K);
+  int4 c = reinterpret_cast<const int4*>(out_coords)[o];
+  int64_t s = hash_find(keys, cap, coord_key(c.x, c.y + offsets[k * 3], c.z + offsets[k * 3 + 1], c.w + offsets[k * 3 + 2]));
+  nbr[t] = s >= 0 ? vals[s] : -1;
+}
+
+// ================================================================================================================
+// fused sparse convolution: output-stationary gather-GEMM on v_mfma_f32_32x32x2_f32
+//   block = 256 threads = 4 waves; tile = (32*WM) output rows x (32*WN) output channels, WM*WN == 4
+//   per (kernel offset k, 32-channel slice of Cin): gather A[rows][32] through nbr, stage W[k][32][cols], 16 MFMAs/wave
+// ================================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BK = 32;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return v > 0.0f ? v : 0.0f;
+  if (act == 2) return v > 0.0f ? v : expm1f(v);
+  return v;
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(
+    const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr, int K, const float* __restrict__ weight,
+    int Cout, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual,
+    int act, float* __restrict__ out, int64_t no_cap, const int32_t* __restrict__ no_dev, int64_t out_row_offset_mul,
+    int w_slices) {
+  constexpr int BM = 32 * WM, BN = 32 * WN;
+  constexpr int LDA = BM + 1;   // k-major A tile, odd stride: conflict-light scattered 4-byte writes
+  constexpr int LDB = BN + 4;   // 16-B aligned rows for ds_write_b128
+  __shared__ float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  __shared__ int32_t nbr_s[BM];
+
+  const int64_t n_live = live_rows(no_cap, no_dev);
+  const int64_t tile0 = (int64_t)blockIdx.x * BM;
+  if (tile0 >= n_live) return;
+  const int cout0 = blockIdx.y * BN;
+  // grid.z walks weight slices (generative transposed conv: slice z writes rows z*n_live + i with W[z])
+  const int zs = blockIdx.z;
+  const float* Wz = weight + (int64_t)zs * (w_slices > 1 ? (int64_t)K * Cin * Cout : 0);
+  const int64_t out_base = (int64_t)zs * out_row_offset_mul * n_live;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid / WN, wc = wid % WN;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+  for (int k = 0; k < K; ++k) {
+    int nb = -1;
+    if (tid < BM) {
+      const int64_t row = tile0 + tid;
+      if (row < n_live) nb = nbr ? nbr[row * K + k] : (int32_t)row;
+      nbr_s[tid] = nb;
+    }
+    if (!__syncthreads_or(nb >= 0)) continue;   // nobody in this tile has a neighbour at offset k
+    const float* Wk = Wz + (int64_t)k * Cin * Cout;
+    for (int cin0 = 0; cin0 < Cin; cin0 += BK) {
+      // ---- stage A: BM rows x 32 channels, 8 lanes per row (one 128-B line per row)
+#pragma unroll
+      for (int i = 0; i < BM * (BK / 4) / 256; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx >> 3, kc = idx & 7;
+        const int32_t src = nbr_s[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cin = cin0 + kc * 4;
+        if (src >= 0) {
+          const float* p = in + (int64_t)src * Cin + cin;
+          if (cin + 3 < Cin && (Cin & 3) == 0) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (cin < Cin) v.x = p[0];
+            if (cin + 1 < Cin) v.y = p[1];
+            if (cin + 2 < Cin) v.z = p[2];
+            if (cin + 3 < Cin) v.w = p[3];
+          }
+        }
+        As[(kc * 4 + 0) * LDA + row] = v.x;
+        As[(kc * 4 + 1) * LDA + row] = v.y;
+        As[(kc * 4 + 2) * LDA + row] = v.z;
+        As[(kc * 4 + 3) * LDA + row] = v.w;
+      }
+      // ---- stage B: 32 x BN slice of W[k]
+#pragma unroll
+      for (int i = 0; i < BK * (BN / 4) / 256; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+        const int cin = cin0 + r, col = cout0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cin < Cin) {
+          const float* p = Wk + (int64_t)cin * Cout + col;
+          if (col + 3 < Cout && (Cout & 3) == 0) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            if (col < Cout) v.x = p[0];
+            if (col + 1 < Cout) v.y = p[1];
+            if (col + 2 < Cout) v.z = p[2];
+            if (col + 3 < Cout) v.w = p[3];
+          }
+        }
+        *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = v;
+      }
+      __syncthreads();
+      const float* a_p = As + (lane >> 5) * LDA + wr * 32 + (lane & 31);
+      const float* b_p = Bs + (lane >> 5) * LDB + wc * 32 + (lane & 31);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_p[kk * LDA], b_p[kk * LDB], acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: folded BN / bias, residual, activation.  D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+  const int col = cout0 + wc * 32 + (lane & 31);
+  if (col < Cout) {
+    const float sc = scale ? scale[col] : 1.0f;
+    const float sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = tile0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < n_live) {
+        float v = acc[r];
+        if (scale) v = v * sc;
+        if (shift) v = v + sh;
+        const int64_t o = (out_base + row) * Cout + col;
+        if (residual) v = v + residual[o];
+        out[o] = apply_act(v, act);
+      }
+    }
+  }
+}
+
+int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float* weight, int Cout, const float* scale,
+                const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
+                int slices, hipStream_t st) {
+  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0) return CNRMA_EINVAL;
+  if (Cout > 32) {
+    dim3 grid((unsigned)ceil_div(no_cap, 64), (unsigned)ceil_div(Cout, 64), (unsigned)slices);
+    hipLaunchKernelGGL((sparse_conv_mfma_kernel<2, 2>), grid, dim3(256), 0, st, in, Cin, nbr, K, weight, Cout, scale,
+                       shift, residual, act, out, no_cap, no_dev, (int64_t)1, slices);
+  } else {
+    dim3 grid((unsigned)ceil_div(no_cap, 128), 1, (unsigned)slices);
+    hipLaunchKernelGGL((sparse_conv_mfma_kernel<4, 1>), grid, dim3(256), 0, st, in, Cin, nbr, K, weight, Cout, scale,
+                       shift, residual, act, out, no_cap, no_dev, (int64_t)1, slices);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// children coordinates of the generative transposed conv: out[k*n + i] = in[i] + off_k * half, k with x fastest
+__global__ __launch_bounds__(256) void convtr_coords_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
+                                                            const int32_t* __restrict__ n_dev, int half,
+                                                            int32_t* __restrict__ out_coords) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 8) return;
+  const int k = (int)(t / n);
+  const int64_t i = t - (int64_t)k * n;
+  int4 c = reinterpret_cast<const int4*>(in_coords)[i];
+  c.y += (k & 1) * half;
+  c.z += ((k >> 1) & 1) * half;
+  c.w += ((k >> 2) & 1) * half;
+  reinterpret_cast<int4*>(out_coords)[t] = c;
+}
+
+// ================================================================================================================
+// pooling / normalisation / elementwise
+// ================================================================================================================
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, int C, const int32_t* __restrict__ nbr,
+                                                      int K, float* __restrict__ out, int64_t no_cap,
+                                                      const int32_t* __restrict__ no_dev) {
+  const int64_t n = live_rows(no_cap, no_dev);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  const int64_t o = t / C;
+  const int c = (int)(t - o * C);
+  float m = -__builtin_inff();
+  bool any = false;
+  for (int k = 0; k < K; ++k) {
+    int32_t s = nbr[o * K + k];
+    if (s >= 0) { m = fmaxf(m, in[(int64_t)s * C + c]); any = true; }
+  }
+  out[t] = any ? m : 0.0f;
+}
+
+// per-channel sum / sum of squares in fp64, deterministic two-stage (partials [nblk][2C])
+__global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __restrict__ in, int64_t n_cap,
+                                                               const int32_t* __restrict__ n_dev, int C,
+                                                               double* __restrict__ part) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  // thread -> channel c = tid % C (C <= 256), row group = tid / C
+  const int c = threadIdx.x % C;
+  const int groups = blockDim.x / C;
+  const int gi = threadIdx.x / C;
+  double s = 0.0, q = 0.0;
+  if (gi < groups) {
+    for (int64_t r = (int64_t)blockIdx.x * groups + gi; r < n; r += (int64_t)gridDim.x * groups) {
+      double v = (double)in[r * C + c];
+      s += v;
+      q += v * v;
+    }
+  }
+  __shared__ double sm[2 * 256];
+  sm[threadIdx.x] = s;
+  sm[256 + threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double ts = 0.0, tq = 0.0;
+    for (int g = 0; g < groups; ++g) { ts += sm[g * C + threadIdx.x]; tq += sm[256 + g * C + threadIdx.x]; }
+    part[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = ts;
+    part[(int64_t)blockIdx.x * 2 * C + C + threadIdx.x] = tq;
+  }
+}
+
+__global__ void colstats_final_kernel(const double* __restrict__ part, int nblk, int C, int64_t n_cap,
+                                      const int32_t* __restrict__ n_dev, double* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 2 * C + c]; q += part[(int64_t)b * 2 * C + C + c]; }
+  const double n = (double)live_rows(n_cap, n_dev);
+  const double mean = s / n;
+  double var = q / n - mean * mean;   // biased variance
+  if (var < 0.0) var = 0.0;
+  stats[c] = mean;
+  stats[C + c] = var;
+}
+
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ in, int64_t n_cap,
+                                                             const int32_t* __restrict__ n_dev, int C,
+                                                             const double* __restrict__ stats,
+                                                             const float* __restrict__ weight,
+                                                             const float* __restrict__ bias, float eps, int relu,
+                                                             float* __restrict__ out) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const float mean = (float)stats[c];
+    const float inv = 1.0f / sqrtf((float)stats[C + c] + eps);
+    float v = (in[t] - mean) * inv;
+    if (weight) v = v * weight[c];
+    if (bias) v = v + bias[c];
+    out[t] = relu ? fmaxf(v, 0.0f) : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ in, int64_t n_cap,
+                                                     const int32_t* __restrict__ n_dev, int C, float* __restrict__ out) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float m = in[i * C];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, in[i * C + c]);
+  out[i] = m;
+}
+
+// ================================================================================================================
+// union-add, interpolation, pruning
+// ================================================================================================================
+__global__ __launch_bounds__(256) void union_flag_kernel(const int32_t* __restrict__ b_coords, int64_t nb_cap,
+                                                         const int32_t* __restrict__ nb_dev,
+                                                         const uint64_t* __restrict__ keys,
+                                                         const int32_t* __restrict__ vals, int64_t cap,
+                                                         int32_t* __restrict__ match, uint8_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb_cap) return;
+  uint8_t f = 0;
+  if (i < live_rows(nb_cap, nb_dev)) {
+    int4 c = reinterpret_cast<const int4*>(b_coords)[i];
+    int64_t s = hash_find(keys, cap, coord_key(c.x, c.y, c.z, c.w));
+    match[i] = s >= 0 ? vals[s] : -1;
+    f = s >= 0 ? 0 : 1;
+  }
+  flag[i] = f;
+}
+
+__global__ __launch_bounds__(256) void union_copy_a_kernel(const int32_t* __restrict__ a_coords,
+                                                           const float* __restrict__ a_feats, int64_t na_cap,
+                                                           const int32_t* __restrict__ na_dev, int C,
+                                                           int32_t* __restrict__ out_coords,
+                                                           float* __restrict__ out_feats) {
+  const int64_t n = live_rows(na_cap, na_dev);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x)
+    out_feats[t] = a_feats[t];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 4; t += (int64_t)gridDim.x * blockDim.x)
+    out_coords[t] = a_coords[t];
+}
+
+__global__ __launch_bounds__(256) void union_merge_b_kernel(const int32_t* __restrict__ b_coords,
+                                                            const float* __restrict__ b_feats, int64_t nb_cap,
+                                                            const int32_t* __restrict__ nb_dev, int C,
+                                                            const int32_t* __restrict__ match,
+                                                            const int32_t* __restrict__ idx, int64_t na_cap,
+                                                            const int32_t* __restrict__ na_dev,
+                                                            uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                            int64_t cap, int32_t* __restrict__ out_coords,
+                                                            float* __restrict__ out_feats,
+                                                            const int32_t* __restrict__ n_new, int32_t* __restrict__ n_out) {
+  const int64_t nb = live_rows(nb_cap, nb_dev);
+  const int64_t na = live_rows(na_cap, na_dev);
+  if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = (int32_t)(na + n_new[0]);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nb * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
+    const int32_t m = match[i];
+    if (m >= 0) {
+      out_feats[(int64_t)m * C + c] += b_feats[t];          // unique coords in B: one writer per element
+    } else {
+      const int64_t row = na + idx[i];
+      out_feats[row * C + c] = b_feats[t];
+      if (c == 0) {
+        int4 cc = reinterpret_cast<const int4*>(b_coords)[i];
+        reinterpret_cast<int4*>(out_coords)[row] = cc;
+        int64_t s = hash_insert(keys, cap, coord_key(cc.x, cc.y, cc.z, cc.w));
+        if (s >= 0) vals[s] = (int32_t)row;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void interp_kernel(const int32_t* __restrict__ q_coords, int64_t n_cap,
+                                                     const int32_t* __restrict__ n_dev, const float* __restrict__ score,
+                                                     const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                     int64_t cap, int s, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= live_rows(n_cap, n_dev)) return;
+  int4 q = reinterpret_cast<const int4*>(q_coords)[i];
+  auto fl = [s](int p) { int r = p / s; if ((p % s != 0) && (p < 0)) --r; return r * s; };
+  const int bx = fl(q.y), by = fl(q.z), bz = fl(q.w);
+  const float fs = (float)s;
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int cx = bx + (k & 1) * s, cy = by + ((k >> 1) & 1) * s, cz = bz + ((k >> 2) & 1) * s;
+    const float w = (1.0f - fabsf((float)(q.y - cx)) / fs) * (1.0f - fabsf((float)(q.z - cy)) / fs) *
+                    (1.0f - fabsf((float)(q.w - cz)) / fs);
+    if (w == 0.0f) continue;
+    int64_t slot = hash_find(keys, cap, coord_key(q.x, cx, cy, cz));
+    if (slot >= 0) acc += w * score[vals[slot]];
+  }
+  out[i] = acc;
+}
+
+__global__ __launch_bounds__(256) void prune_kernel(const int32_t* __restrict__ in_coords,
+                                                    const float* __restrict__ in_feats, int64_t n_cap,
+                                                    const int32_t* __restrict__ n_dev, int C,
+                                                    const int32_t* __restrict__ sel, int32_t* __restrict__ out_coords,
+                                                    float* __restrict__ out_feats) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / C;
+    const int c = (int)(t - i * C);
+    const int32_t j = sel[i];
+    if (j < 0) continue;
+    out_feats[(int64_t)j * C + c] = in_feats[t];
+    if (c == 0) reinterpret_cast<int4*>(out_coords)[j] = reinterpret_cast<const int4*>(in_coords)[i];
+  }
+}
+
+inline unsigned grid_for(int64_t work, int block = 256, int64_t max_blocks = 65536) {
+  int64_t b = ceil_div(work > 0 ? work : 1, block);
+  return (unsigned)(b < max_blocks ? b : max_blocks);
+}
+
+}  // namespace
+
+// ================================================================================================================
+// C-ABI
+// ================================================================================================================
+extern "C" size_t cnrma_voxelize_workspace_bytes(int64_t M) {
+  int64_t n4 = (M + 3) / 4 * 4;
+  return (size_t)(n4 * 9) + cnrma_scan_workspace_bytes(M) + 256;
+}
+
+extern "C" int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, int C, float voxel_size,
+                                  int batch_id, uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap,
+                                  int32_t* out_coords, float* out_feats, int32_t* out_src, int32_t* n_out,
+                                  void* workspace, void* stream) {
+  if (C <= 0 || !(voxel_size > 0.0f) || out_src == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int rc = run_unique<0>(coords, M, nullptr, voxel_size, 1, batch_id, hash_keys, hash_vals, hash_cap, out_coords,
+                         out_src, n_out, workspace, st);
+  if (rc) return rc;
+  if (feats && out_feats) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(M * (int64_t)(C / 4 + 1))), dim3(256), 0, st, feats, out_src, M,
+                       n_out, C, out_feats);
+    CNRMA_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, const int32_t* n_dev, uint64_t* hash_keys,
+                                      int32_t* hash_vals, int64_t hash_cap, void* stream) {
+  if (n_cap <= 0 || hash_cap < 2 || (hash_cap & (hash_cap - 1)) != 0) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(hash_keys, 0xFF, (size_t)hash_cap * sizeof(uint64_t), st);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(build_map_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, st, coords, n_cap, n_dev,
+                     hash_keys, hash_vals, hash_cap);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_stride_coords(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev,
+                                          int new_stride, uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap,
+                                          int32_t* out_coords, int32_t* n_out, void* workspace, void* stream) {
+  if (new_stride <= 0) return CNRMA_EINVAL;
+  return run_unique<1>(in_coords, n_cap, n_dev, 1.0f, new_stride, 0, hash_keys, hash_vals, hash_cap, out_coords,
+                       nullptr, n_out, workspace, as_stream(stream));
+}
+
+extern "C" int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int32_t* no_dev,
+                                       const uint64_t* in_hash_keys, const int32_t* in_hash_vals, int64_t hash_cap,
+                                       const int32_t* offsets, int K, int32_t* nbr, void* stream) {
+  if (no_cap <= 0 || K <= 0) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(kernel_map_kernel, dim3((unsigned)ceil_div(no_cap * K, 256)), dim3(256), 0, as_stream(stream),
+                     out_coords, no_cap, no_dev, in_hash_keys, in_hash_vals, hash_cap, offsets, K, nbr);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight,
+                                     int Cout, const float* scale, const float* shift, const float* residual, int act,
+                                     float* out_feats, int64_t no_cap, const int32_t* no_dev, void* stream) {
+  return launch_conv(in_feats, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
+                     as_stream(stream));
+}
+
+extern "C" int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap,
+                                           const int32_t* n_dev, int Cin, int half_stride, const float* weight,
+                                           int Cout, const float* scale, const float* shift, int act,
+                                           int32_t* out_coords, float* out_feats, void* stream) {
+  if (n_cap <= 0 || half_stride <= 0) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(convtr_coords_kernel, dim3((unsigned)ceil_div(n_cap * 8, 256)), dim3(256), 0, st, in_coords,
+                     n_cap, n_dev, half_stride, out_coords);
+  // 8 weight slices; slice k reads in[i] (identity map, K = 1) and writes row k*n + i
+  return launch_conv(in_feats, Cin, nullptr, 1, weight, Cout, scale, shift, nullptr, act, out_feats, n_cap, n_dev, 8, st);
+}
+
+extern "C" int cnrma_sparse_maxpool_f32(const float* in_feats, int C, const int32_t* nbr, int K, float* out_feats,
+                                        int64_t no_cap, const int32_t* no_dev, void* stream) {
+  if (no_cap <= 0 || C <= 0 || K <= 0) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)ceil_div(no_cap * C, 256)), dim3(256), 0, as_stream(stream),
+                     in_feats, C, nbr, K, out_feats, no_cap, no_dev);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t cnrma_instnorm_workspace_bytes(int C) { return (size_t)(256 * 2 * C + 2 * C) * sizeof(double); }
+
+extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, int C,
+                                         const float* weight, const float* bias, float eps, int relu,
+                                         float* out_feats, double* stats_ws, void* stream) {
+  if (n_cap <= 0 || C <= 0 || C > 256) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = 256;
+  double* part = stats_ws + 2 * C;
+  hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, in_feats, n_cap, n_dev, C, part);
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, st, part, nblk, C, n_cap,
+                     n_dev, stats_ws);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, st, in_feats, n_cap,
+                     n_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_union_add_f32(const int32_t* a_coords, const float* a_feats, int64_t na_cap,
+                                          const int32_t* na_dev, const int32_t* b_coords, const float* b_feats,
+                                          int64_t nb_cap, const int32_t* nb_dev, int C, uint64_t* a_hash_keys,
+                                          int32_t* a_hash_vals, int64_t hash_cap, int32_t* out_coords,
+                                          float* out_feats, int32_t* n_out, void* workspace, void* stream) {
+  if (na_cap <= 0 || nb_cap <= 0 || C <= 0) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  // workspace: match[nb] int32, idx[nb] int32, flag[nb] u8, n_new int32, scan ws
+  char* p = reinterpret_cast<char*>(workspace);
+  int64_t n4 = (nb_cap + 3) / 4 * 4;
+  int32_t* match = reinterpret_cast<int32_t*>(p); p += n4 * 4;
+  int32_t* idx = reinterpret_cast<int32_t*>(p); p += n4 * 4;
+  uint8_t* flag = reinterpret_cast<uint8_t*>(p); p += n4;
+  int32_t* n_new = reinterpret_cast<int32_t*>(p); p += 16;
+  hipLaunchKernelGGL(union_flag_kernel, dim3((unsigned)ceil_div(nb_cap, 256)), dim3(256), 0, st, b_coords, nb_cap,
+                     nb_dev, a_hash_keys, a_hash_vals, hash_cap, match, flag);
+  int rc = cnrma_mask_to_index(flag, idx, n_new, nb_cap, p, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(union_copy_a_kernel, dim3(grid_for(na_cap * C, 256, 4096)), dim3(256), 0, st, a_coords, a_feats,
+                     na_cap, na_dev, C, out_coords, out_feats);
+  hipLaunchKernelGGL(union_merge_b_kernel, dim3(grid_for(nb_cap * C, 256, 4096)), dim3(256), 0, st, b_coords, b_feats,
+                     nb_cap, nb_dev, C, match, idx, na_cap, na_dev, a_hash_keys, a_hash_vals, hash_cap, out_coords,
+                     out_feats, n_new, n_out);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t cnrma_union_workspace_bytes(int64_t nb) {
+  int64_t n4 = (nb + 3) / 4 * 4;
+  return (size_t)(n4 * 9 + 16) + cnrma_scan_workspace_bytes(nb) + 256;
+}
+
+extern "C" int cnrma_sparse_interp_f32(const int32_t* q_coords, int64_t n_cap, const int32_t* n_dev,
+                                       const float* score, const uint64_t* s_hash_keys, const int32_t* s_hash_vals,
+                                       int64_t hash_cap, int score_stride, float* out, void* stream) {
+  if (n_cap <= 0 || score_stride <= 0) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(interp_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, as_stream(stream), q_coords,
+                     n_cap, n_dev, score, s_hash_keys, s_hash_vals, hash_cap, score_stride, out);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_prune_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap,
+                                      const int32_t* n_dev, int C, const int32_t* sel_index, int32_t* out_coords,
+                                      float* out_feats, void* stream) {
+  if (n_cap <= 0 || C <= 0) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(prune_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, as_stream(stream), in_coords,
+                     in_feats, n_cap, n_dev, C, sel_index, out_coords, out_feats);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rowmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out, void* stream) {
+  if (n_cap <= 0 || C <= 0) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, as_stream(stream), in, n_cap,
+                     n_dev, C, out);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}

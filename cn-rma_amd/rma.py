@@ -1,0 +1,278 @@
+"""Host mirror of the aggregation half of the reference's ray_marching.py.
+
+Every function here drives the HIP kernels of csrc/ through the C-ABI (include/cnrma.h); torch only owns the
+device buffers and the stream.  Names and argument meaning follow the reference:
+
+    backproject / aggregate_2d_features / clear_3d_features   -> backproject_accum()
+    get_ray_parameter                                         -> projection_inverse() + ray_params()
+    ray_projection_neus / ray_projection_depth                -> rma_view_rows()  (reference layout, per view)
+    aggregate_2d_features_ray_marching + switch_pointcloud    -> aggregate_points()  (fused production path)
+
+Reference: projects/mvsdetection/models/ray_marching.py (line numbers in each docstring).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _f32(t):
+    return t.contiguous().to(torch.float32)
+
+
+def step_length(dims, voxel_size, n_steps):
+    """t_one as the Python double of ray_marching.py:710-711."""
+    X, Y, Z = dims
+    return math.sqrt(X ** 2 + Y ** 2 + Z ** 2) * voxel_size / n_steps
+
+
+def scale_projection(projection, stride):
+    """rows 0-1 divided by backbone2d_stride (ray_marching.py:238-239 / :275-276). projection [...,3,4]."""
+    p = projection.clone()
+    p[..., :2, :] = p[..., :2, :] / stride
+    return p
+
+
+def to_nhwc(features):
+    """features [V,C,H,W] (reference layout) -> channels-last [V,H,W,C] on the device (one HIP pass)."""
+    _lib.require_gpu()
+    features = _f32(features)
+    V, C, H, W = features.shape
+    out = torch.empty((V, H, W, C), dtype=torch.float32, device=features.device)
+    call("cnrma_nchw_to_nhwc_f32", ptr(features), ptr(out), V, C, H, W, stream())
+    return out
+
+
+def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stride):
+    """Dense unprojection of all views + mean (ray_marching.py:21-69, :220-257) in one kernel.
+
+    features_nhwc [V,H,W,C] device fp32; projections [V,3,4] full-resolution (scaled here by `stride`).
+    Returns volume [C,X,Y,Z] (mean over the views that see the voxel, 0 elsewhere) and count [X,Y,Z] int32;
+    the reference's `valid` is `count > 0`.
+    """
+    _lib.require_gpu()
+    V, H, W, C = features_nhwc.shape
+    X, Y, Z = dims
+    dev = features_nhwc.device
+    proj = _f32(scale_projection(projections.to(torch.float32), stride)).to(dev)
+    volume = torch.empty((C, X, Y, Z), dtype=torch.float32, device=dev)
+    count = torch.empty((X, Y, Z), dtype=torch.int32, device=dev)
+    call("cnrma_backproject_accum_f32", ptr(features_nhwc), ptr(proj), V, C, H, W, X, Y, Z, float(voxel_size),
+         float(origin[0]), float(origin[1]), float(origin[2]), ptr(volume), ptr(count), stream())
+    return volume, count
+
+
+def backproject_index(projection_scaled, hw, dims, voxel_size, origin, device):
+    """Debug/parity: rounded pixel (px, py) and validity of every voxel for ONE view (ray_marching.py:51-58)."""
+    _lib.require_gpu()
+    H, W = hw
+    X, Y, Z = dims
+    G = X * Y * Z
+    proj = _f32(projection_scaled).to(device)
+    px = torch.empty(G, dtype=torch.int32, device=device)
+    py = torch.empty(G, dtype=torch.int32, device=device)
+    valid = torch.empty(G, dtype=torch.uint8, device=device)
+    call("cnrma_backproject_index_f32", ptr(proj), H, W, X, Y, Z, float(voxel_size), float(origin[0]),
+         float(origin[1]), float(origin[2]), ptr(px), ptr(py), ptr(valid), stream())
+    return px, py, valid
+
+
+def projection_inverse(projections, stride):
+    """[V,3,4] full-res -> [V,4,4] inverse of [P/stride; 0 0 0 1], computed with torch.inverse on the HOST in fp32,
+    one matrix at a time, exactly as ray_marching.py:96-102 does, so that it is bit-identical to the reference's
+    CPU run.  (V 4x4 LAPACK calls: microseconds; this is the only host arithmetic on the path.)"""
+    p = scale_projection(projections.detach().to("cpu", torch.float32), stride)
+    last = torch.tensor([[0.0, 0.0, 0.0, 1.0]])
+    return torch.stack([torch.inverse(torch.cat((p[v], last), dim=0)) for v in range(p.shape[0])], dim=0)
+
+
+def ray_params(proj_inv, H, W):
+    """get_ray_parameter (ray_marching.py:71-111): o [V,3], d [V,3,H*W] on the device of proj_inv."""
+    _lib.require_gpu()
+    V = proj_inv.shape[0]
+    o = torch.empty((V, 3), dtype=torch.float32, device=proj_inv.device)
+    d = torch.empty((V, 3, H * W), dtype=torch.float32, device=proj_inv.device)
+    call("cnrma_ray_params_f32", ptr(_f32(proj_inv)), V, H, W, ptr(o), ptr(d), stream())
+    return o, d
+
+
+class _March:
+    """Argument pack shared by the count / emit calls of one scene."""
+
+    def __init__(self, features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids):
+        self.feat = features_nhwc
+        self.V, self.H, self.W, self.C = features_nhwc.shape
+        self.dev = features_nhwc.device
+        self.pinv = _f32(proj_inv).to(self.dev)
+        self.tsdf = _f32(tsdf).to(self.dev)
+        self.X, self.Y, self.Z = dims
+        assert self.tsdf.numel() == self.X * self.Y * self.Z
+        self.vs = float(voxel_size)
+        self.org = [float(x) for x in origin]
+        self.N = int(n_steps)
+        self.t_one = float(step_length(dims, voxel_size, n_steps))
+        self.thr = float(thr) if thr is not None else 0.0
+        self.mode = mode
+        self.k = int(select_grids or 0)
+        self.R = self.V * self.H * self.W
+
+    def count(self):
+        cnt = torch.empty(self.R, dtype=torch.int32, device=self.dev)
+        wsum = torch.empty(self.R, dtype=torch.float64, device=self.dev)
+        head = (ptr(self.pinv), ptr(self.tsdf), self.V, self.H, self.W, self.X, self.Y, self.Z, self.vs, *self.org,
+                self.N, self.t_one)
+        if self.mode == "neus":
+            call("cnrma_rma_neus_count_f32", *head, self.thr, ptr(cnt), ptr(wsum), stream())
+        else:
+            call("cnrma_rma_depth_count_f32", *head, self.k, ptr(cnt), ptr(wsum), stream())
+        return cnt, wsum
+
+    def emit(self, row_offset, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride,
+             out_sample=None):
+        head = (ptr(self.pinv), ptr(self.tsdf), ptr(self.feat), self.V, self.C, self.H, self.W, self.X, self.Y, self.Z,
+                self.vs, *self.org, self.N, self.t_one)
+        tail = (ptr(row_offset), ptr(sel_index), ptr(w_div), float(add[0]), float(add[1]), float(add[2]),
+                out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride)
+        if self.mode == "neus":
+            call("cnrma_rma_neus_emit_f32", *head, self.thr, *tail, ptr(out_sample), stream())
+        else:
+            call("cnrma_rma_depth_emit_f32", *head, self.k, *tail, stream())
+
+
+def exclusive_scan(count):
+    """int32 [n] -> int32 [n+1] exclusive prefix sums (last entry = total), on the device."""
+    n = count.numel()
+    out = torch.empty(n + 1, dtype=torch.int32, device=count.device)
+    ws = torch.empty(_lib.load().cnrma_scan_workspace_bytes(n), dtype=torch.uint8, device=count.device)
+    call("cnrma_exclusive_scan_i32", ptr(count), ptr(out), n, ptr(ws), stream())
+    return out
+
+
+def mask_to_index(mask_u8):
+    """uint8 [n] keep-mask -> (sel_index int32 [n], n_sel int32 [1]) on the device."""
+    n = mask_u8.numel()
+    sel = torch.empty(n, dtype=torch.int32, device=mask_u8.device)
+    n_sel = torch.empty(1, dtype=torch.int32, device=mask_u8.device)
+    ws = torch.empty(_lib.load().cnrma_scan_workspace_bytes(n), dtype=torch.uint8, device=mask_u8.device)
+    call("cnrma_mask_to_index", ptr(mask_u8), ptr(sel), ptr(n_sel), n, ptr(ws), stream())
+    return sel, n_sel
+
+
+def _drop_single_sample_views(cnt, wsum, V):
+    """Reference quirk: a view that keeps exactly ONE sample is dropped entirely -- torch.squeeze() makes the
+    index 0-dim, len() raises and the bare except skips the view (ray_marching.py:781-782, :282-287)."""
+    per_view = cnt.view(V, -1).sum(dim=1)
+    keep = (per_view != 1).to(cnt.dtype).view(V, 1)
+    cnt.view(V, -1).mul_(keep)
+    wsum.view(V, -1).mul_(keep.to(wsum.dtype))
+
+
+def rma_view_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
+                  select_grids=0, with_samples=False):
+    """Raw rows in the reference's own layout [M, 3+1+C] = [x,y,z,w,feat] for ALL given views, view-major
+    (ray_projection_neus :687-807 / ray_projection_depth :809-956), plus per-view row counts [V].
+    With `with_samples` also returns int32 [M,2] = (ray index over all views, step) per row."""
+    _lib.require_gpu()
+    m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids)
+    cnt, wsum = m.count()
+    off = exclusive_scan(cnt)
+    M = int(off[-1].item())
+    per_view = cnt.view(m.V, -1).sum(dim=1)
+    Wd = 4 + m.C
+    rows = torch.empty((M, Wd), dtype=torch.float32, device=m.dev)
+    samples = torch.empty((M, 2), dtype=torch.int32, device=m.dev) if with_samples else None
+    if M > 0:
+        base = rows.data_ptr()
+        m.emit(off, None, None, (0.0, 0.0, 0.0), base, Wd, base + 12, Wd, base + 16, Wd, samples)
+    return (rows, per_view, samples) if with_samples else (rows, per_view)
+
+
+def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
+                     select_grids=0, offset=(0.0, 0.0, 0.0), max_points=None, sampler="numpy", mask=None,
+                     reference_quirks=True):
+    """Fused aggregate_2d_features_ray_marching (:260-307) + switch_pointcloud test path (:339-407).
+
+    Returns (coords [Ms,3], feats [Ms,C], info).  feats = feature * (w / mean(w)) with the mean over ALL M rows of
+    the scene (:303); coords = place + offset (:364); when max_points is set and M > max_points only the rows of
+    the keep-mask are written (sample_points, fcaf3d_transforms.py:283-296), order preserved.
+
+    sampler: "numpy"  -- the mask comes from numpy's global RNG exactly like the reference (host, bit-parity);
+             "device" -- a uniformly random mask with exactly max_points ones drawn on the GPU (same
+                         distribution, different RNG stream; no host RNG on the critical path).
+    mask:    optional explicit keep-mask (numpy bool / torch uint8 of length M); overrides `sampler`.
+    """
+    _lib.require_gpu()
+    m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids)
+    cnt, wsum = m.count()
+    if reference_quirks:
+        _drop_single_sample_views(cnt, wsum, m.V)
+    off = exclusive_scan(cnt)
+    ws = torch.empty(_lib.load().cnrma_scan_workspace_bytes(m.R), dtype=torch.uint8, device=m.dev)
+    wtot = torch.empty(1, dtype=torch.float64, device=m.dev)
+    mean_w = torch.empty(1, dtype=torch.float32, device=m.dev)
+    call("cnrma_sum_f64", ptr(wsum), ptr(wtot), m.R, ptr(ws), stream())
+    m_total = off[m.R:]
+    call("cnrma_rma_mean_weight", ptr(wtot), m_total.data_ptr(), ptr(mean_w), stream())
+    M = int(m_total.item())   # the one read-back the reference also has (nonzero(), :781)
+    if M == 0:
+        raise TypeError("no valid points in any view (ray_marching.py:300)")
+    sel = None
+    Ms = M
+    if mask is not None or (max_points is not None and M > max_points):
+        Ms = None
+        if mask is None:
+            Ms = int(max_points)
+            if sampler == "numpy":
+                mask = np.zeros(M, dtype=bool)
+                mask[np.random.choice(M, max_points, replace=False)] = True
+            elif sampler == "device":
+                mask = torch.zeros(M, dtype=torch.uint8, device=m.dev)
+                mask[torch.randperm(M, device=m.dev)[:max_points]] = 1
+            else:
+                raise ValueError(f"unknown sampler {sampler!r}")
+        if isinstance(mask, np.ndarray):
+            if Ms is None:
+                Ms = int(mask.sum())
+            mask = torch.from_numpy(mask.astype(np.uint8))
+        mask = mask.to(device=m.dev, dtype=torch.uint8).contiguous()
+        assert mask.numel() == M, "mask length must equal the number of aggregated rows"
+        sel, n_sel = mask_to_index(mask)
+        if Ms is None:
+            Ms = int(n_sel.item())
+    coords = torch.empty((Ms, 3), dtype=torch.float32, device=m.dev)
+    feats = torch.empty((Ms, m.C), dtype=torch.float32, device=m.dev)
+    m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
+    info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, per_view=cnt.view(m.V, -1).sum(dim=1))
+    return coords, feats, info
+
+
+def aggregate_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
+                   select_grids=0, reference_quirks=True):
+    """points_detection of the reference after :298-307: [M, 3+C] = [xyz, feat * w/mean(w)] (no offset, no mask)."""
+    coords, feats, info = aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode,
+                                           select_grids, reference_quirks=reference_quirks)
+    return torch.cat((coords, feats), dim=1), info
+
+
+def select_rows(points, offset, mask=None):
+    """switch_pointcloud test path on an existing [M,3+C] matrix (ray_marching.py:360-405)."""
+    _lib.require_gpu()
+    points = _f32(points)
+    M, Wd = points.shape
+    C = Wd - 3
+    sel = None
+    Ms = M
+    if mask is not None:
+        if isinstance(mask, np.ndarray):
+            mask = torch.from_numpy(mask.astype(np.uint8))
+        mask = mask.to(device=points.device, dtype=torch.uint8).contiguous()
+        sel, _ = mask_to_index(mask)
+        Ms = int(mask.sum().item())
+    coords = torch.empty((Ms, 3), dtype=torch.float32, device=points.device)
+    feats = torch.empty((Ms, C), dtype=torch.float32, device=points.device)
+    call("cnrma_select_rows_f32", ptr(points), M, C, ptr(sel), float(offset[0]), float(offset[1]), float(offset[2]),
+         ptr(coords), ptr(feats), stream())
+    return coords, feats

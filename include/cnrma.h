@@ -1,0 +1,237 @@
+/*
+ * cnrma.h -- C-ABI of libcnrma_hip.so: the MI355X (gfx950) hot path of CN-RMA.
+ *
+ * The reference (SerCharles/CN-RMA) is pure Python over third-party CUDA packages; it has no native ABI of
+ * its own.  This header is therefore the boundary a maintainer binds with ctypes: every
+ * entry point names the reference Python it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; buffers are caller-owned (torch
+ *     allocates them); the library never allocates, frees or synchronises unless stated;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, in order;
+ *   - return value: 0 = ok, negative = -(hipError_t) of the failed launch or CNRMA_EINVAL for bad arguments;
+ *   - fp32 everywhere the reference is fp32; integer outputs are int32;
+ *   - feature maps are consumed channels-last ("NHWC": [V][H][W][C]); cnrma_nchw_to_nhwc_f32 converts the
+ *     reference's NCHW layout in one pass;
+ *   - re-entrant: no global mutable state.
+ */
+#ifndef CNRMA_H
+#define CNRMA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNRMA_EINVAL (-22)
+#define CNRMA_ABI_VERSION 1
+
+int cnrma_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * layout helper: feat_nchw[V][C][H][W] -> feat_nhwc[V][H][W][C]
+ * (the reference keeps NCHW: projects/mvsdetection/models/ray_marching.py:64 and :799 gather [b,:,py,px])
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_nchw_to_nhwc_f32(const float* feat_nchw, float* feat_nhwc, int V, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a1-a3  dense unprojection + accumulate + mean
+ * replaces: coordinates()            projects/mvsdetection/datasets/tsdf.py:14-29
+ *           backproject()            projects/mvsdetection/models/ray_marching.py:21-69
+ *           aggregate_2d_features()  ray_marching.py:220-244   (sum over views, in view order)
+ *           clear_3d_features()      ray_marching.py:247-257   (divide by count, zero unseen voxels)
+ * proj[V][3][4]: rows 0-1 already divided by backbone2d_stride (ray_marching.py:238-239).
+ * volume[C][X][Y][Z] (mean, 0 where count == 0), count[X][Y][Z] int32 (number of views that see the voxel).
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
+                                int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                float* volume, int32_t* count, void* stream);
+
+/* single view, debug/parity: px,py int32 [G] (rounded pixel, INT32_MIN when not finite), valid uint8 [G] */
+int cnrma_backproject_index_f32(const float* proj_view, int H, int W, int X, int Y, int Z, float voxel_size,
+                                float ox, float oy, float oz, int32_t* px, int32_t* py, uint8_t* valid,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a4  ray parameters      replaces get_ray_parameter()  ray_marching.py:71-111
+ * proj_inv[V][4][4] = torch.inverse([P;0 0 0 1]) computed by the host (kept on the host LAPACK so that it is
+ * bit-identical to the reference's call at ray_marching.py:100).  o[V][3], d[V][3][H*W].
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_ray_params_f32(const float* proj_inv, int V, int H, int W, float* o, float* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a5/a7  NeuS ray-marching aggregation, two phases (variable-length output)
+ * replaces: ray_projection_neus()                 ray_marching.py:687-807
+ *           aggregate_2d_features_ray_marching()  ray_marching.py:260-307 (concat of views, w/mean(w) scaling)
+ * All V views in one launch; one lane per ray, steps marched in order (fp64 running product like the CPU
+ * cumprod at :760).  t_one = sqrt(X^2+Y^2+Z^2)*voxel_size/N as computed in double by the host, rounded to fp32
+ * (:710-714).  Sample order everywhere = (view, row, col, step).
+ *
+ * phase 1  count[V*H*W] int32 kept samples per ray; wsum[V*H*W] fp64 sum of kept weights per ray.
+ * then     cnrma_exclusive_scan_i32(count) -> row_offset[V*H*W+1]  (row_offset[last] = M).
+ * phase 2  writes rows.  Destination is described by three strided views so that the same kernel serves
+ *            (i) the reference's raw rows [M][4+C]      (xyz=rows, w=rows+3, feat=rows+4, all stride 4+C) and
+ *            (ii) the fused production layout: coords[Ms][3] (+offset), feats[Ms][C] * (w * inv_mean) with the
+ *                 subsample mask of sample_points() applied (fcaf3d_transforms.py:283-296, ray_marching.py:364-405).
+ *          sel_index: NULL = every row m goes to output row m; else int32[M], output row of source row m or -1
+ *          (an exclusive prefix sum of the keep-mask, -1 where dropped).
+ *          w_div: NULL = store features unscaled; else a DEVICE scalar (mean weight, see cnrma_rma_mean_weight):
+ *                 features are multiplied by (w / w_div[0]) (:303-304).
+ *          out_sample: NULL or int32 [M][2] = (ray index, step) of every row (alignment aid for parity tests).
+ *          add[3]: added to xyz (the scene offset of switch_pointcloud, :364); pass zeros for raw rows.
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_rma_neus_count_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y, int Z,
+                             float voxel_size, float ox, float oy, float oz, int n_steps, float t_one, float thr,
+                             int32_t* count, double* wsum, void* stream);
+
+int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const float* feat_nhwc, int V, int C, int H,
+                            int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz, int n_steps,
+                            float t_one, float thr, const int32_t* row_offset, const int32_t* sel_index,
+                            const float* w_div, float addx, float addy, float addz,
+                            float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                            int feat_stride, int32_t* out_sample, void* stream);
+
+/* a6  depth variant   replaces ray_projection_depth()  ray_marching.py:809-956
+ * Every ray emits exactly NUM = max(1, 2*select_grids) candidate slots; count[ray] = number of slots with
+ * weight > 0.  Same two-phase protocol and destination description as the NeuS pair. */
+int cnrma_rma_depth_count_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y, int Z,
+                              float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
+                              int select_grids, int32_t* count, double* wsum, void* stream);
+
+int cnrma_rma_depth_emit_f32(const float* proj_inv, const float* tsdf, const float* feat_nhwc, int V, int C, int H,
+                             int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                             int n_steps, float t_one, int select_grids, const int32_t* row_offset,
+                             const int32_t* sel_index, const float* w_div, float addx, float addy, float addz,
+                             float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                             int feat_stride, void* stream);
+
+/* mean_w[0] = (float)(wsum_total[0] / m_total[0])   -- torch.mean(weights), ray_marching.py:303 */
+int cnrma_rma_mean_weight(const double* wsum_total, const int32_t* m_total, float* mean_w, void* stream);
+
+/* utilities used between the phases (device-side; no host sync) */
+size_t cnrma_scan_workspace_bytes(int64_t n);
+/* out[0..n] (n+1 entries): out[i] = sum(in[0..i-1]) */
+int cnrma_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* workspace, void* stream);
+/* sum of n doubles -> out[0] */
+int cnrma_sum_f64(const double* in, double* out, int64_t n, void* workspace, void* stream);
+/* mask uint8[n] -> sel_index int32[n] (exclusive rank where mask, -1 elsewhere); total written to n_sel[0] */
+int cnrma_mask_to_index(const uint8_t* mask, int32_t* sel_index, int32_t* n_sel, int64_t n, void* workspace,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a8  switch_pointcloud (test path) on an existing point matrix
+ * replaces ray_marching.py:360-405: coord = xyz + offset, keep rows where mask (order preserved).
+ * points[M][3+C] -> coords[Ms][3], feats[Ms][C]; sel_index as above (NULL = keep all).
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_select_rows_f32(const float* points, int64_t M, int C, const int32_t* sel_index, float addx, float addy,
+                          float addz, float* coords, float* feats, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a9  voxelisation = ME.utils.batch_sparse_collate + ME.SparseTensor(quantization_mode=RANDOM_SUBSAMPLE)
+ * replaces ray_marching.py:328-330 (MinkowskiEngine v0.5.4; semantics SURVEY.md Appendix A).
+ * q = floor(coord / voxel_size) (true fp32 division) -> int32, batch id prepended; duplicate voxels collapse
+ * to the row with the SMALLEST source index (the CPU behaviour of ME); output in order of first occurrence.
+ * hash_keys uint64[hash_cap], hash_vals int32[hash_cap]: open-addressing table, hash_cap a power of two >= 2*M;
+ * on return it maps voxel key -> output row (reusable as the coordinate map of the level).
+ * out_coords int32[Mu][4] (b,x,y,z), out_feats[Mu][C], out_src int32[Mu], n_out[0] = Mu (device).
+ * workspace: cnrma_voxelize_workspace_bytes(M).
+ * ---------------------------------------------------------------------------------------------------------- */
+size_t cnrma_voxelize_workspace_bytes(int64_t M);
+int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, int C, float voxel_size, int batch_id,
+                       uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap, int32_t* out_coords,
+                       float* out_feats, int32_t* out_src, int32_t* n_out, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a10-a11  sparse operators (replace the MinkowskiEngine v0.5.4 surface used by
+ *          projects/mvsdetection/models/fcaf3d_backbone.py:26-31,63-70 and fcaf3d_head.py:64-98,107-139,275-298)
+ * Coordinates: int32 [N][4] = (batch, x, y, z) at an explicit tensor stride; features fp32 [N][C] row-major.
+ * Row counts that are produced on the device are written to int32 device words (n_out) and all kernels that
+ * consume such a tensor take BOTH a capacity (grid sizing) and a device pointer to the live row count, so a whole
+ * forward can be enqueued without host synchronisation.  Pass n_dev = NULL to use the capacity as the count.
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* coordinate map: build a hash table key(coords[i]) -> i for N unique coordinates */
+int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, const int32_t* n_dev, uint64_t* hash_keys,
+                           int32_t* hash_vals, int64_t hash_cap, void* stream);
+
+/* strided output coordinate set: unique(floor(p / new_stride) * new_stride) in first-occurrence order
+ * (MinkowskiConvolution / MinkowskiMaxPooling with stride 2: fcaf3d_backbone.py:26-31, BasicBlock stride 2).
+ * Builds the output map (hash) as well.  workspace: cnrma_voxelize_workspace_bytes(n_cap). */
+int cnrma_sparse_stride_coords(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int new_stride,
+                               uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap, int32_t* out_coords,
+                               int32_t* n_out, void* workspace, void* stream);
+
+/* neighbour table ("kernel map", output-stationary): nbr[No][K] = input row at out_coord + offset[k], or -1.
+ * offsets int32 [K][3] in coordinate units (already multiplied by the tensor stride), k with x fastest. */
+int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int32_t* no_dev,
+                            const uint64_t* in_hash_keys, const int32_t* in_hash_vals, int64_t hash_cap,
+                            const int32_t* offsets, int K, int32_t* nbr, void* stream);
+
+/* fused sparse convolution, output-stationary gather-GEMM on fp32 MFMA:
+ *   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift + residual[o] )
+ * W[K][Cin][Cout] (ME "kernel" layout), scale/shift per output channel (folded BatchNorm / bias; NULL = 1 / 0),
+ * residual [No][Cout] or NULL, act: 0 none, 1 ReLU, 2 ELU(alpha=1).  nbr == NULL means K == 1 identity map. */
+int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight, int Cout,
+                          const float* scale, const float* shift, const float* residual, int act,
+                          float* out_feats, int64_t no_cap, const int32_t* no_dev, void* stream);
+
+/* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
+ * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */
+int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap, const int32_t* n_dev,
+                                int Cin, int half_stride, const float* weight, int Cout, const float* scale,
+                                const float* shift, int act, int32_t* out_coords, float* out_feats, void* stream);
+
+/* max pooling over the neighbour table (MinkowskiMaxPooling k=2 s=2, fcaf3d_backbone.py:31) */
+int cnrma_sparse_maxpool_f32(const float* in_feats, int C, const int32_t* nbr, int K, float* out_feats,
+                             int64_t no_cap, const int32_t* no_dev, void* stream);
+
+/* MinkowskiInstanceNorm (single scene): per-channel mean / biased variance over all rows, eps = 1e-8,
+ * affine (weight, bias), optional ReLU (fcaf3d_backbone.py:29-30).  stats_ws: cnrma_instnorm_workspace_bytes(C);
+ * on return stats_ws[0..C) = mean, [C..2C) = biased variance (fp64). */
+size_t cnrma_instnorm_workspace_bytes(int C);
+int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, int C, const float* weight,
+                              const float* bias, float eps, int relu, float* out_feats, double* stats_ws,
+                              void* stream);
+
+/* union-add of two sparse tensors at the same tensor stride (`inputs[i] + x`, fcaf3d_head.py:114):
+ * output rows = all rows of A (in order) followed by the rows of B that are not in A.
+ * a_hash maps A's coords -> A rows.  out_coords [Na+Nb cap][4], out_feats likewise; n_out device word.
+ * On return the A hash additionally maps B-only coords -> their new rows (it becomes the union's map). */
+size_t cnrma_union_workspace_bytes(int64_t nb);
+int cnrma_sparse_union_add_f32(const int32_t* a_coords, const float* a_feats, int64_t na_cap, const int32_t* na_dev,
+                               const int32_t* b_coords, const float* b_feats, int64_t nb_cap, const int32_t* nb_dev,
+                               int C, uint64_t* a_hash_keys, int32_t* a_hash_vals, int64_t hash_cap,
+                               int32_t* out_coords, float* out_feats, int32_t* n_out, void* workspace,
+                               void* stream);
+
+/* features_at_coordinates (linear interpolation on the coarser lattice, fcaf3d_head.py:129):
+ * out[i] = sum over the 8 corners c of floor(q/s)*s + {0,s}^3 of score[c] * prod_d (1 - |q_d - c_d| / s),
+ * missing corners contribute 0.  q = query coords (int32 [N][4]), score [Ns][1]. */
+int cnrma_sparse_interp_f32(const int32_t* q_coords, int64_t n_cap, const int32_t* n_dev, const float* score,
+                            const uint64_t* s_hash_keys, const int32_t* s_hash_vals, int64_t hash_cap,
+                            int score_stride, float* out, void* stream);
+
+/* MinkowskiPruning by keep-mask (fcaf3d_head.py:138): rows kept in order. sel_index from cnrma_mask_to_index. */
+int cnrma_sparse_prune_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap, const int32_t* n_dev,
+                           int C, const int32_t* sel_index, int32_t* out_coords, float* out_feats, void* stream);
+
+/* row-wise max over channels (scores.features.max(dim=1), fcaf3d_head.py:280) */
+int cnrma_rowmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * a12  box decoding   replaces FCAF3DHead._bbox_pred_to_bbox  fcaf3d_head.py:300-349 and the score product of
+ *      _get_bboxes_single :249  (scores = sigmoid(cls) * sigmoid(centerness)).
+ * points int32 coords [n][4] are scaled by voxel_size (:296); reg[n][R] holds exp()'d distances in 0..5 and raw
+ * angle terms in 6.. ; yaw_mode: 0 = 6-DoF (R=6), 1 = 'fcaf3d' (R=8 -> 7), 2 = 'sin-cos' (R=8 -> 7), 3 = 'naive' (R=7).
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_fcaf3d_decode_f32(const float* points_xyz, const float* reg, int R, int64_t n, int yaw_mode,
+                            float* boxes, void* stream);
+int cnrma_fcaf3d_scores_f32(const float* cls, const float* centerness, int64_t n, int n_cls, float* scores,
+                            float* max_score, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNRMA_H */

@@ -1,0 +1,38 @@
+"""Shared helpers for the parity tests."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCENES = ["tiny", "tiny_boxes_origin", "mini_p", "edge_empty_view"]
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, f"rma_{name}.npz"))
+    g = {k: z[k] for k in z.files}
+    g["dims"] = tuple(int(x) for x in g["dims"])
+    g["voxel_size"] = float(g["voxel_size"])
+    g["stride"] = int(g["stride"])
+    g["thr"] = float(g["thr"])
+    g["n_steps"] = int(g["n_steps"])
+    g["origin"] = tuple(float(x) for x in g["origin"])
+    return g
+
+
+def t(a, device=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return x.to(device) if device is not None else x
+
+
+def bits_equal(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.dtype.kind == "f":
+        return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)) | ((a == 0) & (b == 0))
+    return a == b
+
+
+def count_mismatch(a, b):
+    return int(np.count_nonzero(~bits_equal(a, b)))
