@@ -1,0 +1,179 @@
+"""torch.nn modules with the parameter names of the MinkowskiEngine layers the reference builds, executing on the
+HIP sparse engine (sparse.py).  State-dict keys match ME's so that the reference's checkpoints load unchanged:
+convolutions own `kernel` ([K,Cin,Cout], or [Cin,Cout] when K == 1) and optionally `bias` ([1,Cout]);
+MinkowskiBatchNorm owns `bn.*` (an nn.BatchNorm1d); MinkowskiInstanceNorm owns `weight`/`bias` ([1,C]).
+
+Inference (eval mode) fuses conv + BatchNorm + activation (+ residual) into one kernel launch; FusedSequential
+does that pattern matching for the reference's nn.Sequential(conv, BN, ELU) blocks without changing key names.
+Reference: projects/mvsdetection/models/fcaf3d_backbone.py:14-107, fcaf3d_head.py:61-98 and
+MinkowskiEngine/modules/resnet_block.py (BasicBlock; third-party).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import sparse as S
+
+
+class MinkowskiConvolution(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, dilation=1, bias=False, dimension=3):
+        super().__init__()
+        assert dimension == 3 and dilation == 1
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = kernel_size, stride
+        kv = kernel_size ** 3
+        shape = (kv, in_channels, out_channels) if kv > 1 else (in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.zeros(1, out_channels)) if bias else None
+        # ME's default init: uniform(-stdv, stdv), stdv = 1/sqrt(in_channels * kernel_volume)
+        stdv = 1.0 / math.sqrt(in_channels * kv)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+
+    def forward(self, x, scale=None, shift=None, residual=None, act=None):
+        if shift is None and self.bias is not None:
+            shift = self.bias.view(-1).contiguous()
+        return S.conv(x, self.kernel, self.kernel_size, self.stride, scale, shift, residual, act)
+
+
+class MinkowskiGenerativeConvolutionTranspose(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=2, bias=False, dimension=3):
+        super().__init__()
+        assert dimension == 3 and kernel_size == 2 and stride == 2 and not bias
+        self.kernel = nn.Parameter(torch.empty(8, in_channels, out_channels))
+        stdv = 1.0 / math.sqrt(in_channels * 8)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+
+    def forward(self, x, scale=None, shift=None, act=None):
+        return S.conv_transpose_generative(x, self.kernel, scale, shift, act)
+
+
+class MinkowskiBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
+        self._folded = {}
+
+    def train(self, mode=True):
+        self._folded = {}
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._folded = {}
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def folded(self, bias=None):
+        """(scale, shift) of the eval-mode affine map, cached until train()/load_state_dict()/device change."""
+        key = (None if bias is None else bias.data_ptr(), self.bn.weight.data_ptr(), self.bn.weight._version,
+               self.bn.running_var._version)
+        if key not in self._folded:
+            with torch.no_grad():
+                self._folded = {key: S.fold_bn(self.bn, bias)}
+        return self._folded[key]
+
+    def forward(self, x):
+        if self.training:
+            return S.SparseTensor(self.bn(x.F), x.cs)
+        scale, shift = self.folded()
+        return S.SparseTensor(x.F * scale + shift, x.cs)
+
+
+class MinkowskiInstanceNorm(nn.Module):
+    def __init__(self, num_features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(1, num_features))
+        self.bias = nn.Parameter(torch.zeros(1, num_features))
+        self.eps = 1e-8
+
+    def forward(self, x, relu=False):
+        return S.instance_norm(x, self.weight, self.bias, self.eps, relu)
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+    def forward(self, x):
+        return S.SparseTensor(torch.relu(x.F), x.cs)
+
+
+class MinkowskiELU(nn.Module):
+    def forward(self, x):
+        return S.SparseTensor(nn.functional.elu(x.F), x.cs)
+
+
+class MinkowskiMaxPooling(nn.Module):
+    def __init__(self, kernel_size=2, stride=2, dimension=3):
+        super().__init__()
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x):
+        return S.max_pool(x, self.kernel_size, self.stride)
+
+
+class MinkowskiPruning(nn.Module):
+    def forward(self, x, mask):
+        return S.prune(x, mask)
+
+
+def _act_name(m):
+    if isinstance(m, MinkowskiReLU):
+        return "relu"
+    if isinstance(m, MinkowskiELU):
+        return "elu"
+    return None
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential whose eval-mode forward fuses [conv | generative-transpose] -> BatchNorm -> ReLU/ELU and
+    conv -> InstanceNorm(+ReLU) runs; parameter names are those of a plain nn.Sequential."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            nxt2 = mods[i + 2] if i + 2 < len(mods) else None
+            if (not self.training) and isinstance(m, (MinkowskiConvolution, MinkowskiGenerativeConvolutionTranspose)) \
+                    and isinstance(nxt, MinkowskiBatchNorm):
+                scale, shift = nxt.folded(getattr(m, "bias", None))
+                act = _act_name(nxt2)
+                x = m(x, scale=scale, shift=shift, act=act)
+                i += 3 if act else 2
+            elif isinstance(m, MinkowskiInstanceNorm) and isinstance(nxt, MinkowskiReLU):
+                x = m(x, relu=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+class BasicBlock(nn.Module):
+    """ME.modules.resnet_block.BasicBlock: conv1(k3, stride) - norm1 - ReLU - conv2(k3) - norm2 - (+ shortcut) - ReLU.
+    Three launches in eval mode (two when there is no downsample branch)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=3):
+        super().__init__()
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=stride, dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        if self.training:
+            out = self.relu(self.norm1(self.conv1(x)))
+            out = self.norm2(self.conv2(out))
+            res = self.downsample(x) if self.downsample is not None else x
+            return self.relu(S.SparseTensor(out.F + res.F, out.cs))
+        s1, b1 = self.norm1.folded()
+        out = self.conv1(x, scale=s1, shift=b1, act="relu")
+        res = self.downsample(x) if self.downsample is not None else x
+        s2, b2 = self.norm2.folded()
+        return self.conv2(out, scale=s2, shift=b2, residual=res, act="relu")

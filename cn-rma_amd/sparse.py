@@ -1,0 +1,347 @@
+"""Sparse-voxel tensors and operators on the HIP engine (csrc/sparse.hip) -- the replacement of the
+MinkowskiEngine v0.5.4 surface the reference uses:
+
+    ME.utils.batch_sparse_collate + ME.SparseTensor      -> voxelize()
+    MinkowskiConvolution (k3/k1, stride 1/2)              -> conv()
+    MinkowskiGenerativeConvolutionTranspose (k2 s2)       -> conv_transpose_generative()
+    MinkowskiMaxPooling (k2 s2)                           -> max_pool()
+    MinkowskiInstanceNorm / BatchNorm / ReLU / ELU        -> instance_norm() / fused conv epilogues
+    A + B on different coordinate sets                    -> union_add()
+    SparseTensor.features_at_coordinates                  -> interpolate()
+    MinkowskiPruning                                      -> prune()
+
+Reference call sites: projects/mvsdetection/models/ray_marching.py:328-330, fcaf3d_backbone.py:26-31,63-70,
+fcaf3d_head.py:64-98,107-139,275-298.
+
+A CoordSet owns the int32 coordinates [N,4] = (batch,x,y,z) of one lattice level, its hash map and the cached
+neighbour tables / strided children (what ME's CoordinateManager caches); a SparseTensor is (CoordSet, features).
+"""
+import itertools
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _next_pow2(n):
+    p = 2
+    while p < n:
+        p *= 2
+    return p
+
+
+def kernel_offsets(kernel_size, tensor_stride):
+    """ME kernel-offset order: linear index decodes with x fastest; odd k centred, even k = 0..k-1 (Appendix A)."""
+    k = kernel_size
+    rng = [(i - k // 2) if k % 2 == 1 else i for i in range(k)]
+    offs = [(ix * tensor_stride, iy * tensor_stride, iz * tensor_stride)
+            for iz, iy, ix in itertools.product(rng, rng, rng)]
+    return offs
+
+
+class CoordMap:
+    """Open-addressing hash table on the device: uint64 key -> int32 row."""
+
+    def __init__(self, n, device):
+        self.cap = _next_pow2(max(2 * n, 16))
+        self.keys = torch.empty(self.cap, dtype=torch.int64, device=device)   # reinterpreted as uint64
+        self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
+
+
+class CoordSet:
+    def __init__(self, coords, stride, cmap=None):
+        assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        self.C = coords.contiguous()
+        self.n = coords.shape[0]
+        self.stride = int(stride)
+        self.device = coords.device
+        self._map = cmap
+        self._nbr = {}        # (kernel_size, id(out CoordSet)) -> nbr table
+        self._children = {}   # new_stride -> CoordSet
+        self._offsets = {}
+
+    @property
+    def cmap(self):
+        if self._map is None:
+            m = CoordMap(self.n, self.device)
+            call("cnrma_sparse_build_map", ptr(self.C), self.n, None, ptr(m.keys), ptr(m.vals), m.cap, stream())
+            self._map = m
+        return self._map
+
+    def strided(self, factor=2):
+        """output sites of a stride-`factor` conv / pool: unique(floor(p / s') * s'), s' = factor * stride."""
+        ns = self.stride * factor
+        if ns not in self._children:
+            m = CoordMap(self.n, self.device)
+            out = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
+            n_out = torch.empty(1, dtype=torch.int32, device=self.device)
+            ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(self.n), dtype=torch.uint8, device=self.device)
+            call("cnrma_sparse_stride_coords", ptr(self.C), self.n, None, ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
+                 ptr(n_out), ptr(ws), stream())
+            n = int(n_out.item())
+            self._children[ns] = CoordSet(out[:n], ns, m)
+        return self._children[ns]
+
+    def neighbours(self, out_set, kernel_size, offset_stride):
+        """nbr[No][K]: row of `self` at out_coord + offset_k (or -1)."""
+        key = (kernel_size, offset_stride, id(out_set))
+        if key not in self._nbr:
+            offs = torch.tensor(kernel_offsets(kernel_size, offset_stride), dtype=torch.int32, device=self.device)
+            K = offs.shape[0]
+            nbr = torch.empty((out_set.n, K), dtype=torch.int32, device=self.device)
+            m = self.cmap
+            call("cnrma_sparse_kernel_map", ptr(out_set.C), out_set.n, None, ptr(m.keys), ptr(m.vals), m.cap, ptr(offs),
+                 K, ptr(nbr), stream())
+            self._nbr[key] = (nbr, out_set)   # keep out_set alive so that id() stays unique
+        return self._nbr[key][0]
+
+
+class SparseTensor:
+    """features F [N,C] fp32 on a CoordSet; mirrors the attributes of ME.SparseTensor the reference touches."""
+
+    def __init__(self, features, coord_set):
+        assert features.shape[0] == coord_set.n
+        self.F = features
+        self.cs = coord_set
+
+    @property
+    def C(self):
+        return self.cs.C
+
+    @property
+    def features(self):
+        return self.F
+
+    @property
+    def coordinates(self):
+        return self.cs.C
+
+    @property
+    def tensor_stride(self):
+        return [self.cs.stride] * 3
+
+    @property
+    def device(self):
+        return self.F.device
+
+    def __len__(self):
+        return self.cs.n
+
+    @property
+    def decomposition_permutations(self):
+        b = self.cs.C[:, 0]
+        nb = int(b.max().item()) + 1 if self.cs.n else 0
+        if nb <= 1:
+            return [torch.arange(self.cs.n, device=self.device)]
+        return [torch.nonzero(b == i).squeeze(1) for i in range(nb)]
+
+    @property
+    def decomposed_coordinates(self):
+        return [self.cs.C[p, 1:] for p in self.decomposition_permutations]
+
+    def features_at_coordinates(self, query_coords_float):
+        q = query_coords_float.to(torch.int32).contiguous()
+        return interpolate(self, q)
+
+    def __add__(self, other):
+        return union_add(self, other)
+
+
+# --------------------------------------------------------------------------------------------------------------
+def voxelize(coords, feats, voxel_size, batch_id=0):
+    """ME.utils.batch_sparse_collate + ME.SparseTensor (ray_marching.py:328-330): floor(coord / voxel_size),
+    first occurrence wins, rows in first-occurrence order.  Returns (SparseTensor @ stride 1, src_index int32)."""
+    _lib.require_gpu()
+    coords = coords.contiguous().float()
+    feats = feats.contiguous().float()
+    M, C = feats.shape
+    dev = feats.device
+    m = CoordMap(M, dev)
+    out_c = torch.empty((M, 4), dtype=torch.int32, device=dev)
+    out_f = torch.empty((M, C), dtype=torch.float32, device=dev)
+    src = torch.empty(M, dtype=torch.int32, device=dev)
+    n_out = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(M), dtype=torch.uint8, device=dev)
+    call("cnrma_voxelize_f32", ptr(coords), ptr(feats), M, C, float(voxel_size), int(batch_id), ptr(m.keys), ptr(m.vals),
+         m.cap, ptr(out_c), ptr(out_f), ptr(src), ptr(n_out), ptr(ws), stream())
+    n = int(n_out.item())
+    return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
+
+
+def sparse_collate(list_of_coords_feats, voxel_size):
+    """Multi-scene variant: one SparseTensor holding all scenes (batch id = list index)."""
+    parts = [voxelize(c, f, voxel_size, b) for b, (c, f) in enumerate(list_of_coords_feats)]
+    if len(parts) == 1:
+        return parts[0][0]
+    C = torch.cat([p[0].C for p in parts])
+    F = torch.cat([p[0].F for p in parts])
+    return SparseTensor(F, CoordSet(C, 1))
+
+
+def fold_bn(bn, bias=None):
+    """eval-mode BatchNorm1d (+ optional conv bias) -> per-channel (scale, shift)."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias - bn.running_mean * scale
+    if bias is not None:
+        shift = shift + bias.view(-1) * scale
+    return scale.contiguous().float(), shift.contiguous().float()
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
+
+
+def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=None, act=None):
+    """MinkowskiConvolution + fused epilogue: out = act((sum_k in[nbr] @ W[k]) * scale + shift + residual).
+    weight [K,Cin,Cout] (or [Cin,Cout] when K == 1)."""
+    _lib.require_gpu()
+    w = weight.contiguous().float()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, Cin, Cout = w.shape
+    assert K == kernel_size ** 3 and Cin == x.F.shape[1]
+    in_cs = x.cs
+    out_cs = in_cs if stride == 1 else in_cs.strided(stride)
+    if kernel_size == 1 and stride == 1:
+        nbr = None
+    else:
+        nbr = in_cs.neighbours(out_cs, kernel_size, in_cs.stride)
+    out = torch.empty((out_cs.n, Cout), dtype=torch.float32, device=x.device)
+    if out_cs.n:
+        res = residual.F.contiguous() if isinstance(residual, SparseTensor) else residual
+        if res is not None:
+            assert res.shape == out.shape
+        call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
+             ptr(res), ACT[act], ptr(out), out_cs.n, None, stream())
+    return SparseTensor(out, out_cs)
+
+
+def conv_transpose_generative(x, weight, scale=None, shift=None, act=None):
+    """MinkowskiGenerativeConvolutionTranspose(k=2, s=2): 8 children per parent at half the tensor stride;
+    out row k*N + i = in[i] @ W[k] (k decodes with x fastest)."""
+    _lib.require_gpu()
+    w = weight.contiguous().float()
+    K, Cin, Cout = w.shape
+    assert K == 8 and x.cs.stride % 2 == 0
+    n = x.cs.n
+    half = x.cs.stride // 2
+    out_c = torch.empty((8 * n, 4), dtype=torch.int32, device=x.device)
+    out_f = torch.empty((8 * n, Cout), dtype=torch.float32, device=x.device)
+    if n:
+        call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, Cin, half, ptr(w), Cout, ptr(scale),
+             ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
+    return SparseTensor(out_f, CoordSet(out_c, half))
+
+
+def max_pool(x, kernel_size=2, stride=2):
+    _lib.require_gpu()
+    out_cs = x.cs.strided(stride)
+    nbr = x.cs.neighbours(out_cs, kernel_size, x.cs.stride)
+    C = x.F.shape[1]
+    out = torch.empty((out_cs.n, C), dtype=torch.float32, device=x.device)
+    if out_cs.n:
+        call("cnrma_sparse_maxpool_f32", ptr(x.F.contiguous()), C, ptr(nbr), nbr.shape[1], ptr(out), out_cs.n, None,
+             stream())
+    return SparseTensor(out, out_cs)
+
+
+def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
+    """MinkowskiInstanceNorm for a single scene (+ optional fused ReLU)."""
+    _lib.require_gpu()
+    n, C = x.F.shape
+    out = torch.empty_like(x.F)
+    ws = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=x.device)
+    w = weight.contiguous().view(-1).float() if weight is not None else None
+    b = bias.contiguous().view(-1).float() if bias is not None else None
+    call("cnrma_sparse_instnorm_f32", ptr(x.F.contiguous()), n, None, C, ptr(w), ptr(b), float(eps), int(relu), ptr(out),
+         ptr(ws), stream())
+    return SparseTensor(out, x.cs)
+
+
+def union_add(a, b):
+    """`a + b` on different coordinate sets with equal tensor stride (fcaf3d_head.py:114)."""
+    _lib.require_gpu()
+    assert a.cs.stride == b.cs.stride and a.F.shape[1] == b.F.shape[1]
+    if a.cs is b.cs:
+        return SparseTensor(a.F + b.F, a.cs)
+    na, nb, C = a.cs.n, b.cs.n, a.F.shape[1]
+    dev = a.device
+    m = CoordMap(na + nb, dev)
+    call("cnrma_sparse_build_map", ptr(a.C), na, None, ptr(m.keys), ptr(m.vals), m.cap, stream())
+    out_c = torch.empty((na + nb, 4), dtype=torch.int32, device=dev)
+    out_f = torch.empty((na + nb, C), dtype=torch.float32, device=dev)
+    n_out = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.load().cnrma_union_workspace_bytes(nb), dtype=torch.uint8, device=dev)
+    call("cnrma_sparse_union_add_f32", ptr(a.C), ptr(a.F.contiguous()), na, None, ptr(b.C), ptr(b.F.contiguous()), nb,
+         None, C, ptr(m.keys), ptr(m.vals), m.cap, ptr(out_c), ptr(out_f), ptr(n_out), ptr(ws), stream())
+    n = int(n_out.item())
+    return SparseTensor(out_f[:n], CoordSet(out_c[:n], a.cs.stride, m))
+
+
+def interpolate(score, query_coords):
+    """score.features_at_coordinates(query): linear interpolation on score's lattice (fcaf3d_head.py:129)."""
+    _lib.require_gpu()
+    assert score.F.shape[1] == 1
+    n = query_coords.shape[0]
+    out = torch.empty((n, 1), dtype=torch.float32, device=score.device)
+    m = score.cs.cmap
+    if n:
+        call("cnrma_sparse_interp_f32", ptr(query_coords.contiguous()), n, None, ptr(score.F.contiguous()), ptr(m.keys),
+             ptr(m.vals), m.cap, score.cs.stride, ptr(out), stream())
+    return out
+
+
+def prune(x, keep_mask):
+    """MinkowskiPruning: rows where keep_mask, order preserved."""
+    _lib.require_gpu()
+    from .rma import mask_to_index
+    n, C = x.F.shape
+    mask = keep_mask.to(torch.uint8).contiguous()
+    sel, n_sel = mask_to_index(mask)
+    k = int(n_sel.item())
+    out_c = torch.empty((k, 4), dtype=torch.int32, device=x.device)
+    out_f = torch.empty((k, C), dtype=torch.float32, device=x.device)
+    if n:
+        call("cnrma_sparse_prune_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, C, ptr(sel), ptr(out_c), ptr(out_f),
+             stream())
+    return SparseTensor(out_f, CoordSet(out_c, x.cs.stride))
+
+
+def row_max(feats):
+    n, C = feats.shape
+    out = torch.empty((n, 1), dtype=torch.float32, device=feats.device)
+    if n:
+        call("cnrma_rowmax_f32", ptr(feats.contiguous()), n, None, C, ptr(out), stream())
+    return out
+
+
+def decode_boxes(points_xyz, bbox_pred, yaw_parametrization="fcaf3d"):
+    """FCAF3DHead._bbox_pred_to_bbox (fcaf3d_head.py:300-349)."""
+    _lib.require_gpu()
+    n, R = bbox_pred.shape
+    if n == 0:
+        return bbox_pred
+    if R == 6:
+        mode, W = 0, 6
+    elif yaw_parametrization == "naive":
+        mode, W = 3, 7
+    elif yaw_parametrization == "sin-cos":
+        mode, W = 2, 7
+    else:
+        mode, W = 1, 7
+    out = torch.empty((n, W), dtype=torch.float32, device=bbox_pred.device)
+    call("cnrma_fcaf3d_decode_f32", ptr(points_xyz.contiguous().float()), ptr(bbox_pred.contiguous().float()), R, n, mode,
+         ptr(out), stream())
+    return out
+
+
+def class_scores(cls_score, centerness):
+    """scores = sigmoid(cls) * sigmoid(centerness) and their per-row max (fcaf3d_head.py:249-250)."""
+    _lib.require_gpu()
+    n, nc = cls_score.shape
+    scores = torch.empty((n, nc), dtype=torch.float32, device=cls_score.device)
+    mx = torch.empty(n, dtype=torch.float32, device=cls_score.device)
+    if n:
+        call("cnrma_fcaf3d_scores_f32", ptr(cls_score.contiguous().float()), ptr(centerness.contiguous().float()), n, nc,
+             ptr(scores), ptr(mx), stream())
+    return scores, mx

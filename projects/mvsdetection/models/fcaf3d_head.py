@@ -1,0 +1,252 @@
+"""FCAF3D neck + head on the HIP sparse engine.
+
+Registered name, constructor signature, forward outputs, pruning rule, box decoding and the raw-box dump follow
+the reference's projects/mvsdetection/models/fcaf3d_head.py (FCAF3DHead :24-349, compute_centerness :395-402,
+FCAF3DAssigner :405-484).  Parameter names match (up_block_i.0.kernel, out_block_i.1.bn.*, centerness_conv.kernel,
+reg_conv.kernel, cls_conv.kernel/bias, scales.i.scale).  Training losses (:142-214) need mmdet's loss registry and
+are a "next" row of SURVEY.md 8(f); the assigner is provided because it is pure tensor math."""
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from cnrma_amd import nn as snn
+from cnrma_amd import sparse as S
+
+from ..registry import BBOX_ASSIGNERS, HEADS, HAVE_MMDET, build_assigner
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale: a learnable scalar factor (key: `scale`)."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class _TestCfg(dict):
+    __getattr__ = dict.get
+
+
+@HEADS.register_module()
+class FCAF3DHead(nn.Module):
+    def __init__(self, n_classes, in_channels, out_channels, n_reg_outs, voxel_size, pts_threshold, assigner,
+                 yaw_parametrization="fcaf3d",
+                 loss_centerness=dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type="IoU3DLoss", loss_weight=1.0),
+                 loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.fp16_enabled = False
+        self.voxel_size = voxel_size
+        self.yaw_parametrization = yaw_parametrization
+        self.assigner = build_assigner(assigner) if assigner is not None else None
+        if HAVE_MMDET:
+            from mmdet.models.builder import build_loss
+            self.loss_centerness, self.loss_bbox, self.loss_cls = map(build_loss, (loss_centerness, loss_bbox, loss_cls))
+        else:
+            self.loss_centerness = self.loss_bbox = self.loss_cls = None
+        self.train_cfg = train_cfg
+        self.test_cfg = _TestCfg(test_cfg) if isinstance(test_cfg, dict) else test_cfg
+        self.pts_threshold = pts_threshold
+        self.n_classes, self.n_reg_outs = n_classes, n_reg_outs
+        self._init_layers(in_channels, out_channels, n_reg_outs, n_classes)
+        self._fused_head = None
+
+    # ---- layers (reference :61-98) -------------------------------------------------------------------------
+    @staticmethod
+    def _make_block(cin, cout):
+        return snn.FusedSequential(snn.MinkowskiConvolution(cin, cout, kernel_size=3, dimension=3),
+                                   snn.MinkowskiBatchNorm(cout), snn.MinkowskiELU())
+
+    @staticmethod
+    def _make_up_block(cin, cout):
+        return snn.FusedSequential(
+            snn.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=2, stride=2, dimension=3),
+            snn.MinkowskiBatchNorm(cout), snn.MinkowskiELU(),
+            snn.MinkowskiConvolution(cout, cout, kernel_size=3, dimension=3),
+            snn.MinkowskiBatchNorm(cout), snn.MinkowskiELU())
+
+    def _init_layers(self, in_channels, out_channels, n_reg_outs, n_classes):
+        self.pruning = snn.MinkowskiPruning()
+        for i in range(len(in_channels)):
+            if i > 0:
+                setattr(self, f"up_block_{i}", self._make_up_block(in_channels[i], in_channels[i - 1]))
+            setattr(self, f"out_block_{i}", self._make_block(in_channels[i], out_channels))
+        self.centerness_conv = snn.MinkowskiConvolution(out_channels, 1, kernel_size=1, dimension=3)
+        self.reg_conv = snn.MinkowskiConvolution(out_channels, n_reg_outs, kernel_size=1, dimension=3)
+        self.cls_conv = snn.MinkowskiConvolution(out_channels, n_classes, kernel_size=1, bias=True, dimension=3)
+        self.scales = nn.ModuleList([Scale(1.0) for _ in range(len(in_channels))])
+
+    def init_weights(self):
+        nn.init.normal_(self.centerness_conv.kernel, std=.01)
+        nn.init.normal_(self.reg_conv.kernel, std=.01)
+        nn.init.normal_(self.cls_conv.kernel, std=.01)
+        nn.init.constant_(self.cls_conv.bias, float(-np.log((1 - 0.01) / 0.01)))   # bias_init_with_prob(.01)
+        self._fused_head = None
+
+    def train(self, mode=True):
+        self._fused_head = None
+        return super().train(mode)
+
+    # ---- forward (reference :107-139, :275-298) ---------------------------------------------------------------
+    def forward(self, x):
+        outs = []
+        inputs = x
+        x = inputs[-1]
+        scores = None
+        for i in range(len(inputs) - 1, -1, -1):
+            if i < len(inputs) - 1:
+                x = getattr(self, f"up_block_{i + 1}")(x)
+                x = inputs[i] + x                       # coordinate union, features added (:114)
+                x = self._prune(x, scores)
+            out = getattr(self, f"out_block_{i}")(x)
+            out = self.forward_single(out, self.scales[i])
+            scores = out[-1]
+            outs.append(out[:-1])
+        return zip(*outs[::-1])
+
+    def _prune(self, x, scores):
+        """keep the top `pts_threshold` rows per scene by the interpolated max-class score of the coarser level"""
+        if self.pts_threshold < 0:
+            return x
+        with torch.no_grad():
+            perms = x.decomposition_permutations
+            if all(len(p) <= self.pts_threshold for p in perms):
+                return x                                # the top-k keeps every row: pruning is the identity
+            interpolated = scores.features_at_coordinates(x.C.float())
+            mask = torch.zeros(len(interpolated), dtype=torch.bool, device=x.device)
+            for p in perms:
+                k = min(len(p), self.pts_threshold)
+                ids = torch.topk(interpolated[p].squeeze(1), k, sorted=False).indices
+                mask[p[ids]] = True
+        return self.pruning(x, mask)
+
+    def _head_weights(self):
+        """the three 1x1 head convolutions as ONE [128, 1+R+n_cls] GEMM (+ bias row for the class logits)"""
+        if self._fused_head is None or self._fused_head[0].device != self.cls_conv.kernel.device:
+            with torch.no_grad():
+                w = torch.cat((self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel), dim=1).contiguous()
+                b = torch.zeros(w.shape[1], device=w.device)
+                b[1 + self.n_reg_outs:] = self.cls_conv.bias.view(-1)
+            self._fused_head = (w, b.contiguous())
+        return self._fused_head
+
+    def forward_single(self, x, scale):
+        if self.training:
+            centerness = self.centerness_conv(x).F
+            cls_score = self.cls_conv(x).F
+            reg_final = self.reg_conv(x).F
+        else:
+            w, b = self._head_weights()
+            y = S.conv(x, w, kernel_size=1, shift=b).F
+            centerness, reg_final, cls_score = y[:, :1], y[:, 1:1 + self.n_reg_outs], y[:, 1 + self.n_reg_outs:]
+        prune_scores = S.SparseTensor(S.row_max(cls_score.contiguous()), x.cs)           # :279-282
+        reg_distance = torch.exp(scale(reg_final[:, :6]))                                  # :284
+        bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)                     # :285-286
+        perms = x.decomposition_permutations
+        if len(perms) == 1:
+            centernesses, bbox_preds, cls_scores = [centerness], [bbox_pred], [cls_score]
+        else:
+            centernesses = [centerness[p] for p in perms]
+            bbox_preds = [bbox_pred[p] for p in perms]
+            cls_scores = [cls_score[p] for p in perms]
+        points = [c * self.voxel_size for c in x.decomposed_coordinates]                   # :294-296
+        return centernesses, bbox_preds, cls_scores, points, prune_scores
+
+    # ---- decoding (reference :217-271, :300-349) -----------------------------------------------------------------
+    def _bbox_pred_to_bbox(self, points, bbox_pred):
+        if bbox_pred.shape[0] == 0:
+            return bbox_pred
+        return S.decode_boxes(points.float(), bbox_pred, self.yaw_parametrization)
+
+    def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, scene_id=None, save_path=None):
+        mlvl_bboxes, mlvl_scores = [], []
+        nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
+        for centerness, bbox_pred, cls_score, point in zip(centernesses, bbox_preds, cls_scores, points):
+            scores, max_scores = S.class_scores(cls_score, centerness)                      # :249-250
+            if len(scores) > nms_pre > 0:
+                _, ids = max_scores.topk(nms_pre)                                           # :252-256
+                bbox_pred, scores, point = bbox_pred[ids], scores[ids], point[ids]
+            mlvl_bboxes.append(self._bbox_pred_to_bbox(point, bbox_pred))
+            mlvl_scores.append(scores)
+        bboxes, scores = torch.cat(mlvl_bboxes), torch.cat(mlvl_scores)
+        if save_path is not None:
+            save_place = os.path.join(save_path, scene_id)
+            os.makedirs(save_place, exist_ok=True)
+            np.savez(os.path.join(save_place, scene_id + "_bbox_raw.npz"), bboxes=bboxes.detach().cpu().numpy(),
+                     scores=scores.detach().cpu().numpy())                                  # :266-271
+        return bboxes, scores
+
+    def get_bboxes(self, centernesses, bbox_preds, cls_scores, points, scene_ids, save_path):
+        out = []
+        for i in range(len(centernesses[0])):
+            out.append(self._get_bboxes_single([x[i] for x in centernesses], [x[i] for x in bbox_preds],
+                                               [x[i] for x in cls_scores], [x[i] for x in points],
+                                               scene_ids[i] if scene_ids is not None else None, save_path))
+        return out
+
+    def loss(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
+        if self.loss_cls is None:
+            raise NotImplementedError("training losses need mmdet's loss registry (SURVEY.md 8(f) row 3)")
+        raise NotImplementedError("loss path is a later-round item")
+
+
+def compute_centerness(bbox_targets):
+    """sqrt of the product over axes of min/max face distances (reference :395-402)."""
+    d = bbox_targets[..., :6]
+    x, y, z = d[..., 0:2], d[..., 2:4], d[..., 4:6]
+    c = x.min(dim=-1)[0] / x.max(dim=-1)[0] * y.min(dim=-1)[0] / y.max(dim=-1)[0] * z.min(dim=-1)[0] / z.max(dim=-1)[0]
+    return torch.sqrt(c)
+
+
+@BBOX_ASSIGNERS.register_module()
+class FCAF3DAssigner(object):
+    """Point-to-box assignment of FCAF3D (reference :405-484): inside-box, best-scale (first level with fewer than
+    `limit` inside points, minus one), top-k centerness, smallest volume."""
+
+    def __init__(self, limit, topk, n_scales):
+        self.limit, self.topk, self.n_scales = limit, topk, n_scales
+
+    def assign(self, points, gt_bboxes, gt_labels):
+        """points: list (per level) of [n_i,3]; gt_bboxes exposes .gravity_center [m,3], .tensor [m,7], .volume [m].
+        Returns (centerness_targets [n], bbox_targets [n,7], labels [n], -1 = background)."""
+        big = 1e8
+        level = torch.cat([p.new_tensor(i).expand(len(p)) for i, p in enumerate(points)])
+        pts = torch.cat(points, dim=0)
+        n, m = len(pts), len(gt_bboxes)
+        vol = gt_bboxes.volume.to(pts.device).expand(n, m).contiguous()
+        box = torch.cat((gt_bboxes.gravity_center, gt_bboxes.tensor[:, 3:]), dim=1).to(pts.device)     # [m,7]
+        boxes = box.expand(n, m, 7)
+        rel = pts[:, None, :] - box[None, :, :3]                                                       # [n,m,3]
+        # mmdet3d 0.15 rotation_3d_in_axis(shift, -yaw, axis=2): row-vector times [[c,-s,0],[s,c,0],[0,0,1]]
+        # (third-party convention, not pinned by anything under /root/reference)
+        ang = -box[:, 6]
+        c, s = torch.cos(ang)[None], torch.sin(ang)[None]
+        rot = torch.stack((rel[..., 0] * c + rel[..., 1] * s, -rel[..., 0] * s + rel[..., 1] * c, rel[..., 2]), dim=-1)
+        centers = boxes[..., :3] + rot
+        half = boxes[..., 3:6] / 2
+        lo = centers - boxes[..., :3] + half                       # distances to the three "min" faces
+        hi = boxes[..., :3] + half - centers                        # ... and the three "max" faces
+        targets = torch.stack((lo[..., 0], hi[..., 0], lo[..., 1], hi[..., 1], lo[..., 2], hi[..., 2], boxes[..., 6]), -1)
+        inside = targets[..., :6].min(-1)[0] > 0                                                     # condition 1
+        per_level = torch.stack([inside[level == i].sum(dim=0) for i in range(self.n_scales)], dim=0)  # [L,m]
+        too_few = per_level < self.limit
+        lower = torch.argmax(too_few.int(), dim=0) - 1
+        lower = torch.where(lower < 0, torch.zeros_like(lower), lower)
+        best = torch.where(torch.all(~too_few, dim=0), torch.full_like(lower, self.n_scales - 1), lower)
+        at_best = best[None, :].expand(n, m) == level[:, None].expand(n, m)                           # condition 2
+        cness = compute_centerness(targets)
+        cness = torch.where(inside & at_best, cness, -torch.ones_like(cness))
+        kth = torch.topk(cness, min(self.topk + 1, len(cness)), dim=0).values[-1]
+        top = cness > kth[None]                                                                       # condition 3
+        vol = torch.where(inside & at_best & top, vol, torch.full_like(vol, big))
+        min_vol, arg = vol.min(dim=1)
+        labels = torch.where(min_vol == big, torch.full_like(gt_labels[arg], -1), gt_labels[arg])
+        rows = torch.arange(n, device=pts.device)
+        picked = targets[rows, arg]
+        return compute_centerness(picked), boxes[rows, arg], labels

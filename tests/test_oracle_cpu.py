@@ -100,7 +100,11 @@ def test_host_projection_inverse_matches_golden():
     for name in SCENES:
         g = load_golden(name)
         pinv = rma.projection_inverse(t(g["projection"]), g["stride"])
-        assert count_mismatch(pinv, g["proj_inv"]) == 0
+        # same call as the oracle's, so identical on any one host; vs the golden (generated on the build container's
+        # CPU) LAPACK may differ in the last bits on another CPU model
+        for v in range(pinv.shape[0]):
+            assert torch.equal(pinv[v], O.projection_inverse(O.scale_projection(t(g["projection"][v]), g["stride"])))
+        np.testing.assert_allclose(pinv.numpy(), g["proj_inv"], rtol=1e-4, atol=1e-5)
 
 
 def test_synth_scene_is_deterministic():
