@@ -1,0 +1,244 @@
+"""bench.py -- scenes/s of the CN-RMA hot path (dense unprojection -> RMA -> voxelise -> FCAF3D -> decode), forward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S|St|tiny]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one synthetic scene per GPU through the whole hot path (features and TSDF already resident in HBM:
+they are the outputs of the 2D backbone / Atlas 3D network, which are outside the path).  Scenes are independent,
+so N GPUs process N scenes per step (weak scaling) and finish with the variable-length all-gather of detections
+over RCCL.  Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (= vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="S", help="S = ScanNet config (40 views, 32ch 120x160 -> 192x192x80); St; tiny")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(C, device, n_classes=18, n_reg=6):
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
+    torch.manual_seed(0)
+    backbone = FCAF3DBackbone(C, 34)
+    head = FCAF3DHead(n_classes, (64, 128, 256, 512), 128, n_reg, 0.01, 200000, None,
+                      test_cfg=dict(nms_pre=1000, iou_thr=.5, score_thr=.01))
+    backbone.init_weights()
+    head.init_weights()
+    return backbone.to(device).eval(), head.to(device).eval()
+
+
+class KernelProfile:
+    """per C-ABI call HIP-event timing on the launch stream (each timed entry point is exactly one kernel)"""
+    TIMED = ("cnrma_backproject_accum_f32", "cnrma_rma_neus_count_f32", "cnrma_rma_neus_emit_f32",
+             "cnrma_sparse_conv_f32", "cnrma_sparse_convtr_gen_f32", "cnrma_nchw_to_nhwc_f32",
+             "cnrma_sparse_kernel_map", "cnrma_sparse_maxpool_f32")
+
+    def __init__(self):
+        self.records = []
+
+    def install(self):
+        from cnrma_amd import _lib
+        self._orig = _lib.call
+        prof = self
+
+        def timed_call(name, *args):
+            if name not in prof.TIMED:
+                return prof._orig(name, *args)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = prof._orig(name, *args)
+            b.record()
+            prof.records.append((name, args, a, b))
+            return rc
+        for mod in ("cnrma_amd._lib", "cnrma_amd.rma", "cnrma_amd.sparse"):
+            sys.modules[mod].call = timed_call
+
+    def uninstall(self):
+        for mod in ("cnrma_amd._lib", "cnrma_amd.rma", "cnrma_amd.sparse"):
+            sys.modules[mod].call = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, args, a, b in self.records:
+            ms = a.elapsed_time(b)
+            d = agg.setdefault(name, dict(ms=0.0, n=0, flops=0.0))
+            d["ms"] += ms
+            d["n"] += 1
+            if name == "cnrma_sparse_conv_f32":
+                # args: in, Cin, nbr, K, W, Cout, scale, shift, res, act, out, no_cap, no_dev, stream
+                d["flops"] += 2.0 * args[3] * args[1] * args[5] * args[11]      # dense-K upper bound (executed MFMA work)
+        return agg
+
+
+def algorithmic_bytes_dense(V, C, H, W, dims):
+    G = dims[0] * dims[1] * dims[2]
+    return 4 * V * C * H * W + 4 * C * G + 4 * G + 48 * V
+
+
+def conv_pairs(backbone_levels_cache):
+    return None
+
+
+def cpu_baseline(shape_name, n_views=2, n_points=25000):
+    """The oracle (a CPU port of the reference's algorithm) timed on this host's cores on a bounded sample."""
+    from cnrma_amd import synth
+    from oracle import rma_oracle as O
+    from oracle import sparse_oracle as SO
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    V_full = synth.SHAPES[shape_name][0]
+    sc = synth.make_scene(shape_name, seed=0, V=n_views)
+    proj, feat, tsdf = sc["projection"][:, 0], sc["features"][:, 0], sc["tsdf"][0, 0]
+    t0 = time.time()
+    O.backproject_accum(sc["dims"], 0.04, sc["origin"], proj, feat, sc["stride"])
+    t_dense = time.time() - t0
+    t0 = time.time()
+    pts = O.aggregate_rma(proj, feat, tsdf, sc["dims"], 0.04, sc["origin"], sc["stride"])
+    t_rma = time.time() - t0
+    torch.manual_seed(0)
+    backbone = FCAF3DBackbone(feat.shape[1], 34).eval()
+    head = FCAF3DHead(18, (64, 128, 256, 512), 128, 6, 0.01, 200000, None, test_cfg=dict(nms_pre=1000)).eval()
+    head.init_weights()
+    sel = pts[torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(0))[:n_points].sort()[0]]
+    t0 = time.time()
+    Cq, Fq, _ = O.voxelize(sel[:, :3], sel[:, 3:], 0.01)
+    res = SO.head_forward(head, SO.backbone_forward(backbone, Cq.numpy(), Fq.numpy()))
+    SO.get_bboxes(head, res)
+    t_sparse = time.time() - t0
+    full_points = 500000
+    est = (t_dense + t_rma) * V_full / n_views + t_sparse * full_points / max(1, sel.shape[0])
+    return dict(value=1.0 / est, unit="scenes/s", cores=cores, kind="port",
+                sample=f"oracle (torch-CPU/numpy port of the reference algorithm): dense+RMA on {n_views} of {V_full} views "
+                       f"({t_dense:.2f}s+{t_rma:.2f}s, scaled x{V_full / n_views:.0f}) + voxelise/FCAF3D/decode on "
+                       f"{sel.shape[0]} of {full_points} points ({t_sparse:.2f}s, scaled x{full_points / max(1, sel.shape[0]):.0f})")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from cnrma_amd import _lib, pipeline, rma, synth
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    V, C, H, W, dims, stride = synth.SHAPES[args.workload]
+    sc = synth.make_scene(args.workload, seed=rank)
+    feat = sc["features"][:, 0].to(device)
+    proj = sc["projection"][:, 0]                       # host copy (tiny): the inverse is a host LAPACK call
+    tsdf = sc["tsdf"][0, 0].to(device)
+    backbone, head = build_model(C, device)
+    cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
+
+    def step():
+        out = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+        dets = pipeline.gather_detections(out["bboxes"], out["scores"])
+        return out, dets
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, _ = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, _ = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+
+    result = {
+        "metric": "scenes/sec fwd (40-view->192^3-class voxel grid): dense unprojection + RMA + voxelise + FCAF3D + decode",
+        "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}), grid "
+                               f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000, "
+                               f"FCAF3D MinkResNet34 + head (18 classes), 1 scene per GPU per step",
+                   "M_rows": out["M"], "M_selected": out["M_selected"], "M_unique": out["M_unique"],
+                   "level_rows": out["level_rows"], "head_rows": out["head_rows"]},
+    }
+
+    if rank == 0 and not args.no_profile:
+        # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
+        prof = KernelProfile()
+        prof.install()
+        reps = 3
+        for _ in range(reps):
+            out2 = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf, timing=False)
+        prof.uninstall()
+        agg = prof.summary()
+        kern = {k: dict(ms_per_scene=v["ms"] / reps, launches_per_scene=v["n"] / reps) for k, v in agg.items()}
+        dense_ms = agg["cnrma_backproject_accum_f32"]["ms"] / agg["cnrma_backproject_accum_f32"]["n"]
+        dense_bytes = algorithmic_bytes_dense(V, C, H, W, dims)
+        conv = agg["cnrma_sparse_conv_f32"]
+        kern["cnrma_backproject_accum_f32"].update(algorithmic_GB=dense_bytes / 1e9,
+                                                   GBps=dense_bytes / 1e6 / dense_ms,
+                                                   frac_hbm=dense_bytes / 1e6 / dense_ms / HBM_PEAK_GBS)
+        kern["cnrma_sparse_conv_f32"].update(executed_TFLOP=conv["flops"] / reps / 1e12,
+                                             TFLOPps=conv["flops"] / 1e9 / conv["ms"],
+                                             frac_mfma_f32=conv["flops"] / 1e9 / conv["ms"] / MFMA_F32_PEAK_TFLOPS)
+        dominant = max(kern, key=lambda k: kern[k]["ms_per_scene"])
+        if dominant == "cnrma_sparse_conv_f32":
+            ach = conv["flops"] / 1e9 / conv["ms"]
+            result["roofline"] = {"kernel": "sparse_conv_mfma_kernel (cnrma_sparse_conv_f32)", "bound": "mfma",
+                                  "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                  "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32); flops = executed 2*K*Cin*Cout*rows per launch, "
+                                          "averaged over the launches of one scene"}
+        else:
+            ach = dense_bytes / 1e6 / dense_ms
+            result["roofline"] = {"kernel": "backproject_accum_kernel (cnrma_backproject_accum_f32)", "bound": "hbm",
+                                  "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                  "traffic": None}
+        result["kernels"] = kern
+        st = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf, timing=True)["stage_ms"]
+        result["stage_ms"] = st
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.workload if args.workload in ("S", "St") else "tiny")
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

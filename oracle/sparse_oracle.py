@@ -262,7 +262,7 @@ def head_forward(head, levels):
         ctr = o @ _np(head.centerness_conv.kernel)
         cls = o @ _np(head.cls_conv.kernel) + _np(head.cls_conv.bias)
         reg = o @ _np(head.reg_conv.kernel)
-        dist = np.exp(reg[:, :6] * float(head.scales[i].scale))
+        dist = np.exp(reg[:, :6] * float(head.scales[i].scale.detach()))
         bbox = np.concatenate((dist, reg[:, 6:]), axis=1)
         scores = (c, cls.max(axis=1, keepdims=True), ts)
         results[i] = dict(coords=c, centerness=ctr, bbox_pred=bbox, cls_score=cls, points=c[:, 1:] * head.voxel_size)

@@ -1,0 +1,282 @@
+"""CN-RMA detector on the MI355X hot path.
+
+Drop-in for the reference's projects/mvsdetection/models/ray_marching.py: same registered name (`RayMarching`),
+same constructor keywords (:116-147), same method names and return contracts (forward / forward_test -> [{}],
+train_step, val_step, parse_losses, data_converter, init_weights, aggregate_2d_features, clear_3d_features,
+aggregate_2d_features_ray_marching, fcaf3d_detection, switch_pointcloud, ray_projection_neus/_depth) and the
+module-level backproject() / get_ray_parameter().  All aggregation arithmetic runs in the HIP kernels of
+cn-rma_amd/csrc through cnrma_amd.rma; the sparse detector runs on cnrma_amd.sparse.
+
+Out of the hot-path scope: the 2D backbone (rows 7) and the Atlas 3D reconstruction network (row 6).
+When their configs are None the detector takes their OUTPUTS as inputs: `features` [B][V,C,H',W'] and
+`tsdf` (scene_tsdf_004, [B,1,X,Y,Z]) -- that is the synthetic-scene contract of bench.py.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from cnrma_amd import rma
+from cnrma_amd import sparse as S
+
+from ..datasets.pipelines.fcaf3d_transforms import TransformFeaturesBBoxes, sample_points
+from ..registry import DETECTORS, build_backbone, build_head
+
+
+def backproject(voxel_dim, voxel_size, origin, projection, features):
+    """Fill 2D features along camera rays into a voxel volume (reference :21-69).
+    projection [B,3,4] (already stride-scaled), features [B,C,H,W] -> volume [B,C,nx,ny,nz], valid [B,1,nx,ny,nz] bool.
+    One view per batch item, like the reference; the production path uses rma.backproject_accum for all views."""
+    vols, valids = [], []
+    org = origin.view(-1).tolist() if isinstance(origin, torch.Tensor) else list(origin)
+    for b in range(features.shape[0]):
+        nhwc = rma.to_nhwc(features[b:b + 1])
+        vol, cnt = rma.backproject_accum(nhwc, projection[b:b + 1], voxel_dim, voxel_size, org, stride=1)
+        vols.append(vol)
+        valids.append((cnt > 0).unsqueeze(0))
+    return torch.stack(vols), torch.stack(valids)
+
+
+def get_ray_parameter(projection, features):
+    """Ray origin / unit direction per feature-map pixel (reference :71-111): o, d [B,3,H*W]."""
+    B, C, H, W = features.shape
+    pinv = rma.projection_inverse(projection, 1).to(features.device)
+    o, d = rma.ray_params(pinv, H, W)
+    return o.unsqueeze(2).expand(B, 3, H * W).contiguous(), d
+
+
+@DETECTORS.register_module()
+class RayMarching(nn.Module):
+    def __init__(self, pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin,
+                 backbone2d_stride, backbone2d, feature_2d, backbone_3d, tsdf_head, detection_backbone,
+                 detection_head, feature_transform, save_path, loss_weight_recon=1.0, loss_weight_detection=1.0,
+                 voxel_size_fcaf3d=0.01, use_batchnorm_train=True, use_batchnorm_test=True, max_points=None,
+                 train_cfg=None, test_cfg=None, pretrained=None, use_feature_transform=True,
+                 ray_marching_type="neus", depth_points=None, neus_threshold=None, middle_save_path=None,
+                 middle_visualize_path=None, point_sampler="numpy"):
+        super().__init__()
+        self.fp16_enabled = False
+        # sub-networks outside the hot path are optional: None = their outputs come in as inputs
+        self.fpn = build_backbone(backbone2d) if backbone2d is not None else None
+        self.feature_2d = build_backbone(feature_2d) if feature_2d is not None else None
+        self.backbone3d = build_backbone(backbone_3d) if backbone_3d is not None else None
+        self.tsdf_head = build_head(tsdf_head) if tsdf_head is not None else None
+        self.detection_backbone = build_backbone(detection_backbone)
+        self.detection_head = build_head(detection_head)
+        if not use_feature_transform:
+            feature_transform = None
+        self.feature_transform = TransformFeaturesBBoxes(**feature_transform) if feature_transform is not None else None
+        self.pixel_mean = torch.Tensor(pixel_mean).view(-1, 1, 1)
+        self.pixel_std = torch.Tensor(pixel_std).view(-1, 1, 1)
+        self.voxel_size = voxel_size
+        self.n_scales = n_scales
+        self.voxel_dim_train = voxel_dim_train
+        self.voxel_dim_test = voxel_dim_test
+        self.voxel_size_fcaf3d = voxel_size_fcaf3d
+        self.use_batchnorm_train = use_batchnorm_train
+        self.use_batchnorm_test = use_batchnorm_test
+        self.save_path = save_path
+        if save_path is not None:
+            os.makedirs(save_path, exist_ok=True)
+        self.loss_weight_recon = loss_weight_recon
+        self.loss_weight_detection = loss_weight_detection
+        self.max_points = max_points
+        self.origin = torch.tensor(origin, dtype=torch.float32).view(1, 3)
+        self.backbone2d_stride = backbone2d_stride
+        self.ray_marching_type = ray_marching_type
+        self.neus_threshold = neus_threshold
+        self.depth_points = depth_points
+        if ray_marching_type == "neus":
+            assert neus_threshold is not None
+        elif ray_marching_type == "depth":
+            assert depth_points in [1, 2, 3, 4]
+        self.middle_save_path = middle_save_path
+        self.middle_visualize_path = middle_visualize_path
+        self.point_sampler = point_sampler
+        self.voxel_dim = voxel_dim_test
+        self.initialize_volume()
+
+    # ---- state (reference :200-209) --------------------------------------------------------------------------
+    def initialize_volume(self):
+        self.volume = 0
+        self.valid = 0
+        self.points_detection = []
+        self._views = []          # (projection [B,3,4], feature [B,C,H,W]) collected by aggregate_2d_features
+
+    def normalizer(self, x):
+        return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
+
+    def backbone2d(self, image):
+        return self.feature_2d(self.fpn(image))
+
+    def init_weights(self):
+        pass
+
+    # ---- dense unprojection (reference :220-257) ------------------------------------------------------------------
+    def aggregate_2d_features(self, projection, feature):
+        """Collect one view.  The reference adds a full C x G volume per call; here the views are only recorded and
+        clear_3d_features() runs ONE kernel over all of them (sum in view order + mean), which is bit-identical."""
+        self._views.append((projection, feature))
+
+    def clear_3d_features(self):
+        projs = torch.stack([p for p, _ in self._views], dim=0)        # [V,B,3,4]
+        feats = torch.stack([f for _, f in self._views], dim=0)        # [V,B,C,H,W]
+        B = feats.shape[1]
+        vols, valids = [], []
+        org = self.origin.view(-1).tolist()
+        for b in range(B):
+            nhwc = rma.to_nhwc(feats[:, b])
+            vol, cnt = rma.backproject_accum(nhwc, projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                                             self.backbone2d_stride)
+            vols.append(vol)
+            valids.append((cnt > 0).unsqueeze(0))
+        self.volume = torch.stack(vols)
+        self.valid = torch.stack(valids)
+        self._views = []
+
+    # ---- ray marching (reference :260-307, :687-956) ---------------------------------------------------------------
+    def _rows(self, projection, features, tsdf, mode, thr=None, k=0, grids=300):
+        B = features.shape[0]
+        assert B == 1, "the reference is structurally batch-1 per GPU (ray_marching.py:707)"
+        nhwc = rma.to_nhwc(features)
+        pinv = rma.projection_inverse(projection.cpu(), 1).to(features.device)
+        rows, per_view = rma.rma_view_rows(nhwc, pinv, tsdf[0, 0], self.voxel_dim, self.voxel_size,
+                                           self.origin.view(-1).tolist(), grids, thr if thr is not None else 0.0, mode, k)
+        return None if rows.shape[0] == 0 else [rows]
+
+    def ray_projection_neus(self, projection, features, tsdf, grids=300, weight_threshold=None):
+        """projection [B,3,4] stride-scaled, features [B,C,H,W], tsdf [B,1,X,Y,Z] -> [rows [M,4+C]] or None."""
+        return self._rows(projection, features, tsdf, "neus", weight_threshold, 0, grids)
+
+    def ray_projection_depth(self, projection, features, tsdf, grids=300, select_grids=None):
+        return self._rows(projection, features, tsdf, "depth", None, select_grids, grids)
+
+    def aggregate_2d_features_ray_marching(self, projections, features, tsdf):
+        """projections [V,B,3,4] full-res, features [V,B,C,H,W], tsdf [B,1,X,Y,Z] -> self.points_detection =
+        [points [M,3+C]] per scene (features scaled by w/mean(w))."""
+        B = projections.shape[1]
+        assert B == 1, "the reference is structurally batch-1 per GPU (ray_marching.py:707)"
+        self.points_detection = []
+        for b in range(B):
+            nhwc = rma.to_nhwc(features[:, b])
+            pinv = rma.projection_inverse(projections[:, b].cpu(), self.backbone2d_stride).to(nhwc.device)
+            pts, _ = rma.aggregate_rows(nhwc, pinv, tsdf[b, 0], self.voxel_dim, self.voxel_size,
+                                        self.origin.view(-1).tolist(), 300, self.neus_threshold,
+                                        self.ray_marching_type, self.depth_points)
+            self.points_detection.append(pts)
+
+    # ---- detection (reference :322-407) ------------------------------------------------------------------------------
+    def switch_pointcloud(self, points, gt_bboxes, offsets, test):
+        coords, feats, new_gt = [], [], []
+        for b in range(len(points)):
+            mask = None
+            if self.max_points is not None:
+                mask = sample_points(points[b], max_points=self.max_points)        # numpy global RNG, like the reference
+            off = offsets[b].view(-1).tolist()
+            c, f = rma.select_rows(points[b], off, mask)
+            gt = gt_bboxes[b] if gt_bboxes is not None else None
+            if self.feature_transform is not None and not test:
+                c, gt = self.feature_transform(c, gt)
+            coords.append(c)
+            feats.append(f)
+            new_gt.append(gt)
+        return coords, feats, new_gt
+
+    def fcaf3d_detection(self, inputs, points, test=False):
+        coords, feats, gts = self.switch_pointcloud(points, inputs.get("gt_bboxes_3d"), inputs["offset"], test)
+        x = S.sparse_collate(list(zip(coords, feats)), self.voxel_size_fcaf3d)
+        levels = self.detection_backbone(x)
+        centernesses, bbox_preds, cls_scores, pts = map(list, self.detection_head(levels))
+        losses = {}
+        if self.detection_head.loss_cls is not None and inputs.get("gt_bboxes_3d") is not None:
+            losses = self.detection_head.loss(centernesses, bbox_preds, cls_scores, pts, gts, inputs["gt_labels_3d"])
+        if test:
+            self.last_detections = self.detection_head.get_bboxes(centernesses, bbox_preds, cls_scores, pts,
+                                                                  inputs.get("scene"), self.save_path)
+        return losses
+
+    # ---- top level (reference :409-521, :592-682) -----------------------------------------------------------------------
+    def _features(self, inputs, batched):
+        if self.fpn is None:
+            f = inputs["features"]
+            return torch.stack(f, dim=1) if isinstance(f, (list, tuple)) else f      # [V,B,C,H,W]
+        images = inputs["imgs"].transpose(0, 1)
+        if batched:
+            x = self.backbone2d(self.normalizer(images.reshape(-1, *images.shape[2:])))
+            return x.view(images.shape[0], images.shape[1], *x.shape[1:])
+        return torch.stack([self.backbone2d(self.normalizer(im)) for im in images], dim=0)
+
+    def _run(self, inputs, test):
+        self.voxel_dim = self.voxel_dim_test if test else self.voxel_dim_train
+        self.initialize_volume()
+        projections = inputs["projection"].transpose(0, 1)
+        features = self._features(inputs, self.use_batchnorm_test if test else self.use_batchnorm_train)
+        for projection, feature in zip(projections, features):
+            self.aggregate_2d_features(projection, feature)
+        self.clear_3d_features()
+        recon_loss = {}
+        if self.backbone3d is not None:
+            recon_result, recon_loss = self.tsdf_head(self.backbone3d(self.volume), inputs.get("tsdf_list"))
+            tsdf = recon_result["scene_tsdf_004"]
+        else:
+            tsdf = inputs["tsdf"]
+        self.aggregate_2d_features_ray_marching(projections, features, tsdf)
+        detection_loss = self.fcaf3d_detection(inputs, self.points_detection, test=test)
+        losses = {k: v * self.loss_weight_recon for k, v in recon_loss.items()}
+        losses.update({k: v * self.loss_weight_detection for k, v in detection_loss.items()})
+        return losses
+
+    def forward_train(self, inputs):
+        return self._run(inputs, test=False)
+
+    def forward_test(self, inputs):
+        self._run(inputs, test=True)
+        return [{}]
+
+    def forward(self, return_loss=True, rescale=False, **kwargs):
+        if return_loss:
+            return self.forward_train(kwargs)
+        return self.forward_test(self.data_converter(kwargs))
+
+    def data_converter(self, data):
+        """stack the per-sample lists of the DataContainer scatter (reference :653-682)"""
+        for key in ("imgs", "projection", "offset", "axis_align_matrix"):
+            if key in data and isinstance(data[key], (list, tuple)):
+                data[key] = torch.stack(list(data[key]), dim=0)
+        if "tsdf_dict" in data:
+            names = list(data["tsdf_dict"][0].keys())
+            dev = data["projection"].device
+            data["tsdf_list"] = {n: torch.stack([d[n].tsdf_vol.unsqueeze(0) for d in data["tsdf_dict"]], 0).to(dev)
+                                 for n in names}
+            data.pop("tsdf_dict")
+        data.pop("axis_align_matrix", None)
+        return data
+
+    def parse_losses(self, losses):
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f"{name} is not a tensor or list of tensors")
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["total_loss"] = loss
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item() if isinstance(value, torch.Tensor) else float(value)
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        data = self.data_converter(data)
+        loss, log_vars = self.parse_losses(self(**data))
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["projection"]))
+
+    def val_step(self, data, optimizer=None):
+        return self(**data, return_loss=False)

@@ -189,6 +189,10 @@ def test_fcaf3d_forward_vs_oracle(device, n_reg, yaw):
                       pts_threshold=1500, assigner=None, yaw_parametrization=yaw, test_cfg=dict(nms_pre=300, iou_thr=.5, score_thr=.01))
     _randomise(backbone, 1)
     _randomise(head, 2)
+    head.init_weights()            # head convs ~ N(0, .01) like the reference (:100-104): keeps exp(reg) finite
+    with torch.no_grad():
+        for sc in head.scales:
+            sc.scale.fill_(1.3)
     backbone.eval(); head.eval()
     Cq, Fq, _ = RO.voxelize(torch.from_numpy(pts), torch.from_numpy(feats), 0.01)
     levels = SO.backbone_forward(backbone, Cq.numpy(), Fq.numpy())
