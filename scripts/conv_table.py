@@ -1,0 +1,27 @@
+"""per-launch table of the sparse-conv calls of one scene (rows, Cin, Cout, K, ms, TF/s) -- diagnostics"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from cnrma_amd import pipeline, synth
+dev = torch.device("cuda:0")
+V, C, H, W, dims, stride = synth.SHAPES["S"]
+sc = synth.make_scene("S", seed=0)
+feat, proj, tsdf = sc["features"][:, 0].to(dev), sc["projection"][:, 0], sc["tsdf"][0, 0].to(dev)
+backbone, head = bench.build_model(C, dev)
+cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
+for _ in range(2):
+    pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+prof = bench.KernelProfile(); prof.install()
+pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+prof.uninstall(); torch.cuda.synchronize()
+tot = 0
+for name, a, e0, e1 in prof.records:
+    ms = e0.elapsed_time(e1)
+    if name == "cnrma_sparse_conv_f32":
+        rows, cin, cout, K = a[11], a[1], a[5], a[3]
+        fl = 2.0 * K * cin * cout * rows
+        tot += ms
+        print(f"conv rows={rows:7d} Cin={cin:4d} Cout={cout:4d} K={K:2d} {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s")
+    else:
+        print(f"{name} {ms:.3f} ms")
+print("conv total", tot)
