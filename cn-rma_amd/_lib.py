@@ -31,11 +31,12 @@ SIGNATURES = {
     "cnrma_mask_to_index": (c_int, [P, P, P, L, P, P]),
     "cnrma_select_rows_f32": (c_int, [P, L, I, P, F, F, F, P, P, P]),
     "cnrma_voxelize_workspace_bytes": (c_size_t, [L]),
-    "cnrma_voxelize_f32": (c_int, [P, P, L, I, F, I, P, P, L, P, P, P, P, P, P]),
+    "cnrma_voxelize_f32": (c_int, [P, P, L, I, F, I, I, P, P, L, P, P, P, P, P, P]),
     "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, P]),
     "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, P, P, P]),
     "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
-    "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P]),
+    "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
+    "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_convtr_gen_f32": (c_int, [P, P, L, P, I, I, P, I, P, P, I, P, P, P]),
     "cnrma_sparse_maxpool_f32": (c_int, [P, I, P, I, P, L, P, P]),
     "cnrma_instnorm_workspace_bytes": (c_size_t, [I]),

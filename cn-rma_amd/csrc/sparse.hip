@@ -10,6 +10,8 @@
 // activation epilogue is fused into the store.
 #include "common.h"
 
+#include <hipcub/hipcub.hpp>
+
 namespace {
 
 // ================================================================================================================
@@ -20,17 +22,53 @@ struct UniqueWs {
   int32_t* idx;     // [n] output row of i or -1
   uint8_t* flag;    // [n] 1 when row i is the representative of its voxel
   void* scan;       // scan workspace
+  // Morton ordering (voxelise): radix-sort double buffers + hipcub temporary storage
+  uint64_t* key_a; uint64_t* key_b;
+  int32_t* val_a; int32_t* val_b;
+  void* sort_tmp; size_t sort_tmp_bytes;
 };
+
+size_t sort_temp_bytes(int64_t n) {
+  size_t bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                                    (const int32_t*)nullptr, (int32_t*)nullptr, (int)n, 0, 64, nullptr);
+  if (e != hipSuccess || bytes == 0) bytes = (size_t)n * 16 + (1u << 20);   // no device (CPU-only container): estimate
+  (void)hipGetLastError();
+  return (bytes + 255) / 256 * 256;
+}
 
 __host__ UniqueWs carve_unique_ws(void* workspace, int64_t n) {
   UniqueWs w;
   char* p = reinterpret_cast<char*>(workspace);
   int64_t n4 = (n + 3) / 4 * 4;
+  w.key_a = reinterpret_cast<uint64_t*>(p); p += n4 * 8;
+  w.key_b = reinterpret_cast<uint64_t*>(p); p += n4 * 8;
+  w.val_a = reinterpret_cast<int32_t*>(p); p += n4 * 4;
+  w.val_b = reinterpret_cast<int32_t*>(p); p += n4 * 4;
   w.slot = reinterpret_cast<int32_t*>(p); p += n4 * 4;
   w.idx = reinterpret_cast<int32_t*>(p); p += n4 * 4;
   w.flag = reinterpret_cast<uint8_t*>(p); p += n4;
+  p = reinterpret_cast<char*>(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  w.sort_tmp_bytes = sort_temp_bytes(n);
+  w.sort_tmp = p; p += w.sort_tmp_bytes;
   w.scan = p;
   return w;
+}
+
+// 48-bit Morton code of the biased coordinates (bias 32768 is a multiple of every tensor stride, so the children of
+// one strided parent are contiguous in this order and every coarser level inherits the ordering), batch on top
+__device__ __forceinline__ uint64_t spread3(uint32_t v) {
+  uint64_t x = v & 0xFFFFu;
+  x = (x | (x << 32)) & 0x00FF00000000FFFFull;   // not needed for 16 bits but keeps the classic ladder readable
+  x = (x | (x << 16)) & 0x00FF0000FF0000FFull;
+  x = (x | (x << 8)) & 0xF00F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x30C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x9249249249249249ull;
+  return x;
+}
+__device__ __forceinline__ uint64_t morton_key(int b, int x, int y, int z) {
+  return ((uint64_t)(uint16_t)b << 48) | (spread3((uint32_t)(x + 32768)) << 2) | (spread3((uint32_t)(y + 32768)) << 1) |
+         spread3((uint32_t)(z + 32768));
 }
 
 // MODE 0: float coords / voxel_size -> floor (voxelise); MODE 1: int coords -> floor(p / s) * s (stride)
@@ -100,6 +138,43 @@ __global__ __launch_bounds__(256) void uniq_write_kernel(const void* __restrict_
   vals[slot[i]] = j;  // the table now maps voxel key -> output row
 }
 
+// sort key of row i: Morton code for representatives, all-ones (sorted last) for duplicates / dead rows
+template <int MODE>
+__global__ __launch_bounds__(256) void uniq_sortkey_kernel(const void* __restrict__ src, int64_t n_cap,
+                                                           const int32_t* __restrict__ n_dev, float vs, int new_stride,
+                                                           int batch_id, const uint8_t* __restrict__ flag,
+                                                           uint64_t* __restrict__ key, int32_t* __restrict__ val) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cap) return;
+  uint64_t k = ~0ull;
+  if (i < live_rows(n_cap, n_dev) && flag[i]) {
+    int b, x, y, z;
+    quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
+    k = morton_key(b, x, y, z);
+  }
+  key[i] = k;
+  val[i] = (int32_t)i;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void uniq_write_sorted_kernel(const void* __restrict__ src, int64_t n_cap, float vs,
+                                                                int new_stride, int batch_id,
+                                                                const int32_t* __restrict__ order,
+                                                                const int32_t* __restrict__ n_out,
+                                                                const int32_t* __restrict__ slot,
+                                                                int32_t* __restrict__ vals,
+                                                                int32_t* __restrict__ out_coords,
+                                                                int32_t* __restrict__ out_src) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= live_rows(n_cap, n_out)) return;
+  const int64_t i = order[j];
+  int b, x, y, z;
+  quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
+  reinterpret_cast<int4*>(out_coords)[j] = make_int4(b, x, y, z);
+  if (out_src) out_src[j] = (int32_t)i;
+  vals[slot[i]] = (int32_t)j;
+}
+
 // out[j][:] = in[src[j]][:]   (lanes across channels: coalesced row copies)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ src,
                                                           int64_t n_cap, const int32_t* __restrict__ n_dev, int C,
@@ -124,7 +199,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 template <int MODE>
 int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, int new_stride, int batch_id,
                uint64_t* keys, int32_t* vals, int64_t cap, int32_t* out_coords, int32_t* out_src, int32_t* n_out,
-               void* workspace, hipStream_t st) {
+               void* workspace, hipStream_t st, bool morton = false) {
   if (n_cap <= 0 || cap < 2 || (cap & (cap - 1)) != 0 || cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
   UniqueWs w = carve_unique_ws(workspace, n_cap);
   hipError_t e = hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint64_t), st);
@@ -137,8 +212,21 @@ int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, i
   hipLaunchKernelGGL(uniq_flag_kernel, dim3(nb), dim3(256), 0, st, n_cap, n_dev, vals, w.slot, w.flag);
   int rc = cnrma_mask_to_index(w.flag, w.idx, n_out, n_cap, w.scan, st);
   if (rc) return rc;
-  hipLaunchKernelGGL((uniq_write_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
-                     batch_id, w.idx, w.slot, vals, out_coords, out_src);
+  if (!morton) {
+    hipLaunchKernelGGL((uniq_write_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
+                       batch_id, w.idx, w.slot, vals, out_coords, out_src);
+  } else {
+    // spatial (Morton) row order: a tile of consecutive rows is a compact block of voxels, so the gathers of the
+    // convolutions hit L2 and whole kernel offsets can be skipped per tile on thin surfaces
+    hipLaunchKernelGGL((uniq_sortkey_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
+                       batch_id, w.flag, w.key_a, w.val_a);
+    size_t tmp = w.sort_tmp_bytes;
+    hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tmp, w.key_a, w.key_b, w.val_a, w.val_b, (int)n_cap,
+                                                       0, 64, st);
+    if (e2 != hipSuccess) return -(int)e2;
+    hipLaunchKernelGGL((uniq_write_sorted_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, vs, new_stride,
+                       batch_id, w.val_b, n_out, w.slot, vals, out_coords, out_src);
+  }
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -174,8 +262,13 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
 
 // ================================================================================================================
 // fused sparse convolution: output-stationary gather-GEMM on v_mfma_f32_32x32x2_f32
-//   block = 256 threads = 4 waves; tile = (32*WM) output rows x (32*WN) output channels, WM*WN == 4
-//   per (kernel offset k, 32-channel slice of Cin): gather A[rows][32] through nbr, stage W[k][32][cols], 16 MFMAs/wave
+//   block = 256 threads = 4 waves arranged WAVES_M x WAVES_N; every wave owns TM x TN accumulator tiles of 32x32
+//   (register blocking: one LDS read feeds TN resp. TM MFMAs); block tile BM x BN = (32*TM*WAVES_M) x (32*TN*WAVES_N).
+//   A "stage" = (kernel offset k, 32-channel slice of Cin): gather A[BM][32] through the neighbour table, stage
+//   W[k][32][BN], then 16*TM*TN MFMAs per wave.  Stages are software-pipelined: the global loads of stage s+1 are in
+//   flight (in registers) while the MFMAs of stage s run.  Kernel offsets at which no row of the tile has a neighbour
+//   are skipped (frequent with Morton-ordered rows on thin surfaces).  Small layers are split over kernel offsets
+//   (grid.z) into fp32 partial slabs that a second kernel reduces in a fixed order -- deterministic, no atomics.
 // ================================================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
@@ -186,131 +279,284 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(
-    const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr, int K, const float* __restrict__ weight,
-    int Cout, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual,
-    int act, float* __restrict__ out, int64_t no_cap, const int32_t* __restrict__ no_dev, int64_t out_row_offset_mul,
-    int w_slices) {
-  constexpr int BM = 32 * WM, BN = 32 * WN;
+struct ConvArgs {
+  const float* in; int Cin;
+  const int32_t* nbr; int K;
+  const float* weight; int Cout;
+  const float* scale; const float* shift; const float* residual; int act;
+  float* out; int64_t no_cap; const int32_t* no_dev;
+  int slices;        // > 1: generative transpose, slice z uses W[z] and writes rows z*n_live + i
+  int splits;        // > 1: split over kernel offsets, raw partial sums go to slab[z]
+  int k_per_split;
+  float* slab;       // [splits][no_cap][Cout]
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   constexpr int LDA = BM + 1;   // k-major A tile, odd stride: conflict-light scattered 4-byte writes
   constexpr int LDB = BN + 4;   // 16-B aligned rows for ds_write_b128
+  constexpr int A_ITERS = BM * (BK / 4) / 256;
+  constexpr int B_ITERS = BK * (BN / 4) / 256;
+  static_assert(WAVES_M * WAVES_N == 4 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
+  constexpr int KMAX = 27;
   __shared__ float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  __shared__ int32_t nbr_s[BM];
+  __shared__ int32_t nbr_s[BM * KMAX];   // the tile's slice of the neighbour table, [row][K]: gathers never chase a
+                                         // dependent global load
+  __shared__ unsigned mask_s;
 
-  const int64_t n_live = live_rows(no_cap, no_dev);
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
   const int64_t tile0 = (int64_t)blockIdx.x * BM;
   if (tile0 >= n_live) return;
   const int cout0 = blockIdx.y * BN;
-  // grid.z walks weight slices (generative transposed conv: slice z writes rows z*n_live + i with W[z])
   const int zs = blockIdx.z;
-  const float* Wz = weight + (int64_t)zs * (w_slices > 1 ? (int64_t)K * Cin * Cout : 0);
-  const int64_t out_base = (int64_t)zs * out_row_offset_mul * n_live;
-
+  const int Cin = p.Cin, Cout = p.Cout, K = p.K;
+  const float* Wz = p.weight + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout : 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid / WN, wc = wid % WN;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const int wr = wid / WAVES_N, wc = wid % WAVES_N;
 
-  for (int k = 0; k < K; ++k) {
-    int nb = -1;
-    if (tid < BM) {
-      const int64_t row = tile0 + tid;
-      if (row < n_live) nb = nbr ? nbr[row * K + k] : (int32_t)row;
-      nbr_s[tid] = nb;
+  // ---- which kernel offsets have at least one neighbour in this tile (restricted to this block's k-range)
+  int k_lo = 0, k_hi = K;
+  if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
+  unsigned mask = 0;
+  if (p.nbr == nullptr) {
+    mask = 1u;                                    // identity map (K == 1)
+  } else {
+    if (tid == 0) mask_s = 0;
+    __syncthreads();
+    unsigned local = 0;
+    const int rows_here = (int)min((int64_t)BM, n_live - tile0);
+    const int32_t* nb = p.nbr + tile0 * K;
+    for (int i = tid; i < BM * K; i += 256) {
+      const int k = i % K;
+      const int32_t v = i < rows_here * K ? nb[i] : -1;
+      nbr_s[i] = v;
+      if (k >= k_lo && k < k_hi && v >= 0) local |= 1u << k;
     }
-    if (!__syncthreads_or(nb >= 0)) continue;   // nobody in this tile has a neighbour at offset k
-    const float* Wk = Wz + (int64_t)k * Cin * Cout;
-    for (int cin0 = 0; cin0 < Cin; cin0 += BK) {
-      // ---- stage A: BM rows x 32 channels, 8 lanes per row (one 128-B line per row)
-#pragma unroll
-      for (int i = 0; i < BM * (BK / 4) / 256; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx >> 3, kc = idx & 7;
-        const int32_t src = nbr_s[row];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int cin = cin0 + kc * 4;
-        if (src >= 0) {
-          const float* p = in + (int64_t)src * Cin + cin;
-          if (cin + 3 < Cin && (Cin & 3) == 0) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (cin < Cin) v.x = p[0];
-            if (cin + 1 < Cin) v.y = p[1];
-            if (cin + 2 < Cin) v.z = p[2];
-            if (cin + 3 < Cin) v.w = p[3];
-          }
-        }
-        As[(kc * 4 + 0) * LDA + row] = v.x;
-        As[(kc * 4 + 1) * LDA + row] = v.y;
-        As[(kc * 4 + 2) * LDA + row] = v.z;
-        As[(kc * 4 + 3) * LDA + row] = v.w;
-      }
-      // ---- stage B: 32 x BN slice of W[k]
-#pragma unroll
-      for (int i = 0; i < BK * (BN / 4) / 256; ++i) {
-        const int idx = tid + i * 256;
-        const int r = idx / (BN / 4), c4 = idx % (BN / 4);
-        const int cin = cin0 + r, col = cout0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cin < Cin) {
-          const float* p = Wk + (int64_t)cin * Cout + col;
-          if (col + 3 < Cout && (Cout & 3) == 0) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            if (col < Cout) v.x = p[0];
-            if (col + 1 < Cout) v.y = p[1];
-            if (col + 2 < Cout) v.z = p[2];
-            if (col + 3 < Cout) v.w = p[3];
-          }
-        }
-        *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = v;
-      }
-      __syncthreads();
-      const float* a_p = As + (lane >> 5) * LDA + wr * 32 + (lane & 31);
-      const float* b_p = Bs + (lane >> 5) * LDB + wc * 32 + (lane & 31);
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_p[kk * LDA], b_p[kk * LDB], acc, 0, 0, 0);
-      }
-      __syncthreads();
-    }
+    if (local) atomicOr(&mask_s, local);
+    __syncthreads();
+    mask = mask_s;
   }
 
-  // ---- epilogue: folded BN / bias, residual, activation.  D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-  const int col = cout0 + wc * 32 + (lane & 31);
-  if (col < Cout) {
-    const float sc = scale ? scale[col] : 1.0f;
-    const float sh = shift ? shift[col] : 0.0f;
+  f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = tile0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < n_live) {
-        float v = acc[r];
-        if (scale) v = v * sc;
-        if (shift) v = v + sh;
-        const int64_t o = (out_base + row) * Cout + col;
-        if (residual) v = v + residual[o];
-        out[o] = apply_act(v, act);
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  float4 ra[A_ITERS], rb[B_ITERS];
+  auto load_stage = [&](int k, int cin0) {
+    const float* Wk = Wz + (int64_t)k * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, kc = idx & 7;
+      const int64_t grow = tile0 + row;
+      int32_t src;
+      if (p.nbr) src = nbr_s[row * K + k];
+      else src = grow < n_live ? (int32_t)grow : -1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cin = cin0 + kc * 4;
+      if (src >= 0) {
+        const float* q = p.in + (int64_t)src * Cin + cin;
+        if (cin + 3 < Cin && (Cin & 3) == 0) {
+          v = *reinterpret_cast<const float4*>(q);
+        } else {
+          if (cin < Cin) v.x = q[0];
+          if (cin + 1 < Cin) v.y = q[1];
+          if (cin + 2 < Cin) v.z = q[2];
+          if (cin + 3 < Cin) v.w = q[3];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+      const int cin = cin0 + r, col = cout0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cin < Cin) {
+        const float* q = Wk + (int64_t)cin * Cout + col;
+        if (col + 3 < Cout && (Cout & 3) == 0) {
+          v = *reinterpret_cast<const float4*>(q);
+        } else {
+          if (col < Cout) v.x = q[0];
+          if (col + 1 < Cout) v.y = q[1];
+          if (col + 2 < Cout) v.z = q[2];
+          if (col + 3 < Cout) v.w = q[3];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, kc = idx & 7;
+      As[(kc * 4 + 0) * LDA + row] = ra[i].x;
+      As[(kc * 4 + 1) * LDA + row] = ra[i].y;
+      As[(kc * 4 + 2) * LDA + row] = ra[i].z;
+      As[(kc * 4 + 3) * LDA + row] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+      *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = rb[i];
+    }
+  };
+
+  // ---- pipelined stage loop over (active k, cin slice)
+  int k = mask ? __ffs(mask) - 1 : -1;
+  int cin0 = 0;
+  if (k >= 0) load_stage(k, 0);
+  while (k >= 0) {
+    store_stage();
+    __syncthreads();
+    // next stage
+    int nk = k, ncin = cin0 + BK;
+    if (ncin >= Cin) {
+      ncin = 0;
+      const unsigned rest = mask & ~((2u << k) - 1u);
+      nk = rest ? __ffs(rest) - 1 : -1;
+    }
+    if (nk >= 0) load_stage(nk, ncin);           // global loads in flight during the MFMAs below
+    const float* a_p = As + (lane >> 5) * LDA + wr * (32 * TM) + (lane & 31);
+    const float* b_p = Bs + (lane >> 5) * LDB + wc * (32 * TN) + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) av[a] = a_p[kk * LDA + a * 32];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bv[b] = b_p[kk * LDB + b * 32];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    k = nk;
+    cin0 = ncin;
+  }
+
+  // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool partial = p.splits > 1;
+  float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
+  const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
+    if (col >= Cout) continue;
+    const float sc = (!partial && p.scale) ? p.scale[col] : 1.0f;
+    const float sh = (!partial && p.shift) ? p.shift[col] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = tile0 + wr * (32 * TM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < n_live) {
+          float v = acc[a][b][r];
+          const int64_t o = (out_base + row) * Cout + col;
+          if (!partial) {
+            if (p.scale) v = v * sc;
+            if (p.shift) v = v + sh;
+            if (p.residual) v = v + p.residual[o];
+            v = apply_act(v, p.act);
+          }
+          dst[o] = v;
+        }
       }
     }
   }
 }
 
+// reduce the split-K slabs in a fixed order and apply the fused epilogue
+__global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int64_t total = n_live * p.Cout;
+  const int64_t slab_stride = p.no_cap * p.Cout;
+  for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (int64_t)gridDim.x * blockDim.x * 4) {
+    if ((p.Cout & 3) == 0) {
+      float4 s = *reinterpret_cast<const float4*>(p.slab + t);
+      for (int z = 1; z < p.splits; ++z) {
+        const float4 q = *reinterpret_cast<const float4*>(p.slab + (int64_t)z * slab_stride + t);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      }
+      float v[4] = {s.x, s.y, s.z, s.w};
+      const int col = (int)(t % p.Cout);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = v[j];
+        if (p.scale) x = x * p.scale[col + j];
+        if (p.shift) x = x + p.shift[col + j];
+        if (p.residual) x = x + p.residual[t + j];
+        v[j] = apply_act(x, p.act);
+      }
+      *reinterpret_cast<float4*>(p.out + t) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int j = 0; j < 4 && t + j < total; ++j) {
+        float x = 0.0f;
+        for (int z = 0; z < p.splits; ++z) x += p.slab[(int64_t)z * slab_stride + t + j];
+        const int col = (int)((t + j) % p.Cout);
+        if (p.scale) x = x * p.scale[col];
+        if (p.shift) x = x + p.shift[col];
+        if (p.residual) x = x + p.residual[t + j];
+        p.out[t + j] = apply_act(x, p.act);
+      }
+    }
+  }
+}
+
+// how many kernel-offset groups a layer is split into: enough blocks to fill 256 CUs a few times over
+int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes) {
+  if (K <= 1) return 1;
+  const int64_t tiles = ceil_div(rows, bm) * ceil_div(Cout, bn);
+  if (tiles >= 512) return 1;
+  int s = (int)ceil_div(1024, tiles);
+  if (s > K) s = K;
+  const size_t per = (size_t)rows * Cout * sizeof(float);
+  if (per == 0) return 1;
+  const int64_t fit = (int64_t)(ws_bytes / per);
+  if (s > fit) s = (int)fit;
+  return s < 2 ? 1 : s;
+}
+
 int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float* weight, int Cout, const float* scale,
                 const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
-                int slices, hipStream_t st) {
-  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0) return CNRMA_EINVAL;
-  if (Cout > 32) {
-    dim3 grid((unsigned)ceil_div(no_cap, 64), (unsigned)ceil_div(Cout, 64), (unsigned)slices);
-    hipLaunchKernelGGL((sparse_conv_mfma_kernel<2, 2>), grid, dim3(256), 0, st, in, Cin, nbr, K, weight, Cout, scale,
-                       shift, residual, act, out, no_cap, no_dev, (int64_t)1, slices);
-  } else {
-    dim3 grid((unsigned)ceil_div(no_cap, 128), 1, (unsigned)slices);
-    hipLaunchKernelGGL((sparse_conv_mfma_kernel<4, 1>), grid, dim3(256), 0, st, in, Cin, nbr, K, weight, Cout, scale,
-                       shift, residual, act, out, no_cap, no_dev, (int64_t)1, slices);
+                int slices, void* workspace, size_t ws_bytes, hipStream_t st) {
+  if (Cin <= 0 || Cout <= 0 || K <= 0 || K > 27 || no_cap <= 0) return CNRMA_EINVAL;
+  ConvArgs p{in, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out, no_cap, no_dev, slices, 1, K,
+             reinterpret_cast<float*>(workspace)};
+  int bm, bn;
+  // tile choice: wide tiles for wide layers; 64x64 tiles for short layers (more blocks, less row padding)
+  enum { T128x128, T128x64, T64x64, T128x32 } shape;
+  if (Cout <= 32) { shape = T128x32; bm = 128; bn = 32; }
+  else if (no_cap < 16384) { shape = T64x64; bm = 64; bn = 64; }
+  else if (Cout >= 128) { shape = T128x128; bm = 128; bn = 128; }
+  else { shape = T128x64; bm = 128; bn = 64; }
+  if (slices == 1 && workspace != nullptr) {
+    p.splits = choose_splits(no_cap, Cout, K, bm, bn, ws_bytes);
+    p.k_per_split = (int)ceil_div(K, p.splits);
+    p.splits = (int)ceil_div(K, p.k_per_split);
+    if (p.splits < 2) { p.splits = 1; p.k_per_split = K; }
+  }
+  dim3 grid((unsigned)ceil_div(no_cap, bm), (unsigned)ceil_div(Cout, bn), (unsigned)(slices > 1 ? slices : p.splits));
+  switch (shape) {
+    case T128x128: hipLaunchKernelGGL((sparse_conv_mfma_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p); break;
+    case T128x64: hipLaunchKernelGGL((sparse_conv_mfma_kernel<4, 1, 1, 2>), grid, dim3(256), 0, st, p); break;
+    case T64x64: hipLaunchKernelGGL((sparse_conv_mfma_kernel<2, 2, 1, 1>), grid, dim3(256), 0, st, p); break;
+    case T128x32: hipLaunchKernelGGL((sparse_conv_mfma_kernel<4, 1, 1, 1>), grid, dim3(256), 0, st, p); break;
+  }
+  if (p.splits > 1) {
+    int64_t blocks = ceil_div(no_cap * Cout / 4 + 1, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
   }
   CNRMA_LAUNCH_CHECK();
   return 0;
@@ -538,17 +784,17 @@ inline unsigned grid_for(int64_t work, int block = 256, int64_t max_blocks = 655
 // ================================================================================================================
 extern "C" size_t cnrma_voxelize_workspace_bytes(int64_t M) {
   int64_t n4 = (M + 3) / 4 * 4;
-  return (size_t)(n4 * 9) + cnrma_scan_workspace_bytes(M) + 256;
+  return (size_t)(n4 * 33) + sort_temp_bytes(M) + cnrma_scan_workspace_bytes(M) + 1024;
 }
 
 extern "C" int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, int C, float voxel_size,
-                                  int batch_id, uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap,
-                                  int32_t* out_coords, float* out_feats, int32_t* out_src, int32_t* n_out,
-                                  void* workspace, void* stream) {
-  if (C <= 0 || !(voxel_size > 0.0f) || out_src == nullptr) return CNRMA_EINVAL;
+                                  int batch_id, int row_order, uint64_t* hash_keys, int32_t* hash_vals,
+                                  int64_t hash_cap, int32_t* out_coords, float* out_feats, int32_t* out_src,
+                                  int32_t* n_out, void* workspace, void* stream) {
+  if (C <= 0 || !(voxel_size > 0.0f) || out_src == nullptr || row_order < 0 || row_order > 1) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
   int rc = run_unique<0>(coords, M, nullptr, voxel_size, 1, batch_id, hash_keys, hash_vals, hash_cap, out_coords,
-                         out_src, n_out, workspace, st);
+                         out_src, n_out, workspace, st, row_order == 1);
   if (rc) return rc;
   if (feats && out_feats) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(M * (int64_t)(C / 4 + 1))), dim3(256), 0, st, feats, out_src, M,
@@ -588,11 +834,18 @@ extern "C" int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap
   return 0;
 }
 
+extern "C" size_t cnrma_sparse_conv_workspace_bytes(int64_t no_cap, int Cout, int K) {
+  // room for a full split over the kernel offsets of a short layer; long layers are never split
+  if (K <= 1 || no_cap >= 65536) return 0;
+  return (size_t)K * (size_t)no_cap * (size_t)Cout * sizeof(float);
+}
+
 extern "C" int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight,
                                      int Cout, const float* scale, const float* shift, const float* residual, int act,
-                                     float* out_feats, int64_t no_cap, const int32_t* no_dev, void* stream) {
+                                     float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   return launch_conv(in_feats, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
-                     as_stream(stream));
+                     workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap,
@@ -604,7 +857,8 @@ extern "C" int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float
   hipLaunchKernelGGL(convtr_coords_kernel, dim3((unsigned)ceil_div(n_cap * 8, 256)), dim3(256), 0, st, in_coords,
                      n_cap, n_dev, half_stride, out_coords);
   // 8 weight slices; slice k reads in[i] (identity map, K = 1) and writes row k*n + i
-  return launch_conv(in_feats, Cin, nullptr, 1, weight, Cout, scale, shift, nullptr, act, out_feats, n_cap, n_dev, 8, st);
+  return launch_conv(in_feats, Cin, nullptr, 1, weight, Cout, scale, shift, nullptr, act, out_feats, n_cap, n_dev, 8,
+                     nullptr, 0, st);
 }
 
 extern "C" int cnrma_sparse_maxpool_f32(const float* in_feats, int C, const int32_t* nbr, int K, float* out_feats,

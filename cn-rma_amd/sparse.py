@@ -149,9 +149,11 @@ class SparseTensor:
 
 
 # --------------------------------------------------------------------------------------------------------------
-def voxelize(coords, feats, voxel_size, batch_id=0):
+def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
     """ME.utils.batch_sparse_collate + ME.SparseTensor (ray_marching.py:328-330): floor(coord / voxel_size),
-    first occurrence wins, rows in first-occurrence order.  Returns (SparseTensor @ stride 1, src_index int32)."""
+    first occurrence wins.  row_order "first" = rows in first-occurrence order, "morton" = rows sorted by the
+    Morton code of the voxel (ME's own order is implementation-defined).  Returns (SparseTensor @ stride 1,
+    src_index int32 = source row of every output row)."""
     _lib.require_gpu()
     coords = coords.contiguous().float()
     feats = feats.contiguous().float()
@@ -163,7 +165,8 @@ def voxelize(coords, feats, voxel_size, batch_id=0):
     src = torch.empty(M, dtype=torch.int32, device=dev)
     n_out = torch.empty(1, dtype=torch.int32, device=dev)
     ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(M), dtype=torch.uint8, device=dev)
-    call("cnrma_voxelize_f32", ptr(coords), ptr(feats), M, C, float(voxel_size), int(batch_id), ptr(m.keys), ptr(m.vals),
+    call("cnrma_voxelize_f32", ptr(coords), ptr(feats), M, C, float(voxel_size), int(batch_id),
+         {"first": 0, "morton": 1}[row_order], ptr(m.keys), ptr(m.vals),
          m.cap, ptr(out_c), ptr(out_f), ptr(src), ptr(n_out), ptr(ws), stream())
     n = int(n_out.item())
     return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
@@ -190,6 +193,17 @@ def fold_bn(bn, bias=None):
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
 
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """grow-only scratch buffer per device (stream-ordered reuse: every user is enqueued on the same stream)"""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[device] = buf
+    return buf
+
 
 def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=None, act=None):
     """MinkowskiConvolution + fused epilogue: out = act((sum_k in[nbr] @ W[k]) * scale + shift + residual).
@@ -211,8 +225,10 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
         res = residual.F.contiguous() if isinstance(residual, SparseTensor) else residual
         if res is not None:
             assert res.shape == out.shape
+        ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(out_cs.n, Cout, K)
+        ws = _workspace(ws_bytes, x.device) if ws_bytes else None
         call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
-             ptr(res), ACT[act], ptr(out), out_cs.n, None, stream())
+             ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
     return SparseTensor(out, out_cs)
 
 

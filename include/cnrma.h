@@ -132,7 +132,10 @@ int cnrma_select_rows_f32(const float* points, int64_t M, int C, const int32_t* 
  * a9  voxelisation = ME.utils.batch_sparse_collate + ME.SparseTensor(quantization_mode=RANDOM_SUBSAMPLE)
  * replaces ray_marching.py:328-330 (MinkowskiEngine v0.5.4; semantics SURVEY.md Appendix A).
  * q = floor(coord / voxel_size) (true fp32 division) -> int32, batch id prepended; duplicate voxels collapse
- * to the row with the SMALLEST source index (the CPU behaviour of ME); output in order of first occurrence.
+ * to the row with the SMALLEST source index (the CPU behaviour of ME).  row_order: 0 = output rows in order of
+ * first occurrence; 1 = output rows sorted by the Morton code of (x,y,z) (ME leaves the row order
+ * implementation-defined; spatial order makes the convolution gathers cache-friendly and is inherited by every
+ * strided level).
  * hash_keys uint64[hash_cap], hash_vals int32[hash_cap]: open-addressing table, hash_cap a power of two >= 2*M;
  * on return it maps voxel key -> output row (reusable as the coordinate map of the level).
  * out_coords int32[Mu][4] (b,x,y,z), out_feats[Mu][C], out_src int32[Mu], n_out[0] = Mu (device).
@@ -140,8 +143,9 @@ int cnrma_select_rows_f32(const float* points, int64_t M, int C, const int32_t* 
  * ---------------------------------------------------------------------------------------------------------- */
 size_t cnrma_voxelize_workspace_bytes(int64_t M);
 int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, int C, float voxel_size, int batch_id,
-                       uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap, int32_t* out_coords,
-                       float* out_feats, int32_t* out_src, int32_t* n_out, void* workspace, void* stream);
+                       int row_order, uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap,
+                       int32_t* out_coords, float* out_feats, int32_t* out_src, int32_t* n_out, void* workspace,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * a10-a11  sparse operators (replace the MinkowskiEngine v0.5.4 surface used by
@@ -172,10 +176,15 @@ int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int
 /* fused sparse convolution, output-stationary gather-GEMM on fp32 MFMA:
  *   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift + residual[o] )
  * W[K][Cin][Cout] (ME "kernel" layout), scale/shift per output channel (folded BatchNorm / bias; NULL = 1 / 0),
- * residual [No][Cout] or NULL, act: 0 none, 1 ReLU, 2 ELU(alpha=1).  nbr == NULL means K == 1 identity map. */
+ * residual [No][Cout] or NULL, act: 0 none, 1 ReLU, 2 ELU(alpha=1).  nbr == NULL means K == 1 identity map.
+ * workspace (optional, may be NULL): fp32 scratch for the split over kernel offsets that short layers use to fill
+ * the chip (partial slabs reduced in a fixed order: run-to-run deterministic, no atomics);
+ * cnrma_sparse_conv_workspace_bytes gives the size that allows the widest split. */
+size_t cnrma_sparse_conv_workspace_bytes(int64_t no_cap, int Cout, int K);
 int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight, int Cout,
                           const float* scale, const float* shift, const float* residual, int act,
-                          float* out_feats, int64_t no_cap, const int32_t* no_dev, void* stream);
+                          float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */

@@ -50,10 +50,25 @@ def check(st, oc, of, tol=TOL, same_order=True):
 def test_voxelize_vs_golden(device, name):
     from cnrma_amd import sparse as S
     g = load_golden(name)
-    st, src = S.voxelize(t(g["sel_coords"], device), t(g["sel_feats"], device), 0.01)
+    st, src = S.voxelize(t(g["sel_coords"], device), t(g["sel_feats"], device), 0.01, row_order="first")
     assert (st.C.cpu().numpy() == g["vox_coords"]).all()
     assert (src.cpu().numpy() == g["vox_src"]).all()
     assert torch.equal(st.F.cpu(), t(g["sel_feats"])[t(g["vox_src"]).long()])
+    # Morton row order: same voxels, same representatives, rows sorted by the interleaved-bit key
+    sm, srcm = S.voxelize(t(g["sel_coords"], device), t(g["sel_feats"], device), 0.01, row_order="morton")
+    cm = sm.C.cpu().numpy().astype(np.int64)
+    assert sorted(map(tuple, cm)) == sorted(map(tuple, g["vox_coords"]))
+    assert sorted(srcm.cpu().numpy()) == sorted(g["vox_src"])
+    assert torch.equal(sm.F.cpu(), t(g["sel_feats"])[srcm.cpu().long()])
+
+    def morton(c):
+        k = np.zeros(len(c), dtype=np.uint64)
+        for bit in range(16):
+            for ax, sh in ((1, 2), (2, 1), (3, 0)):
+                k |= (((c[:, ax] + 32768) >> bit) & 1).astype(np.uint64) << np.uint64(3 * bit + sh)
+        return k
+    mk = morton(cm)
+    assert (np.diff(mk.astype(np.float64)) > 0).all()
 
 
 def test_voxelize_duplicates_negative_and_first_wins(device):
@@ -61,7 +76,8 @@ def test_voxelize_duplicates_negative_and_first_wins(device):
     rng = np.random.RandomState(0)
     coords = (rng.rand(20000, 3).astype(np.float32) - 0.5) * 0.6          # heavy duplication at 1 cm, negatives
     feats = rng.randn(20000, 8).astype(np.float32)
-    st, src = S.voxelize(torch.from_numpy(coords).to(device), torch.from_numpy(feats).to(device), 0.01, batch_id=3)
+    st, src = S.voxelize(torch.from_numpy(coords).to(device), torch.from_numpy(feats).to(device), 0.01, batch_id=3,
+                         row_order="first")
     Cq, Fq, first = RO.voxelize(torch.from_numpy(coords), torch.from_numpy(feats), 0.01, batch_id=3)
     assert (st.C.cpu() == Cq).all() and (src.cpu().long() == first).all() and torch.equal(st.F.cpu(), Fq)
     assert len(st) < 20000
@@ -189,6 +205,7 @@ def test_fcaf3d_forward_vs_oracle(device, n_reg, yaw):
                       pts_threshold=1500, assigner=None, yaw_parametrization=yaw, test_cfg=dict(nms_pre=300, iou_thr=.5, score_thr=.01))
     _randomise(backbone, 1)
     _randomise(head, 2)
+    torch.manual_seed(7)
     head.init_weights()            # head convs ~ N(0, .01) like the reference (:100-104): keeps exp(reg) finite
     with torch.no_grad():
         for sc in head.scales:
@@ -202,7 +219,7 @@ def test_fcaf3d_forward_vs_oracle(device, n_reg, yaw):
         x, _ = S.voxelize(torch.from_numpy(pts).to(device), torch.from_numpy(feats).to(device), 0.01)
         outs = backbone(x)
         for o, (c, f, ts) in zip(outs, levels):
-            check(o, c, f, tol=2e-4)
+            check(o, c, f, tol=2e-4, same_order=False)      # Morton row order on the device, first-occurrence in the oracle
             assert o.cs.stride == ts
         cen, box, cls, points = map(list, head(outs))
     for i in range(4):
@@ -217,11 +234,19 @@ def test_fcaf3d_forward_vs_oracle(device, n_reg, yaw):
         gi = np.argsort(ck)[np.searchsorted(np.sort(ck), common)]
         ei = np.argsort(ek)[np.searchsorted(np.sort(ek), common)]
         for got, key in ((cen[i][0], "centerness"), (box[i][0], "bbox_pred"), (cls[i][0], "cls_score")):
-            g_, e_ = got.cpu().numpy()[gi], e[key][ei]
+            g_, e_ = got.cpu().numpy()[gi].astype(np.float64), e[key][ei]
+            if key == "bbox_pred":      # exp(scale * reg): compare the exponent (random weights can overflow fp32)
+                with np.errstate(over="ignore", divide="ignore"):
+                    g_ = np.concatenate((np.log(g_[:, :6]), g_[:, 6:]), axis=1)
+                    e_ = np.concatenate((np.log(e_[:, :6]), e_[:, 6:]), axis=1)
+                fin = np.isfinite(e_) & (np.abs(e_) < 80)
+                g_, e_ = g_[fin], e_[fin]
             np.testing.assert_allclose(g_, e_, rtol=5e-4, atol=5e-4 * max(1.0, np.abs(e_).max()))
     # decode: compare the boxes of level 3 (no top-k ambiguity at this size)
     b_got = head._bbox_pred_to_bbox(points[3][0], box[3][0]).cpu().numpy()
     b_exp = SO.decode_boxes(torch.from_numpy(exp[3]["points"]), torch.from_numpy(exp[3]["bbox_pred"]), yaw).numpy()
     o1 = np.lexsort(np.round(points[3][0].cpu().numpy() / 0.01).T)
     o2 = np.lexsort(np.round(exp[3]["points"] / 0.01).T)
-    np.testing.assert_allclose(b_got[o1], b_exp[o2], rtol=1e-3, atol=1e-3)
+    ok = np.isfinite(b_exp[o2]).all(axis=1) & (np.abs(b_exp[o2]).max(axis=1) < 1e4)
+    assert ok.sum() > 0
+    np.testing.assert_allclose(b_got[o1][ok], b_exp[o2][ok], rtol=1e-3, atol=1e-3)
