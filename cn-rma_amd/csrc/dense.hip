@@ -88,6 +88,78 @@ __global__ __launch_bounds__(256) void backproject_accum_kernel(DenseParams p, c
   if (blockIdx.y == 0) count[g] = cnt;
 }
 
+// ---- cooperative-gather variant (C % 4 == 0) -------------------------------------------------------------------
+// A wave owns 64 consecutive voxels.  Per view every lane projects ITS voxel; then the wave walks the voxels in
+// groups of 64/LPV and LPV lanes read one pixel's channel vector together (LPV x 16 B = one full 128-B line at
+// C = 32), so a gather instruction touches 64/LPV lines instead of 64 and every fetched byte is used.  Lane l ends
+// up holding channels 4*(l % LPV) .. +3 of voxels (g * 64/LPV + l / LPV), g = 0 .. LPV-1.
+template <int LPV>
+__global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams p, const float* __restrict__ feat,
+                                                                     const float* __restrict__ proj,
+                                                                     float* __restrict__ volume,
+                                                                     int32_t* __restrict__ count) {
+  constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  if (wave_base >= G) return;
+  const int64_t g = wave_base + lane;
+  const int c0 = blockIdx.y * (4 * LPV);
+  float wx = 0.f, wy = 0.f, wz = 0.f;
+  const bool in_grid = g < G;
+  if (in_grid) voxel_world(p, g, &wx, &wy, &wz);
+  float4 acc[LPV];
+#pragma unroll
+  for (int i = 0; i < LPV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;
+  const int sub = lane % LPV, vsel = lane / LPV;
+  const int64_t plane = (int64_t)p.H * p.W * p.C;
+  for (int v = 0; v < p.V; ++v) {
+    float rx, ry;
+    const bool ok = in_grid && project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry);
+    const unsigned long long any = __ballot(ok);
+    if (any == 0ull) continue;
+    cnt += ok ? 1 : 0;
+    const int pix = ok ? ((int)ry * p.W + (int)rx) : -1;
+    const float* fv = feat + v * plane + c0 + 4 * sub;
+#pragma unroll
+    for (int grp = 0; grp < LPV; ++grp) {
+      if (((any >> (grp * VPG)) & ((VPG == 64) ? ~0ull : ((1ull << VPG) - 1ull))) == 0ull) continue;   // wave-uniform
+      const int pq = __shfl(pix, grp * VPG + vsel, 64);
+      if (pq >= 0) {
+        const float4 q = *reinterpret_cast<const float4*>(fv + (int64_t)pq * p.C);
+        acc[grp].x += q.x; acc[grp].y += q.y; acc[grp].z += q.z; acc[grp].w += q.w;
+      }
+    }
+  }
+  // the count of the voxel a lane accumulates for (group grp) lives in lane grp*VPG + vsel
+#pragma unroll
+  for (int grp = 0; grp < LPV; ++grp) {
+    const int cv = __shfl(cnt, grp * VPG + vsel, 64);
+    const int64_t gv = wave_base + grp * VPG + vsel;
+    if (gv < G) {
+      const float denom = (float)cv;
+      const float4 a = acc[grp];
+      const int c = c0 + 4 * sub;
+      volume[(int64_t)(c + 0) * G + gv] = cv > 0 ? a.x / denom : 0.0f;
+      volume[(int64_t)(c + 1) * G + gv] = cv > 0 ? a.y / denom : 0.0f;
+      volume[(int64_t)(c + 2) * G + gv] = cv > 0 ? a.z / denom : 0.0f;
+      volume[(int64_t)(c + 3) * G + gv] = cv > 0 ? a.w / denom : 0.0f;
+    }
+  }
+  if (blockIdx.y == 0 && in_grid) count[g] = cnt;
+}
+
+template <int LPV>
+int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
+                      hipStream_t st) {
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  dim3 grid((unsigned)ceil_div(G, 256), (unsigned)ceil_div(p.C, 4 * LPV));
+  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void backproject_index_kernel(DenseParams p, const float* __restrict__ proj,
                                                                 int32_t* __restrict__ px, int32_t* __restrict__ py,
                                                                 uint8_t* __restrict__ valid) {
@@ -121,10 +193,10 @@ extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* 
   if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
   DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
   hipStream_t st = as_stream(stream);
-  if (C % 32 == 0) return launch_accum<32>(p, feat_nhwc, proj, volume, count, st);
-  if (C % 16 == 0) return launch_accum<16>(p, feat_nhwc, proj, volume, count, st);
-  if (C % 8 == 0) return launch_accum<8>(p, feat_nhwc, proj, volume, count, st);
-  if (C % 4 == 0) return launch_accum<4>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 8 == 0) return launch_accum_coop<2>(p, feat_nhwc, proj, volume, count, st);
+  if (C % 4 == 0) return launch_accum_coop<1>(p, feat_nhwc, proj, volume, count, st);
   return launch_accum<1>(p, feat_nhwc, proj, volume, count, st);
 }
 
