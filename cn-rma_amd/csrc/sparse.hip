@@ -291,7 +291,10 @@ struct ConvArgs {
   float* slab;       // [splits][no_cap][Cout]
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+// FAST: Cin % 32 == 0 and Cout % 4 == 0 and Cout >= 4 -- every staging load is an unconditional 16-byte load with
+// a clamped address and a select afterwards (no per-element branches: hipcc would wait vmcnt(0) inside each one and
+// serialise the whole prefetch).
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool HAS_RES>
 __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   constexpr int LDA = BM + 1;   // k-major A tile, odd stride: conflict-light scattered 4-byte writes
@@ -320,17 +323,16 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   int k_lo = 0, k_hi = K;
   if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
   unsigned mask = 0;
-  if (p.nbr == nullptr) {
-    mask = 1u;                                    // identity map (K == 1)
-  } else {
+  {
     if (tid == 0) mask_s = 0;
     __syncthreads();
     unsigned local = 0;
     const int rows_here = (int)min((int64_t)BM, n_live - tile0);
-    const int32_t* nb = p.nbr + tile0 * K;
+    const int32_t* nb = p.nbr ? p.nbr + tile0 * K : nullptr;
     for (int i = tid; i < BM * K; i += 256) {
       const int k = i % K;
-      const int32_t v = i < rows_here * K ? nb[i] : -1;
+      int32_t v = -1;
+      if (i < rows_here * K) v = nb ? nb[i] : (int32_t)(tile0 + i);     // identity map (K == 1) when no table
       nbr_s[i] = v;
       if (k >= k_lo && k < k_hi && v >= 0) local |= 1u << k;
     }
@@ -354,13 +356,14 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 3, kc = idx & 7;
-      const int64_t grow = tile0 + row;
-      int32_t src;
-      if (p.nbr) src = nbr_s[row * K + k];
-      else src = grow < n_live ? (int32_t)grow : -1;
+      const int32_t src = nbr_s[row * K + k];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int cin = cin0 + kc * 4;
-      if (src >= 0) {
+      if constexpr (FAST) {
+        const float4 q = *reinterpret_cast<const float4*>(p.in + (int64_t)(src < 0 ? 0 : src) * Cin + cin);
+        const bool ok = src >= 0;
+        v.x = ok ? q.x : 0.f; v.y = ok ? q.y : 0.f; v.z = ok ? q.z : 0.f; v.w = ok ? q.w : 0.f;
+      } else if (src >= 0) {
         const float* q = p.in + (int64_t)src * Cin + cin;
         if (cin + 3 < Cin && (Cin & 3) == 0) {
           v = *reinterpret_cast<const float4*>(q);
@@ -379,7 +382,11 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
       const int r = idx / (BN / 4), c4 = idx % (BN / 4);
       const int cin = cin0 + r, col = cout0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cin < Cin) {
+      if constexpr (FAST) {
+        const bool ok = col < Cout;               // Cout % 4 == 0: a 4-column group is all in or all out
+        const float4 q = *reinterpret_cast<const float4*>(Wk + (int64_t)cin * Cout + (ok ? col : 0));
+        v.x = ok ? q.x : 0.f; v.y = ok ? q.y : 0.f; v.z = ok ? q.z : 0.f; v.w = ok ? q.w : 0.f;
+      } else if (cin < Cin) {
         const float* q = Wk + (int64_t)cin * Cout + col;
         if (col + 3 < Cout && (Cout & 3) == 0) {
           v = *reinterpret_cast<const float4*>(q);
@@ -449,28 +456,36 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   const bool partial = p.splits > 1;
   float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
   const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+  const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
+  const int act = partial ? 0 : p.act;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
-    if (col >= Cout) continue;
-    const float sc = (!partial && p.scale) ? p.scale[col] : 1.0f;
-    const float sh = (!partial && p.shift) ? p.shift[col] : 0.0f;
+    const bool col_ok = col < Cout;
+    const int colc = col_ok ? col : 0;
+    const float sc = use_scale ? p.scale[colc] : 1.0f;
+    const float sh = use_shift ? p.shift[colc] : 0.0f;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
+      const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
+      float res[16];
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+          const int64_t rc = row < n_live ? row : n_live - 1;        // clamped, branch-free
+          res[r] = partial ? 0.0f : p.residual[(out_base + rc) * Cout + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = tile0 + wr * (32 * TM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < n_live) {
-          float v = acc[a][b][r];
-          const int64_t o = (out_base + row) * Cout + col;
-          if (!partial) {
-            if (p.scale) v = v * sc;
-            if (p.shift) v = v + sh;
-            if (p.residual) v = v + p.residual[o];
-            v = apply_act(v, p.act);
-          }
-          dst[o] = v;
-        }
+        const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+        float v = acc[a][b][r];
+        v = v * sc;
+        v = v + sh;
+        if constexpr (HAS_RES) v = v + res[r];
+        v = apply_act(v, act);
+        if (col_ok && row < n_live) dst[(out_base + row) * Cout + col] = v;
       }
     }
   }
@@ -547,12 +562,26 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     if (p.splits < 2) { p.splits = 1; p.k_per_split = K; }
   }
   dim3 grid((unsigned)ceil_div(no_cap, bm), (unsigned)ceil_div(Cout, bn), (unsigned)(slices > 1 ? slices : p.splits));
+  const bool fast = (Cin % 32 == 0) && (Cout % 4 == 0);
+  const bool has_res = residual != nullptr && p.splits == 1;   // split layers add the residual in the reduce kernel
+#define CNRMA_CONV_LAUNCH(WM, WN, TM_, TN_)                                                                        \
+  do {                                                                                                             \
+    if (fast && has_res)                                                                                           \
+      hipLaunchKernelGGL((sparse_conv_mfma_kernel<WM, WN, TM_, TN_, true, true>), grid, dim3(256), 0, st, p);      \
+    else if (fast)                                                                                                 \
+      hipLaunchKernelGGL((sparse_conv_mfma_kernel<WM, WN, TM_, TN_, true, false>), grid, dim3(256), 0, st, p);     \
+    else if (has_res)                                                                                              \
+      hipLaunchKernelGGL((sparse_conv_mfma_kernel<WM, WN, TM_, TN_, false, true>), grid, dim3(256), 0, st, p);     \
+    else                                                                                                           \
+      hipLaunchKernelGGL((sparse_conv_mfma_kernel<WM, WN, TM_, TN_, false, false>), grid, dim3(256), 0, st, p);    \
+  } while (0)
   switch (shape) {
-    case T128x128: hipLaunchKernelGGL((sparse_conv_mfma_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, p); break;
-    case T128x64: hipLaunchKernelGGL((sparse_conv_mfma_kernel<4, 1, 1, 2>), grid, dim3(256), 0, st, p); break;
-    case T64x64: hipLaunchKernelGGL((sparse_conv_mfma_kernel<2, 2, 1, 1>), grid, dim3(256), 0, st, p); break;
-    case T128x32: hipLaunchKernelGGL((sparse_conv_mfma_kernel<4, 1, 1, 1>), grid, dim3(256), 0, st, p); break;
+    case T128x128: CNRMA_CONV_LAUNCH(2, 2, 2, 2); break;
+    case T128x64: CNRMA_CONV_LAUNCH(4, 1, 1, 2); break;
+    case T64x64: CNRMA_CONV_LAUNCH(2, 2, 1, 1); break;
+    case T128x32: CNRMA_CONV_LAUNCH(4, 1, 1, 1); break;
   }
+#undef CNRMA_CONV_LAUNCH
   if (p.splits > 1) {
     int64_t blocks = ceil_div(no_cap * Cout / 4 + 1, 256);
     if (blocks > 4096) blocks = 4096;

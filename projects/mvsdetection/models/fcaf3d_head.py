@@ -130,9 +130,12 @@ class FCAF3DHead(nn.Module):
         """the three 1x1 head convolutions as ONE [128, 1+R+n_cls] GEMM (+ bias row for the class logits)"""
         if self._fused_head is None or self._fused_head[0].device != self.cls_conv.kernel.device:
             with torch.no_grad():
-                w = torch.cat((self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel), dim=1).contiguous()
+                w = torch.cat((self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel), dim=1)
+                n_out = w.shape[1]
+                pad = (-n_out) % 4                       # 16-byte rows: the conv kernel's branch-free staging path
+                w = torch.cat((w, w.new_zeros(w.shape[0], pad)), dim=1).contiguous()
                 b = torch.zeros(w.shape[1], device=w.device)
-                b[1 + self.n_reg_outs:] = self.cls_conv.bias.view(-1)
+                b[1 + self.n_reg_outs:n_out] = self.cls_conv.bias.view(-1)
             self._fused_head = (w, b.contiguous())
         return self._fused_head
 
@@ -144,7 +147,8 @@ class FCAF3DHead(nn.Module):
         else:
             w, b = self._head_weights()
             y = S.conv(x, w, kernel_size=1, shift=b).F
-            centerness, reg_final, cls_score = y[:, :1], y[:, 1:1 + self.n_reg_outs], y[:, 1 + self.n_reg_outs:]
+            n_out = 1 + self.n_reg_outs + self.n_classes
+            centerness, reg_final, cls_score = y[:, :1], y[:, 1:1 + self.n_reg_outs], y[:, 1 + self.n_reg_outs:n_out]
         prune_scores = S.SparseTensor(S.row_max(cls_score.contiguous()), x.cs)           # :279-282
         reg_distance = torch.exp(scale(reg_final[:, :6]))                                  # :284
         bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)                     # :285-286
