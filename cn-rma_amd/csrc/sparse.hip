@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
   float4 ra[A_ITERS], rb[B_ITERS];
+  unsigned a_ok = 0, b_ok = 0;   // FAST path: validity bits of the prefetched registers; the zero-select happens in
+                                 // store_stage so that nothing consumes a loaded value before the MFMAs have run
   auto load_stage = [&](int k, int cin0) {
+    a_ok = 0; b_ok = 0;
     const float* Wk = Wz + (int64_t)k * Cin * Cout;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -360,9 +363,8 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int cin = cin0 + kc * 4;
       if constexpr (FAST) {
-        const float4 q = *reinterpret_cast<const float4*>(p.in + (int64_t)(src < 0 ? 0 : src) * Cin + cin);
-        const bool ok = src >= 0;
-        v.x = ok ? q.x : 0.f; v.y = ok ? q.y : 0.f; v.z = ok ? q.z : 0.f; v.w = ok ? q.w : 0.f;
+        v = *reinterpret_cast<const float4*>(p.in + (int64_t)(src < 0 ? 0 : src) * Cin + cin);
+        a_ok |= (src >= 0 ? 1u : 0u) << i;
       } else if (src >= 0) {
         const float* q = p.in + (int64_t)src * Cin + cin;
         if (cin + 3 < Cin && (Cin & 3) == 0) {
@@ -384,8 +386,8 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (FAST) {
         const bool ok = col < Cout;               // Cout % 4 == 0: a 4-column group is all in or all out
-        const float4 q = *reinterpret_cast<const float4*>(Wk + (int64_t)cin * Cout + (ok ? col : 0));
-        v.x = ok ? q.x : 0.f; v.y = ok ? q.y : 0.f; v.z = ok ? q.z : 0.f; v.w = ok ? q.w : 0.f;
+        v = *reinterpret_cast<const float4*>(Wk + (int64_t)cin * Cout + (ok ? col : 0));
+        b_ok |= (ok ? 1u : 0u) << i;
       } else if (cin < Cin) {
         const float* q = Wk + (int64_t)cin * Cout + col;
         if (col + 3 < Cout && (Cout & 3) == 0) {
@@ -405,16 +407,26 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 3, kc = idx & 7;
-      As[(kc * 4 + 0) * LDA + row] = ra[i].x;
-      As[(kc * 4 + 1) * LDA + row] = ra[i].y;
-      As[(kc * 4 + 2) * LDA + row] = ra[i].z;
-      As[(kc * 4 + 3) * LDA + row] = ra[i].w;
+      float4 v = ra[i];
+      if constexpr (FAST) {
+        const bool ok = (a_ok >> i) & 1u;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      }
+      As[(kc * 4 + 0) * LDA + row] = v.x;
+      As[(kc * 4 + 1) * LDA + row] = v.y;
+      As[(kc * 4 + 2) * LDA + row] = v.z;
+      As[(kc * 4 + 3) * LDA + row] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       const int idx = tid + i * 256;
       const int r = idx / (BN / 4), c4 = idx % (BN / 4);
-      *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = rb[i];
+      float4 v = rb[i];
+      if constexpr (FAST) {
+        const bool ok = (b_ok >> i) & 1u;
+        v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(&Bs[r * LDB + c4 * 4]) = v;
     }
   };
 
