@@ -302,11 +302,8 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   constexpr int A_ITERS = BM * (BK / 4) / 256;
   constexpr int B_ITERS = BK * (BN / 4) / 256;
   static_assert(WAVES_M * WAVES_N == 4 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
-  constexpr int KMAX = 27;
   __shared__ float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  __shared__ int32_t nbr_s[BM * KMAX];   // the tile's slice of the neighbour table, [row][K]: gathers never chase a
-                                         // dependent global load
   __shared__ unsigned mask_s;
 
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
@@ -323,23 +320,34 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   int k_lo = 0, k_hi = K;
   if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
   unsigned mask = 0;
-  {
+  const int rows_here = (int)min((int64_t)BM, n_live - tile0);
+  if (p.nbr == nullptr) {
+    mask = 1u;                                   // identity map (K == 1)
+  } else {
     if (tid == 0) mask_s = 0;
     __syncthreads();
     unsigned local = 0;
-    const int rows_here = (int)min((int64_t)BM, n_live - tile0);
-    const int32_t* nb = p.nbr ? p.nbr + tile0 * K : nullptr;
-    for (int i = tid; i < BM * K; i += 256) {
+    const int32_t* nb = p.nbr + tile0 * K;
+    for (int i = tid; i < rows_here * K; i += 256) {
       const int k = i % K;
-      int32_t v = -1;
-      if (i < rows_here * K) v = nb ? nb[i] : (int32_t)(tile0 + i);     // identity map (K == 1) when no table
-      nbr_s[i] = v;
-      if (k >= k_lo && k < k_hi && v >= 0) local |= 1u << k;
+      if (k >= k_lo && k < k_hi && nb[i] >= 0) local |= 1u << k;
     }
     if (local) atomicOr(&mask_s, local);
     __syncthreads();
     mask = mask_s;
   }
+  // neighbour rows of this thread's A_ITERS staging rows: for the current offset (src_cur) and, prefetched one
+  // offset ahead, for the next active one (src_nxt) -- the gathers never wait on a dependent index load
+  int32_t src_cur[A_ITERS], src_nxt[A_ITERS];
+  auto load_src = [&](int k, int32_t* dst) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int row = (tid + i * 256) >> 3;
+      int32_t v = -1;
+      if (row < rows_here && k >= 0) v = p.nbr ? p.nbr[(tile0 + row) * K + k] : (int32_t)(tile0 + row);
+      dst[i] = v;
+    }
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -352,14 +360,14 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   float4 ra[A_ITERS], rb[B_ITERS];
   unsigned a_ok = 0, b_ok = 0;   // FAST path: validity bits of the prefetched registers; the zero-select happens in
                                  // store_stage so that nothing consumes a loaded value before the MFMAs have run
-  auto load_stage = [&](int k, int cin0) {
+  auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
     a_ok = 0; b_ok = 0;
     const float* Wk = Wz + (int64_t)k * Cin * Cout;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 3, kc = idx & 7;
-      const int32_t src = nbr_s[row * K + k];
+      const int32_t src = srcs[i];
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int cin = cin0 + kc * 4;
       if constexpr (FAST) {
@@ -431,9 +439,12 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   };
 
   // ---- pipelined stage loop over (active k, cin slice)
+  auto next_active = [&](int k) { const unsigned rest = mask & ~((2u << k) - 1u); return rest ? __ffs(rest) - 1 : -1; };
   int k = mask ? __ffs(mask) - 1 : -1;
   int cin0 = 0;
-  if (k >= 0) load_stage(k, 0);
+  load_src(k, src_cur);
+  load_src(k >= 0 ? next_active(k) : -1, src_nxt);
+  if (k >= 0) load_stage(k, 0, src_cur);
   while (k >= 0) {
     store_stage();
     __syncthreads();
@@ -441,10 +452,12 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
     int nk = k, ncin = cin0 + BK;
     if (ncin >= Cin) {
       ncin = 0;
-      const unsigned rest = mask & ~((2u << k) - 1u);
-      nk = rest ? __ffs(rest) - 1 : -1;
+      nk = next_active(k);
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
+      if (nk >= 0) load_src(next_active(nk), src_nxt);      // index prefetch one offset ahead
     }
-    if (nk >= 0) load_stage(nk, ncin);           // global loads in flight during the MFMAs below
+    if (nk >= 0) load_stage(nk, ncin, src_cur);   // global loads in flight during the MFMAs below
     const float* a_p = As + (lane >> 5) * LDA + wr * (32 * TM) + (lane & 31);
     const float* b_p = Bs + (lane >> 5) * LDB + wc * (32 * TN) + (lane & 31);
 #pragma unroll
@@ -480,24 +493,279 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
-      float res[16];
-      if constexpr (HAS_RES) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-          const int64_t rc = row < n_live ? row : n_live - 1;        // clamped, branch-free
-          res[r] = partial ? 0.0f : p.residual[(out_base + rc) * Cout + colc];
+      for (int rg = 0; rg < 4; ++rg) {                                 // 4 rows at a time: short live ranges
+        float res[4];
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q + 8 * rg;
+            const int64_t rc = row < n_live ? row : n_live - 1;        // clamped, branch-free
+            res[q] = p.residual[(out_base + rc) * Cout + colc];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = row0 + q + 8 * rg;
+          float v = acc[a][b][rg * 4 + q];
+          v = v * sc;
+          v = v + sh;
+          if constexpr (HAS_RES) v = v + res[q];
+          v = apply_act(v, act);
+          if (col_ok && row < n_live) dst[(out_base + row) * Cout + col] = v;
         }
       }
+    }
+  }
+}
+
+// ================================================================================================================
+// fp32-grade convolution on the bf16 matrix cores ("bf16x6"): every fp32 operand is split exactly into three bf16
+// pieces a = h + m + l (|a - h - m - l| <= 2^-27 |a|), and the product is rebuilt from the six partial products whose
+// magnitude is >= 2^-16 |ab| (hh, hm, mh, hl, lh, mm; the dropped ml/lm/ll terms are <= 2^-23 |ab|), accumulated in
+// fp32.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each):
+// 2.67x fewer matrix-pipe cycles at the accuracy of an fp32 fma chain.  Weights are pre-split / pre-transposed once
+// (cnrma_sparse_conv_prepare_weights); features are split while they are staged into LDS.
+// LDS images: [plane][row][k] bf16 with a row stride of 40 elements (80 B): the ds_read_b128 fragment reads of
+// 16 consecutive rows then fall on 16 distinct 16-byte bank slots.
+// ================================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+constexpr int LDK = 40;
+
+__device__ __forceinline__ void split3(const float4& v, bf16x4_t& h, bf16x4_t& m, bf16x4_t& l) {
+  const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-        float v = acc[a][b][r];
-        v = v * sc;
-        v = v + sh;
-        if constexpr (HAS_RES) v = v + res[r];
-        v = apply_act(v, act);
-        if (col_ok && row < n_live) dst[(out_base + row) * Cout + col] = v;
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 hh = (__bf16)a[j];
+    const float r1 = a[j] - (float)hh;       // exact
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;         // exact
+    h[j] = hh; m[j] = mm; l[j] = (__bf16)r2;
+  }
+}
+
+// W fp32 [K][Cin][Cout] -> Wt bf16 [3 planes][K][Cout][Cin]
+__global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
+                                                           int Cin, int Cout) {
+  const int64_t total = (int64_t)K * Cin * Cout;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int cin = (int)(t % Cin);
+    const int64_t q = t / Cin;
+    const int co = (int)(q % Cout);
+    const int k = (int)(q / Cout);
+    const float a = w[((int64_t)k * Cin + cin) * Cout + co];
+    const __bf16 hh = (__bf16)a;
+    const float r1 = a - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    wt[t] = hh;
+    wt[total + t] = mm;
+    wt[2 * total + t] = (__bf16)r2;
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES>
+__global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  constexpr int A_ITERS = BM * (BK / 4) / 256;          // float4 gathers per thread
+  constexpr int B_CHUNKS = 3 * BN * (BK / 8);           // 16-byte (8 x bf16) chunks over the 3 planes
+  constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
+  static_assert(WAVES_M * WAVES_N == 4 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDK];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * LDK];
+  __shared__ unsigned mask_s;
+
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int64_t tile0 = (int64_t)blockIdx.x * BM;
+  if (tile0 >= n_live) return;
+  const int cout0 = blockIdx.y * BN;
+  const int zs = blockIdx.z;
+  const int Cin = p.Cin, Cout = p.Cout, K = p.K;
+  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * K * Cin * Cout;
+  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid / WAVES_N, wc = wid % WAVES_N;
+
+  int k_lo = 0, k_hi = K;
+  if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
+  unsigned mask = 0;
+  const int rows_here = (int)min((int64_t)BM, n_live - tile0);
+  if (p.nbr == nullptr) {
+    mask = 1u;                                   // identity map (K == 1)
+  } else {
+    if (tid == 0) mask_s = 0;
+    __syncthreads();
+    unsigned local = 0;
+    const int32_t* nb = p.nbr + tile0 * K;
+    for (int i = tid; i < rows_here * K; i += 256) {
+      const int k = i % K;
+      if (k >= k_lo && k < k_hi && nb[i] >= 0) local |= 1u << k;
+    }
+    if (local) atomicOr(&mask_s, local);
+    __syncthreads();
+    mask = mask_s;
+  }
+  // neighbour rows of this thread's A_ITERS staging rows: for the current offset (src_cur) and, prefetched one
+  // offset ahead, for the next active one (src_nxt) -- the gathers never wait on a dependent index load
+  int32_t src_cur[A_ITERS], src_nxt[A_ITERS];
+  auto load_src = [&](int k, int32_t* dst) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int row = (tid + i * 256) >> 3;
+      int32_t v = -1;
+      if (row < rows_here && k >= 0) v = p.nbr ? p.nbr[(tile0 + row) * K + k] : (int32_t)(tile0 + row);
+      dst[i] = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  float4 ra[A_ITERS];
+  uint4 rb[B_ITERS];
+  unsigned a_ok = 0, b_ok = 0;
+  auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
+    a_ok = 0; b_ok = 0;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      const int kc = idx & 7;
+      const int32_t src = srcs[i];
+      ra[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)(src < 0 ? 0 : src) * Cin + cin0 + kc * 4);
+      a_ok |= (src >= 0 ? 1u : 0u) << i;
+    }
+    const __bf16* Wk = Wz + (int64_t)k * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      int idx = tid + i * 256;                         // over [plane][row][chunk]
+      const bool in_tile = idx < B_CHUNKS;
+      idx = in_tile ? idx : 0;
+      const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
+      const int co = cout0 + row;
+      const bool ok = in_tile && co < Cout;
+      rb[i] = *reinterpret_cast<const uint4*>(Wk + pl * plane_elems + (int64_t)(ok ? co : 0) * Cin + cin0 + chunk * 8);
+      b_ok |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, kc = idx & 7;
+      float4 v = ra[i];
+      const bool ok = (a_ok >> i) & 1u;
+      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+      bf16x4_t h, m, l;
+      split3(v, h, m, l);
+      *reinterpret_cast<bf16x4_t*>(&As[0][row * LDK + kc * 4]) = h;
+      *reinterpret_cast<bf16x4_t*>(&As[1][row * LDK + kc * 4]) = m;
+      *reinterpret_cast<bf16x4_t*>(&As[2][row * LDK + kc * 4]) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < B_CHUNKS) {
+        const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
+        uint4 v = rb[i];
+        const bool ok = (b_ok >> i) & 1u;
+        v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+        *reinterpret_cast<uint4*>(&Bs[pl][row * LDK + chunk * 8]) = v;
+      }
+    }
+  };
+
+  auto next_active = [&](int k) { const unsigned rest = mask & ~((2u << k) - 1u); return rest ? __ffs(rest) - 1 : -1; };
+  int k = mask ? __ffs(mask) - 1 : -1;
+  int cin0 = 0;
+  load_src(k, src_cur);
+  load_src(k >= 0 ? next_active(k) : -1, src_nxt);
+  if (k >= 0) load_stage(k, 0, src_cur);
+  while (k >= 0) {
+    store_stage();
+    __syncthreads();
+    int nk = k, ncin = cin0 + BK;
+    if (ncin >= Cin) {
+      ncin = 0;
+      nk = next_active(k);
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
+      if (nk >= 0) load_src(next_active(nk), src_nxt);
+    }
+    if (nk >= 0) load_stage(nk, ncin, src_cur);
+    const int a_off = (wr * (32 * TM) + (lane & 31)) * LDK + (lane >> 5) * 8;
+    const int b_off = (wc * (32 * TN) + (lane & 31)) * LDK + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[a][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][a_off + a * 32 * LDK + ks]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[b][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][b_off + b * 32 * LDK + ks]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);   // l*h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);   // h*l
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);   // m*m
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);   // m*h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);   // h*m
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);   // h*h
+          acc[a][b] = c;
+        }
+    }
+    __syncthreads();
+    k = nk;
+    cin0 = ncin;
+  }
+
+  const bool partial = p.splits > 1;
+  float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
+  const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+  const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
+  const int act = partial ? 0 : p.act;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
+    const bool col_ok = col < Cout;
+    const int colc = col_ok ? col : 0;
+    const float sc = use_scale ? p.scale[colc] : 1.0f;
+    const float sh = use_shift ? p.shift[colc] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {                                 // 4 rows at a time: short live ranges
+        float res[4];
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q + 8 * rg;
+            const int64_t rc = row < n_live ? row : n_live - 1;        // clamped, branch-free
+            res[q] = p.residual[(out_base + rc) * Cout + colc];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = row0 + q + 8 * rg;
+          float v = acc[a][b][rg * 4 + q];
+          v = v * sc;
+          v = v + sh;
+          if constexpr (HAS_RES) v = v + res[q];
+          v = apply_act(v, act);
+          if (col_ok && row < n_live) dst[(out_base + row) * Cout + col] = v;
+        }
       }
     }
   }
@@ -556,7 +824,7 @@ int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes
 
 int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float* weight, int Cout, const float* scale,
                 const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
-                int slices, void* workspace, size_t ws_bytes, hipStream_t st) {
+                int slices, void* workspace, size_t ws_bytes, hipStream_t st, const void* weight_split = nullptr) {
   if (Cin <= 0 || Cout <= 0 || K <= 0 || K > 27 || no_cap <= 0) return CNRMA_EINVAL;
   ConvArgs p{in, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out, no_cap, no_dev, slices, 1, K,
              reinterpret_cast<float*>(workspace)};
@@ -576,6 +844,28 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   dim3 grid((unsigned)ceil_div(no_cap, bm), (unsigned)ceil_div(Cout, bn), (unsigned)(slices > 1 ? slices : p.splits));
   const bool fast = (Cin % 32 == 0) && (Cout % 4 == 0);
   const bool has_res = residual != nullptr && p.splits == 1;   // split layers add the residual in the reduce kernel
+  if (weight_split != nullptr && Cin % 32 == 0) {
+    const __bf16* wt = reinterpret_cast<const __bf16*>(weight_split);
+#define CNRMA_CONV6_LAUNCH(WM, WN, TM_, TN_)                                                                       \
+  do {                                                                                                             \
+    if (has_res) hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true>), grid, dim3(256), 0, st, p, wt);   \
+    else hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false>), grid, dim3(256), 0, st, p, wt);  \
+  } while (0)
+    switch (shape) {
+      case T128x128: CNRMA_CONV6_LAUNCH(2, 2, 2, 2); break;
+      case T128x64: CNRMA_CONV6_LAUNCH(4, 1, 1, 2); break;
+      case T64x64: CNRMA_CONV6_LAUNCH(2, 2, 1, 1); break;
+      case T128x32: CNRMA_CONV6_LAUNCH(4, 1, 1, 1); break;
+    }
+#undef CNRMA_CONV6_LAUNCH
+    if (p.splits > 1) {
+      int64_t blocks = ceil_div(no_cap * Cout / 4 + 1, 256);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    }
+    CNRMA_LAUNCH_CHECK();
+    return 0;
+  }
 #define CNRMA_CONV_LAUNCH(WM, WN, TM_, TN_)                                                                        \
   do {                                                                                                             \
     if (fast && has_res)                                                                                           \
@@ -887,6 +1177,27 @@ extern "C" int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32
                                      size_t workspace_bytes, void* stream) {
   return launch_conv(in_feats, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
                      workspace, workspace_bytes, as_stream(stream));
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights(const float* weight, int K, int Cin, int Cout, void* weight_split,
+                                                 void* stream) {
+  if (K <= 0 || Cin <= 0 || Cout <= 0) return CNRMA_EINVAL;
+  int64_t total = (int64_t)K * Cin * Cout;
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
+                     reinterpret_cast<__bf16*>(weight_split), K, Cin, Cout);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_bf16x6(const float* in_feats, int Cin, const int32_t* nbr, int K,
+                                        const void* weight_split, int Cout, const float* scale, const float* shift,
+                                        const float* residual, int act, float* out_feats, int64_t no_cap,
+                                        const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  if (weight_split == nullptr || Cin % 32 != 0) return CNRMA_EINVAL;
+  return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
+                     workspace, workspace_bytes, as_stream(stream), weight_split);
 }
 
 extern "C" int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap,

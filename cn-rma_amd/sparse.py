@@ -205,7 +205,32 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=None, act=None):
+# "bf16x6": fp32-grade result on the bf16 matrix cores (3-way exact operand split, 6 partial products);
+# "f32":    v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).  Layers with Cin % 32 != 0 always use "f32".
+CONV_PRECISION = "bf16x6"
+
+
+def split_weights(weight):
+    """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [3,K,Cout,Cin] (hi / mid / lo pieces).  The result is cached ON
+    the weight tensor object (so it dies with it) and rebuilt when the tensor is modified in place or moved."""
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    hit = getattr(weight, "_cnrma_split", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    w = weight.detach().contiguous().float()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, Cin, Cout = w.shape
+    ws = torch.empty((3, K, Cout, Cin), dtype=torch.bfloat16, device=w.device)
+    call("cnrma_sparse_conv_prepare_weights", ptr(w), K, Cin, Cout, ptr(ws), stream())
+    try:
+        weight._cnrma_split = (tag, ws)
+    except AttributeError:
+        pass
+    return ws
+
+
+def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=None, act=None, precision=None):
     """MinkowskiConvolution + fused epilogue: out = act((sum_k in[nbr] @ W[k]) * scale + shift + residual).
     weight [K,Cin,Cout] (or [Cin,Cout] when K == 1)."""
     _lib.require_gpu()
@@ -227,8 +252,12 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             assert res.shape == out.shape
         ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(out_cs.n, Cout, K)
         ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-        call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
-             ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
+        if (precision or CONV_PRECISION) == "bf16x6" and Cin % 32 == 0:
+            call("cnrma_sparse_conv_bf16x6", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(split_weights(weight)), Cout,
+                 ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
+        else:
+            call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
+                 ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
     return SparseTensor(out, out_cs)
 
 

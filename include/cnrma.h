@@ -186,6 +186,17 @@ int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, in
                           float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* fp32-grade convolution on the bf16 matrix cores ("bf16x6": each fp32 operand split exactly into 3 bf16 pieces, the 6
+ * significant partial products accumulated in fp32; relative error ~2^-23 per product, i.e. that of an fp32 fma chain;
+ * 2.67x fewer matrix-pipe cycles than the fp32 MFMA path).  Needs Cin % 32 == 0.
+ * cnrma_sparse_conv_prepare_weights: weight fp32 [K][Cin][Cout] -> weight_split bf16 [3][K][Cout][Cin]
+ * (6*K*Cin*Cout bytes), done once per layer.  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
+int cnrma_sparse_conv_prepare_weights(const float* weight, int K, int Cin, int Cout, void* weight_split, void* stream);
+int cnrma_sparse_conv_bf16x6(const float* in_feats, int Cin, const int32_t* nbr, int K, const void* weight_split,
+                             int Cout, const float* scale, const float* shift, const float* residual, int act,
+                             float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */
 int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap, const int32_t* n_dev,

@@ -17,7 +17,7 @@ prof.uninstall(); torch.cuda.synchronize()
 tot = 0
 for name, a, e0, e1 in prof.records:
     ms = e0.elapsed_time(e1)
-    if name == "cnrma_sparse_conv_f32":
+    if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
         rows, cin, cout, K = a[11], a[1], a[5], a[3]
         fl = 2.0 * K * cin * cout * rows
         tot += ms

@@ -86,15 +86,40 @@ def test_voxelize_duplicates_negative_and_first_wins(device):
 @pytest.mark.parametrize("cin,cout,k,stride,ts", [(32, 64, 3, 1, 1), (64, 64, 3, 1, 2), (32, 64, 3, 2, 1), (64, 128, 3, 2, 4),
                                                    (64, 128, 1, 2, 2), (128, 25, 1, 1, 1), (5, 7, 3, 1, 1), (48, 96, 3, 1, 1),
                                                    (256, 256, 3, 1, 2), (8, 3, 1, 1, 1)])
-def test_conv_vs_oracle(device, cin, cout, k, stride, ts):
+@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+def test_conv_vs_oracle(device, cin, cout, k, stride, ts, precision):
     from cnrma_amd import sparse as S
     rng = np.random.RandomState(cin + cout + k)
     c, f = rand_sparse(rng, n=4000, span=12, C=cin, ts=ts, batch=2)
     W = (rng.randn(k ** 3, cin, cout) / np.sqrt(cin * k ** 3)).astype(np.float32)
-    out = S.conv(to_st(c, f, ts, device), torch.from_numpy(W).to(device), k, stride)
+    out = S.conv(to_st(c, f, ts, device), torch.from_numpy(W).to(device), k, stride, precision=precision)
     oc, of = SO.conv(c, f, W, k, stride, ts)
-    check(out, oc, of)
+    check(out, oc, of, tol=2e-6 if precision == "bf16x6" or True else TOL)   # both paths are fp32-grade
     assert out.cs.stride == ts * stride
+
+
+def test_bf16x6_is_fp32_grade_on_wide_dynamic_range(device):
+    """the 3-way bf16 split must hold fp32 accuracy for operands spanning many binades (bf16 keeps fp32's exponent)"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(9)
+    c, f = rand_sparse(rng, n=6000, span=9, C=64)
+    f = (f * np.exp(rng.uniform(-12, 12, size=f.shape))).astype(np.float32)
+    W = (rng.randn(27, 64, 64) * np.exp(rng.uniform(-8, 8, size=(27, 64, 64)))).astype(np.float32)
+    x = to_st(c, f, 1, device)
+    y6 = S.conv(x, torch.from_numpy(W).to(device), 3, 1, precision="bf16x6").F.cpu().numpy().astype(np.float64)
+    y32 = S.conv(x, torch.from_numpy(W).to(device), 3, 1, precision="f32").F.cpu().numpy().astype(np.float64)
+    _, ref = SO.conv(c, f, W, 3, 1, 1)
+    # error relative to sum |a||b| (the natural scale of a dot product's rounding error)
+    look = SO.Lookup(c)
+    mag = np.zeros_like(ref)
+    for k, off in enumerate(SO.kernel_offsets(3, 1)):
+        q = c.copy(); q[:, 1:] += off
+        idx = look(q); m = idx >= 0
+        mag[m] += np.abs(f[idx[m]].astype(np.float64)) @ np.abs(W[k].astype(np.float64))
+    e6 = np.abs(y6 - ref).max() / mag.max()
+    e32 = np.abs(y32 - ref).max() / mag.max()
+    assert e6 < 4e-7 and e32 < 4e-7, (e6, e32)
+    assert (np.abs(y6 - ref) / (mag + 1e-30)).max() < 2e-6
 
 
 def test_conv_fused_epilogue(device):
