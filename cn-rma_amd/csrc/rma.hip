@@ -159,20 +159,6 @@ __device__ __forceinline__ bool ray_setup(const MarchParams& p, const float* __r
   return true;
 }
 
-__global__ __launch_bounds__(256) void neus_count_kernel(MarchParams p, const float* __restrict__ proj_inv,
-                                                         const float* __restrict__ tsdf, int32_t* __restrict__ count,
-                                                         double* __restrict__ wsum) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  Ray ray; int view, pix;
-  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
-  const float s_out = sigmoid_neg(1.0f);
-  int c = 0;
-  double ws = 0.0;
-  neus_march(ray, p, tsdf, s_out, [&](int, const Sample&, float w) { ++c; ws += (double)w; });
-  count[r] = c;
-  wsum[r] = ws;
-}
-
 struct EmitDst {
   float* xyz; int xyz_stride;
   float* w; int w_stride;
@@ -182,6 +168,94 @@ struct EmitDst {
   const float* w_div;    // device scalar, may be NULL
   float ax, ay, az;
 };
+
+// kept: optional per-ray record of the kept samples, [ray][cap] x {weight bits, step}; lets the emission run one
+// thread group per OUTPUT row instead of re-marching every ray.  A ray can keep at most ~1/thr samples (the weights
+// of a ray sum to 1 - prod(1-alpha) <= 1), so cap = floor(1/thr) + 2 never overflows; overflow[0] counts violations.
+__global__ __launch_bounds__(256) void neus_count_kernel(MarchParams p, const float* __restrict__ proj_inv,
+                                                         const float* __restrict__ tsdf, int32_t* __restrict__ count,
+                                                         double* __restrict__ wsum, int2* __restrict__ kept, int cap,
+                                                         int32_t* __restrict__ overflow) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Ray ray; int view, pix;
+  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
+  const float s_out = sigmoid_neg(1.0f);
+  int c = 0;
+  double ws = 0.0;
+  int2* mine = kept ? kept + r * cap : nullptr;
+  neus_march(ray, p, tsdf, s_out, [&](int n, const Sample&, float w) {
+    if (mine) {
+      if (c < cap) mine[c] = make_int2(__float_as_int(w), n);
+      else atomicAdd(overflow, 1);
+    }
+    ++c;
+    ws += (double)w;
+  });
+  count[r] = c;
+  wsum[r] = ws;
+}
+
+// Emission from the kept-sample records: LPR lanes per SOURCE row m (rows that the keep-mask drops exit at once).
+// The row's ray is found by binary search in row_offset; place = o + d*t is recomputed with the march's arithmetic.
+template <int LPR>
+__global__ __launch_bounds__(256) void neus_emit_rows_kernel(MarchParams p, int C, const float* __restrict__ proj_inv,
+                                                            const float* __restrict__ feat,
+                                                            const int32_t* __restrict__ row_offset,
+                                                            const int2* __restrict__ kept, int cap, EmitDst dst) {
+  const int64_t R = (int64_t)p.V * p.H * p.W;
+  const int64_t M = row_offset[R];
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = t / LPR;
+  const int sub = (int)(t % LPR);
+  if (m >= M) return;
+  int64_t j = m;
+  if (dst.sel) {
+    j = dst.sel[m];
+    if (j < 0) return;
+  }
+  // largest r with row_offset[r] <= m
+  int64_t lo = 0, hi = R;                       // invariant: row_offset[lo] <= m < row_offset[hi]
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (row_offset[mid] <= m) lo = mid; else hi = mid;
+  }
+  const int64_t r = lo;
+  const int2 rec = kept[r * cap + (m - row_offset[r])];
+  const float w = __int_as_float(rec.x);
+  const int n = rec.y;
+  const int view = (int)(r / ((int64_t)p.H * p.W));
+  const int pix = (int)(r - (int64_t)view * p.H * p.W);
+  if (sub == 0) {
+    const int v = pix / p.W, u = pix - v * p.W;
+    const Ray ray = make_ray(proj_inv + (int64_t)view * 16, (float)u, (float)v);
+    const float tt = (float)n * p.t_one;
+    if (dst.xyz) {
+      float* q = dst.xyz + j * dst.xyz_stride;
+      q[0] = (ray.ox + ray.dx * tt) + dst.ax;
+      q[1] = (ray.oy + ray.dy * tt) + dst.ay;
+      q[2] = (ray.oz + ray.dz * tt) + dst.az;
+    }
+    if (dst.w) dst.w[j * dst.w_stride] = w;
+    if (dst.sample) { dst.sample[2 * j] = (int32_t)r; dst.sample[2 * j + 1] = n; }
+  }
+  if (dst.feat) {
+    const float* f = feat + ((int64_t)view * p.H * p.W + pix) * C;
+    float* q = dst.feat + j * dst.feat_stride;
+    const bool scaled = dst.w_div != nullptr;
+    const float scale = scaled ? w / dst.w_div[0] : 1.0f;
+    const bool vec = ((C | dst.feat_stride) & 3) == 0 && ((((uintptr_t)dst.feat) | ((uintptr_t)feat)) & 15) == 0;
+    if (vec) {
+      for (int c = 4 * sub; c < C; c += 4 * LPR) {
+        float4 x = *reinterpret_cast<const float4*>(f + c);
+        if (scaled) { x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale; }
+        *reinterpret_cast<float4*>(q + c) = x;
+      }
+    } else {
+      for (int c = sub; c < C; c += LPR) q[c] = scaled ? f[c] * scale : f[c];
+    }
+  }
+}
+
 
 __device__ __forceinline__ void emit_row(const EmitDst& d, int64_t m, float x, float y, float z, float w,
                                          const float* __restrict__ f, int C, int64_t ray, int step) {
@@ -354,7 +428,42 @@ extern "C" int cnrma_rma_neus_count_f32(const float* proj_inv, const float* tsdf
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
   int64_t R = (int64_t)V * H * W;
   hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
-                     proj_inv, tsdf, count, wsum);
+                     proj_inv, tsdf, count, wsum, (int2*)nullptr, 0, (int32_t*)nullptr);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y,
+                                        int Z, float voxel_size, float ox, float oy, float oz, int n_steps,
+                                        float t_one, float thr, int32_t* count, double* wsum, void* kept, int cap,
+                                        int32_t* overflow, void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
+  int64_t R = (int64_t)V * H * W;
+  hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int32_t), as_stream(stream));
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
+                     proj_inv, tsdf, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
+                                            int n_steps, float t_one, const int32_t* row_offset, int64_t m_cap,
+                                            const void* kept, int cap, const int32_t* sel_index, const float* w_div,
+                                            float addx, float addy, float addz, float* out_xyz, int xyz_stride,
+                                            float* out_w, int w_stride, float* out_feat, int feat_stride,
+                                            int32_t* out_sample, void* stream) {
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || m_cap <= 0 || kept == nullptr || cap <= 0) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, 1, 1, 1, 1.0f, 0.f, 0.f, 0.f, n_steps, t_one, 0.0f);
+  EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, out_sample, sel_index, w_div, addx, addy, addz};
+  if (C % 32 == 0) {
+    hipLaunchKernelGGL((neus_emit_rows_kernel<8>), dim3((unsigned)ceil_div(m_cap * 8, 256)), dim3(256), 0,
+                       as_stream(stream), p, C, proj_inv, feat_nhwc, row_offset, reinterpret_cast<const int2*>(kept), cap, d);
+  } else {
+    hipLaunchKernelGGL((neus_emit_rows_kernel<2>), dim3((unsigned)ceil_div(m_cap * 2, 256)), dim3(256), 0,
+                       as_stream(stream), p, C, proj_inv, feat_nhwc, row_offset, reinterpret_cast<const int2*>(kept), cap, d);
+  }
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

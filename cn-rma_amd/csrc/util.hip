@@ -137,7 +137,123 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
+// ---- exact-count uniform random subset (device replacement of np.random.choice(M, n_keep, replace=False)) ----------
+// every row gets a 32-bit hash key of (seed, index); the n_keep smallest keys are kept (radix select through two
+// 16-bit histograms); ties on the threshold key are broken by index, so the result is deterministic for a seed.
+__device__ __forceinline__ uint32_t row_hash(uint32_t seed, uint32_t i) {
+  uint32_t x = i * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+struct SampleWs {          // layout of the sampler workspace (int32 words)
+  int32_t hist_hi[65536];
+  int32_t hist_lo[65536];
+  int32_t m, thr_hi, need_lo, thr_key_valid, thr_lo, need_tie, tie_count, pad;
+  int32_t tie_idx[256];
+};
+
+__global__ __launch_bounds__(256) void sample_hist_hi_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
+                                                             SampleWs* __restrict__ ws) {
+  const int64_t M = m_dev[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&ws->hist_hi[row_hash(seed, (uint32_t)i) >> 16], 1);
+}
+
+// one block: first bin b with cumulative count >= n_keep; need = n_keep - cumulative_before(b)
+__global__ __launch_bounds__(1024) void sample_find_kernel(const int32_t* __restrict__ hist, int n_keep_in,
+                                                           const int32_t* __restrict__ need_dev, int32_t* __restrict__ bin_out,
+                                                           int32_t* __restrict__ need_out) {
+  __shared__ int smem[1024 / 64 + 1];
+  __shared__ int found_bin, found_need;
+  const int n_keep = need_dev ? need_dev[0] : n_keep_in;
+  if (threadIdx.x == 0) { found_bin = 65536; found_need = 0; }
+  __syncthreads();
+  int carry = 0;
+  for (int base = 0; base < 65536; base += 1024) {
+    const int v = hist[base + threadIdx.x];
+    int total;
+    const int ex = block_excl_scan<1024>(v, smem, &total) + carry;
+    if (ex < n_keep && ex + v >= n_keep) { found_bin = base + threadIdx.x; found_need = n_keep - ex; }
+    carry += total;
+    __syncthreads();
+    if (found_bin < 65536) break;
+  }
+  if (threadIdx.x == 0) { bin_out[0] = found_bin; need_out[0] = found_need; }
+}
+
+__global__ __launch_bounds__(256) void sample_hist_lo_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
+                                                             SampleWs* __restrict__ ws) {
+  const int64_t M = m_dev[0];
+  const uint32_t hi = (uint32_t)ws->thr_hi;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = row_hash(seed, (uint32_t)i);
+    if ((k >> 16) == hi) atomicAdd(&ws->hist_lo[k & 0xFFFFu], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
+                                                          SampleWs* __restrict__ ws) {
+  const int64_t M = m_dev[0];
+  const uint32_t key = ((uint32_t)ws->thr_hi << 16) | (uint32_t)ws->thr_lo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    if (row_hash(seed, (uint32_t)i) == key) {
+      const int slot = atomicAdd(&ws->tie_count, 1);
+      if (slot < 256) ws->tie_idx[slot] = (int32_t)i;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
+                                                          const SampleWs* __restrict__ ws, int n_keep,
+                                                          uint8_t* __restrict__ mask) {
+  const int64_t M = m_dev[0];
+  __shared__ int32_t tie_bound;     // rows with the threshold key are kept when their index <= tie_bound
+  if (threadIdx.x == 0) {
+    // the need_tie smallest indices among the (normally 1, at most 256) rows that carry the threshold key
+    const int cnt = min(ws->tie_count, 256), need = ws->need_tie;
+    int32_t bound = -1;
+    for (int r = 0; r < need; ++r) {
+      int32_t best = 0x7FFFFFFF;
+      for (int q = 0; q < cnt; ++q) { const int32_t v = ws->tie_idx[q]; if (v > bound && v < best) best = v; }
+      bound = best;
+    }
+    tie_bound = bound;
+  }
+  __syncthreads();
+  const bool all = M <= n_keep;
+  const uint32_t key = ((uint32_t)ws->thr_hi << 16) | (uint32_t)ws->thr_lo;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = row_hash(seed, (uint32_t)i);
+    mask[i] = (all || k < key || (k == key && (int32_t)i <= tie_bound)) ? 1 : 0;
+  }
+}
+
 }  // namespace
+
+extern "C" size_t cnrma_sample_workspace_bytes(void) { return sizeof(SampleWs); }
+
+// mask[0..M) (M = m_dev[0] <= m_cap, read on the device): exactly min(M, n_keep) ones, uniformly random subset
+extern "C" int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask,
+                                 void* workspace, void* stream) {
+  if (m_cap <= 0 || n_keep <= 0 || m_cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  SampleWs* ws = reinterpret_cast<SampleWs*>(workspace);
+  hipError_t e = hipMemsetAsync(ws, 0, sizeof(SampleWs), st);
+  if (e != hipSuccess) return -(int)e;
+  int blocks = (int)(m_cap / 1024 + 1);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sample_hist_hi_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
+  hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws->hist_hi, n_keep, (const int32_t*)nullptr,
+                     &ws->thr_hi, &ws->need_lo);
+  hipLaunchKernelGGL(sample_hist_lo_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
+  hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws->hist_lo, 0, &ws->need_lo, &ws->thr_lo,
+                     &ws->need_tie);
+  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
+  hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws, n_keep, mask);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" size_t cnrma_scan_workspace_bytes(int64_t n) {
   int64_t n_tiles = ceil_div(n > 0 ? n : 1, SCAN_TILE);

@@ -130,6 +130,30 @@ class _March:
             call("cnrma_rma_depth_count_f32", *head, self.k, ptr(cnt), ptr(wsum), stream())
         return cnt, wsum
 
+    def kept_cap(self):
+        """slots per ray for the kept-sample records: a ray's weights sum to <= 1, so it keeps <= 1/thr samples"""
+        if self.mode != "neus" or not (self.thr > 1.0 / 62.0):
+            return 0
+        return int(1.0 / self.thr) + 2
+
+    def march(self):
+        """phase 1 + kept-sample records (NeuS with thr > 1/62 only)"""
+        cap = self.kept_cap()
+        cnt = torch.empty(self.R, dtype=torch.int32, device=self.dev)
+        wsum = torch.empty(self.R, dtype=torch.float64, device=self.dev)
+        kept = torch.empty((self.R, cap, 2), dtype=torch.int32, device=self.dev)
+        overflow = torch.empty(1, dtype=torch.int32, device=self.dev)
+        call("cnrma_rma_neus_march_f32", ptr(self.pinv), ptr(self.tsdf), self.V, self.H, self.W, self.X, self.Y, self.Z,
+             self.vs, *self.org, self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow), stream())
+        return cnt, wsum, kept, overflow
+
+    def emit_rows(self, row_offset, m_cap, kept, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat,
+                  feat_stride, out_sample=None):
+        call("cnrma_rma_neus_emit_rows_f32", ptr(self.pinv), ptr(self.feat), self.V, self.C, self.H, self.W, self.N,
+             self.t_one, ptr(row_offset), int(m_cap), ptr(kept), kept.shape[1], ptr(sel_index), ptr(w_div), float(add[0]),
+             float(add[1]), float(add[2]), out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, ptr(out_sample),
+             stream())
+
     def emit(self, row_offset, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride,
              out_sample=None):
         head = (ptr(self.pinv), ptr(self.tsdf), ptr(self.feat), self.V, self.C, self.H, self.W, self.X, self.Y, self.Z,
@@ -161,6 +185,21 @@ def mask_to_index(mask_u8):
     return sel, n_sel
 
 
+_SAMPLE_CALLS = [0]
+
+
+def sample_mask_device(m_dev, M, n_keep, seed=None):
+    """uint8 [M] keep-mask with exactly min(M, n_keep) ones: a uniformly random subset drawn ON THE DEVICE (device-side
+    stand-in for sample_points' np.random.choice; deterministic in `seed`, advancing per call when seed is None)."""
+    if seed is None:
+        _SAMPLE_CALLS[0] += 1
+        seed = (0x9E3779B9 * _SAMPLE_CALLS[0] + int(torch.initial_seed())) & 0xFFFFFFFF
+    mask = torch.empty(M, dtype=torch.uint8, device=m_dev.device)
+    ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=m_dev.device)
+    call("cnrma_sample_mask", m_dev.data_ptr(), M, int(n_keep), int(seed), ptr(mask), ptr(ws), stream())
+    return mask
+
+
 def _drop_single_sample_views(cnt, wsum, V):
     """Reference quirk: a view that keeps exactly ONE sample is dropped entirely -- torch.squeeze() makes the
     index 0-dim, len() raises and the bare except skips the view (ray_marching.py:781-782, :282-287)."""
@@ -171,13 +210,18 @@ def _drop_single_sample_views(cnt, wsum, V):
 
 
 def rma_view_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
-                  select_grids=0, with_samples=False):
+                  select_grids=0, with_samples=False, single_march=None):
     """Raw rows in the reference's own layout [M, 3+1+C] = [x,y,z,w,feat] for ALL given views, view-major
     (ray_projection_neus :687-807 / ray_projection_depth :809-956), plus per-view row counts [V].
     With `with_samples` also returns int32 [M,2] = (ray index over all views, step) per row."""
     _lib.require_gpu()
     m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids)
-    cnt, wsum = m.count()
+    if single_march is None:
+        single_march = m.kept_cap() > 0
+    if single_march:
+        cnt, wsum, kept, overflow = m.march()
+    else:
+        cnt, wsum = m.count()
     off = exclusive_scan(cnt)
     M = int(off[-1].item())
     per_view = cnt.view(m.V, -1).sum(dim=1)
@@ -186,7 +230,11 @@ def rma_view_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_ste
     samples = torch.empty((M, 2), dtype=torch.int32, device=m.dev) if with_samples else None
     if M > 0:
         base = rows.data_ptr()
-        m.emit(off, None, None, (0.0, 0.0, 0.0), base, Wd, base + 12, Wd, base + 16, Wd, samples)
+        if single_march:
+            assert int(overflow.item()) == 0
+            m.emit_rows(off, M, kept, None, None, (0.0, 0.0, 0.0), base, Wd, base + 12, Wd, base + 16, Wd, samples)
+        else:
+            m.emit(off, None, None, (0.0, 0.0, 0.0), base, Wd, base + 12, Wd, base + 16, Wd, samples)
     return (rows, per_view, samples) if with_samples else (rows, per_view)
 
 
@@ -206,7 +254,11 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
     """
     _lib.require_gpu()
     m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids)
-    cnt, wsum = m.count()
+    single_march = m.kept_cap() > 0
+    if single_march:
+        cnt, wsum, kept, overflow = m.march()
+    else:
+        cnt, wsum = m.count()
     if reference_quirks:
         _drop_single_sample_views(cnt, wsum, m.V)
     off = exclusive_scan(cnt)
@@ -216,7 +268,13 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
     call("cnrma_sum_f64", ptr(wsum), ptr(wtot), m.R, ptr(ws), stream())
     m_total = off[m.R:]
     call("cnrma_rma_mean_weight", ptr(wtot), m_total.data_ptr(), ptr(mean_w), stream())
-    M = int(m_total.item())   # the one read-back the reference also has (nonzero(), :781)
+    # the one read-back the reference also has (nonzero(), :781): total row count (+ the record-overflow guard)
+    if single_march:
+        M, ovf = torch.cat((m_total, overflow)).tolist()
+        if ovf:
+            raise _lib.CnrmaError("kept-sample record overflow: a ray kept more than 1/thr samples")
+    else:
+        M = int(m_total.item())
     if M == 0:
         raise TypeError("no valid points in any view (ray_marching.py:300)")
     sel = None
@@ -229,8 +287,7 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
                 mask = np.zeros(M, dtype=bool)
                 mask[np.random.choice(M, max_points, replace=False)] = True
             elif sampler == "device":
-                mask = torch.zeros(M, dtype=torch.uint8, device=m.dev)
-                mask[torch.randperm(M, device=m.dev)[:max_points]] = 1
+                mask = sample_mask_device(m_total, M, max_points)
             else:
                 raise ValueError(f"unknown sampler {sampler!r}")
         if isinstance(mask, np.ndarray):
@@ -244,8 +301,11 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
             Ms = int(n_sel.item())
     coords = torch.empty((Ms, 3), dtype=torch.float32, device=m.dev)
     feats = torch.empty((Ms, m.C), dtype=torch.float32, device=m.dev)
-    m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
-    info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, per_view=cnt.view(m.V, -1).sum(dim=1))
+    if single_march:
+        m.emit_rows(off, M, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
+    else:
+        m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
+    info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, count=cnt)
     return coords, feats, info
 
 

@@ -93,6 +93,29 @@ int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const floa
                             float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
                             int feat_stride, int32_t* out_sample, void* stream);
 
+/* Single-march variant of the NeuS pair (production path).  cnrma_rma_neus_march_f32 = phase 1 plus a per-ray record
+ * of the kept samples: kept[ray][cap] x {int32 weight bits, int32 step} (8 bytes each), cap >= floor(1/thr) + 2 (a
+ * ray's weights sum to <= 1, so it keeps at most 1/thr samples; overflow[0] counts violations and must read 0).
+ * cnrma_rma_neus_emit_rows_f32 = phase 2 from those records: one lane group per SOURCE row m < M (M = row_offset[R],
+ * read on the device; m_cap bounds the grid), rows dropped by sel_index exit immediately -- nothing is re-marched.
+ * Same destination description and arithmetic (place = o + d * (n * t_one)) as cnrma_rma_neus_emit_f32. */
+int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y, int Z,
+                             float voxel_size, float ox, float oy, float oz, int n_steps, float t_one, float thr,
+                             int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow, void* stream);
+int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
+                                 int n_steps, float t_one, const int32_t* row_offset, int64_t m_cap, const void* kept,
+                                 int cap, const int32_t* sel_index, const float* w_div, float addx, float addy,
+                                 float addz, float* out_xyz, int xyz_stride, float* out_w, int w_stride,
+                                 float* out_feat, int feat_stride, int32_t* out_sample, void* stream);
+
+/* Device-side replacement of sample_points()'s np.random.choice(M, n_keep, replace=False)
+ * (fcaf3d_transforms.py:283-296): mask[0..M) gets exactly min(M, n_keep) ones, a uniformly random subset that is a
+ * deterministic function of `seed` (smallest n_keep 32-bit hash keys, ties by index).  M = m_dev[0] is read on the
+ * device (no host sync); m_cap bounds the grid.  Same distribution as the reference, different random stream. */
+size_t cnrma_sample_workspace_bytes(void);
+int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask, void* workspace,
+                      void* stream);
+
 /* a6  depth variant   replaces ray_projection_depth()  ray_marching.py:809-956
  * Every ray emits exactly NUM = max(1, 2*select_grids) candidate slots; count[ray] = number of slots with
  * weight > 0.  Same two-phase protocol and destination description as the NeuS pair. */

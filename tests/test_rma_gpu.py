@@ -69,13 +69,14 @@ def test_ray_params_bit_exact(device, name):
     assert count_mismatch(d, g["ray_d"]) == 0
 
 
+@pytest.mark.parametrize("single_march", [False, True])
 @pytest.mark.parametrize("name", SCENES)
-def test_neus_rows_vs_golden(device, name):
+def test_neus_rows_vs_golden(device, name, single_march):
     from cnrma_amd import rma
     g = load_golden(name)
     feats, pinv, tsdf = _scene(g, device)
     rows, per_view, samples = rma.rma_view_rows(feats, pinv, tsdf, g["dims"], g["voxel_size"], g["origin"], g["n_steps"],
-                                                g["thr"], with_samples=True)
+                                                g["thr"], with_samples=True, single_march=single_march)
     assert list(per_view.cpu().numpy()) == list(g["neus_counts"])        # kept set: same size per view
     rows = rows.cpu().numpy()
     exp = g["neus_rows"]
@@ -151,6 +152,22 @@ def test_device_sampler_keeps_exactly_max_points(device):
     full, _ = rma.aggregate_rows(feats, pinv, tsdf, g["dims"], g["voxel_size"], g["origin"], 300, g["thr"])
     key = {tuple(r) for r in full[:, :3].cpu().numpy().view(np.uint32)}
     assert all(tuple(r) in key for r in c.cpu().numpy().view(np.uint32))
+
+
+def test_device_sampler_is_exact_uniform_and_deterministic(device):
+    from cnrma_amd import rma
+    M, keep = 1_000_003, 250_000
+    m_dev = torch.tensor([M], dtype=torch.int32, device=device)
+    a = rma.sample_mask_device(m_dev, M, keep, seed=123)
+    b = rma.sample_mask_device(m_dev, M, keep, seed=123)
+    c = rma.sample_mask_device(m_dev, M, keep, seed=124)
+    assert int(a.sum()) == keep and torch.equal(a, b) and int(c.sum()) == keep and not torch.equal(a, c)
+    # uniformity: every tenth of the index range holds ~keep/10 selected rows (binomial sd ~ 137)
+    parts = a.view(-1)[: M // 10 * 10].view(10, -1).sum(dim=1).float()
+    assert (parts - keep / 10).abs().max() < 900
+    assert int(rma.sample_mask_device(m_dev, M, M + 5, seed=1).sum()) == M       # keep everything when M <= n_keep
+    for k in (1, 2, 999_999):
+        assert int(rma.sample_mask_device(m_dev, M, k, seed=7).sum()) == k
 
 
 def test_all_views_empty_raises_like_reference(device):
