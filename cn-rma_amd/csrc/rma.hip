@@ -195,34 +195,38 @@ __global__ __launch_bounds__(256) void neus_count_kernel(MarchParams p, const fl
   wsum[r] = ws;
 }
 
-// Emission from the kept-sample records: LPR lanes per SOURCE row m (rows that the keep-mask drops exit at once).
-// The row's ray is found by binary search in row_offset; place = o + d*t is recomputed with the march's arithmetic.
+// Emission from the kept-sample records, two small kernels:
+//  (1) one lane per ray copies the records of its SELECTED samples to their output position: rec[j] = {ray, step, w};
+//  (2) LPR lanes per OUTPUT row j rebuild the place (o + d*t with the march's arithmetic) and copy the pixel's
+//      channel vector (one full 128-B line read and written per row at C = 32).
+__global__ __launch_bounds__(256) void neus_scatter_records_kernel(int64_t R, const int32_t* __restrict__ row_offset,
+                                                                   const int2* __restrict__ kept, int cap,
+                                                                   const int32_t* __restrict__ sel,
+                                                                   int4* __restrict__ rec) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int64_t m0 = row_offset[r];
+  const int c = (int)(row_offset[r + 1] - m0);     // 0 for rays of dropped views as well
+  for (int i = 0; i < c; ++i) {
+    const int64_t j = sel ? (int64_t)sel[m0 + i] : m0 + i;
+    if (j < 0) continue;
+    const int2 k = kept[r * cap + i];
+    rec[j] = make_int4((int)r, k.y, k.x, 0);
+  }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void neus_emit_rows_kernel(MarchParams p, int C, const float* __restrict__ proj_inv,
-                                                            const float* __restrict__ feat,
-                                                            const int32_t* __restrict__ row_offset,
-                                                            const int2* __restrict__ kept, int cap, EmitDst dst) {
-  const int64_t R = (int64_t)p.V * p.H * p.W;
-  const int64_t M = row_offset[R];
+                                                            const float* __restrict__ feat, int64_t n_rows,
+                                                            const int4* __restrict__ rec, EmitDst dst) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t m = t / LPR;
+  const int64_t j = t / LPR;
   const int sub = (int)(t % LPR);
-  if (m >= M) return;
-  int64_t j = m;
-  if (dst.sel) {
-    j = dst.sel[m];
-    if (j < 0) return;
-  }
-  // largest r with row_offset[r] <= m
-  int64_t lo = 0, hi = R;                       // invariant: row_offset[lo] <= m < row_offset[hi]
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (row_offset[mid] <= m) lo = mid; else hi = mid;
-  }
-  const int64_t r = lo;
-  const int2 rec = kept[r * cap + (m - row_offset[r])];
-  const float w = __int_as_float(rec.x);
-  const int n = rec.y;
+  if (j >= n_rows) return;
+  const int4 rc = rec[j];
+  const int64_t r = rc.x;
+  const int n = rc.y;
+  const float w = __int_as_float(rc.z);
   const int view = (int)(r / ((int64_t)p.H * p.W));
   const int pix = (int)(r - (int64_t)view * p.H * p.W);
   if (sub == 0) {
@@ -255,7 +259,6 @@ __global__ __launch_bounds__(256) void neus_emit_rows_kernel(MarchParams p, int 
     }
   }
 }
-
 
 __device__ __forceinline__ void emit_row(const EmitDst& d, int64_t m, float x, float y, float z, float w,
                                          const float* __restrict__ f, int C, int64_t ray, int step) {
@@ -449,20 +452,26 @@ extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf
 }
 
 extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
-                                            int n_steps, float t_one, const int32_t* row_offset, int64_t m_cap,
-                                            const void* kept, int cap, const int32_t* sel_index, const float* w_div,
-                                            float addx, float addy, float addz, float* out_xyz, int xyz_stride,
-                                            float* out_w, int w_stride, float* out_feat, int feat_stride,
-                                            int32_t* out_sample, void* stream) {
-  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || m_cap <= 0 || kept == nullptr || cap <= 0) return CNRMA_EINVAL;
+                                            int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
+                                            const void* kept, int cap, const int32_t* sel_index, void* records,
+                                            const float* w_div, float addx, float addy, float addz, float* out_xyz,
+                                            int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                                            int feat_stride, int32_t* out_sample, void* stream) {
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || n_out <= 0 || kept == nullptr || cap <= 0 || records == nullptr)
+    return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, 1, 1, 1, 1.0f, 0.f, 0.f, 0.f, n_steps, t_one, 0.0f);
-  EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, out_sample, sel_index, w_div, addx, addy, addz};
+  EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, out_sample, nullptr, w_div, addx, addy, addz};
+  const int64_t R = (int64_t)V * H * W;
+  hipStream_t st = as_stream(stream);
+  int4* rec = reinterpret_cast<int4*>(records);
+  hipLaunchKernelGGL(neus_scatter_records_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, st, R, row_offset,
+                     reinterpret_cast<const int2*>(kept), cap, sel_index, rec);
   if (C % 32 == 0) {
-    hipLaunchKernelGGL((neus_emit_rows_kernel<8>), dim3((unsigned)ceil_div(m_cap * 8, 256)), dim3(256), 0,
-                       as_stream(stream), p, C, proj_inv, feat_nhwc, row_offset, reinterpret_cast<const int2*>(kept), cap, d);
+    hipLaunchKernelGGL((neus_emit_rows_kernel<8>), dim3((unsigned)ceil_div(n_out * 8, 256)), dim3(256), 0, st, p, C,
+                       proj_inv, feat_nhwc, n_out, rec, d);
   } else {
-    hipLaunchKernelGGL((neus_emit_rows_kernel<2>), dim3((unsigned)ceil_div(m_cap * 2, 256)), dim3(256), 0,
-                       as_stream(stream), p, C, proj_inv, feat_nhwc, row_offset, reinterpret_cast<const int2*>(kept), cap, d);
+    hipLaunchKernelGGL((neus_emit_rows_kernel<2>), dim3((unsigned)ceil_div(n_out * 2, 256)), dim3(256), 0, st, p, C,
+                       proj_inv, feat_nhwc, n_out, rec, d);
   }
   CNRMA_LAUNCH_CHECK();
   return 0;

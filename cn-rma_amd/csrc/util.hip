@@ -146,56 +146,55 @@ __device__ __forceinline__ uint32_t row_hash(uint32_t seed, uint32_t i) {
   return x;
 }
 
-struct SampleWs {          // layout of the sampler workspace (int32 words)
-  int32_t hist_hi[65536];
-  int32_t hist_lo[65536];
-  int32_t m, thr_hi, need_lo, thr_key_valid, thr_lo, need_tie, tie_count, pad;
+struct SampleWs {          // sampler workspace (int32 words)
+  int32_t hist[3][2048];   // digit histograms: bits 31..21, 20..10, 9..0 of the key (within the selected prefix)
+  int32_t prefix[3];       // selected digit per pass
+  int32_t need[4];         // need[d] = rows still to take inside the prefix after pass d-1 (need[0] = n_keep)
+  int32_t tie_count, pad;
   int32_t tie_idx[256];
 };
 
-__global__ __launch_bounds__(256) void sample_hist_hi_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
-                                                             SampleWs* __restrict__ ws) {
-  const int64_t M = m_dev[0];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&ws->hist_hi[row_hash(seed, (uint32_t)i) >> 16], 1);
+__device__ __forceinline__ int key_digit(uint32_t k, int pass) {
+  return pass == 0 ? (int)(k >> 21) : (pass == 1 ? (int)((k >> 10) & 2047u) : (int)(k & 1023u));
+}
+__device__ __forceinline__ bool key_matches(uint32_t k, int pass, const int32_t* prefix) {
+  if (pass >= 1 && (int)(k >> 21) != prefix[0]) return false;
+  if (pass >= 2 && (int)((k >> 10) & 2047u) != prefix[1]) return false;
+  return true;
 }
 
-// one block: first bin b with cumulative count >= n_keep; need = n_keep - cumulative_before(b)
-__global__ __launch_bounds__(1024) void sample_find_kernel(const int32_t* __restrict__ hist, int n_keep_in,
-                                                           const int32_t* __restrict__ need_dev, int32_t* __restrict__ bin_out,
-                                                           int32_t* __restrict__ need_out) {
-  __shared__ int smem[1024 / 64 + 1];
-  __shared__ int found_bin, found_need;
-  const int n_keep = need_dev ? need_dev[0] : n_keep_in;
-  if (threadIdx.x == 0) { found_bin = 65536; found_need = 0; }
+// block-private LDS histogram of one digit, flushed with (contiguous) global atomics
+__global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restrict__ m_dev, uint32_t seed, int pass,
+                                                          SampleWs* __restrict__ ws) {
+  __shared__ int h[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
   __syncthreads();
-  int carry = 0;
-  for (int base = 0; base < 65536; base += 1024) {
-    const int v = hist[base + threadIdx.x];
-    int total;
-    const int ex = block_excl_scan<1024>(v, smem, &total) + carry;
-    if (ex < n_keep && ex + v >= n_keep) { found_bin = base + threadIdx.x; found_need = n_keep - ex; }
-    carry += total;
-    __syncthreads();
-    if (found_bin < 65536) break;
-  }
-  if (threadIdx.x == 0) { bin_out[0] = found_bin; need_out[0] = found_need; }
-}
-
-__global__ __launch_bounds__(256) void sample_hist_lo_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
-                                                             SampleWs* __restrict__ ws) {
   const int64_t M = m_dev[0];
-  const uint32_t hi = (uint32_t)ws->thr_hi;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t k = row_hash(seed, (uint32_t)i);
-    if ((k >> 16) == hi) atomicAdd(&ws->hist_lo[k & 0xFFFFu], 1);
+    if (key_matches(k, pass, ws->prefix)) atomicAdd(&h[key_digit(k, pass)], 1);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (h[i]) atomicAdd(&ws->hist[pass][i], h[i]);
+}
+
+// one block of 1024 threads, 2 bins each: first digit whose cumulative count reaches need[pass]
+__global__ __launch_bounds__(1024) void sample_find_kernel(SampleWs* __restrict__ ws, int pass, int n_keep) {
+  __shared__ int smem[1024 / 64 + 1];
+  const int need = pass == 0 ? n_keep : ws->need[pass];
+  const int a = ws->hist[pass][2 * threadIdx.x], b = ws->hist[pass][2 * threadIdx.x + 1];
+  int total;
+  const int ex = block_excl_scan<1024>(a + b, smem, &total);
+  if (ex < need && ex + a >= need) { ws->prefix[pass] = 2 * threadIdx.x; ws->need[pass + 1] = need - ex; }
+  else if (ex + a < need && ex + a + b >= need) { ws->prefix[pass] = 2 * threadIdx.x + 1; ws->need[pass + 1] = need - ex - a; }
+  if (threadIdx.x == 0 && pass == 0) ws->need[0] = n_keep;
 }
 
 __global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
                                                           SampleWs* __restrict__ ws) {
   const int64_t M = m_dev[0];
-  const uint32_t key = ((uint32_t)ws->thr_hi << 16) | (uint32_t)ws->thr_lo;
+  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     if (row_hash(seed, (uint32_t)i) == key) {
       const int slot = atomicAdd(&ws->tie_count, 1);
@@ -210,8 +209,8 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
   const int64_t M = m_dev[0];
   __shared__ int32_t tie_bound;     // rows with the threshold key are kept when their index <= tie_bound
   if (threadIdx.x == 0) {
-    // the need_tie smallest indices among the (normally 1, at most 256) rows that carry the threshold key
-    const int cnt = min(ws->tie_count, 256), need = ws->need_tie;
+    // the need smallest indices among the (normally 1, at most 256) rows that carry the threshold key
+    const int cnt = min(ws->tie_count, 256), need = ws->need[3];
     int32_t bound = -1;
     for (int r = 0; r < need; ++r) {
       int32_t best = 0x7FFFFFFF;
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
   }
   __syncthreads();
   const bool all = M <= n_keep;
-  const uint32_t key = ((uint32_t)ws->thr_hi << 16) | (uint32_t)ws->thr_lo;
+  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t k = row_hash(seed, (uint32_t)i);
     mask[i] = (all || k < key || (k == key && (int32_t)i <= tie_bound)) ? 1 : 0;
@@ -241,14 +240,12 @@ extern "C" int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep
   SampleWs* ws = reinterpret_cast<SampleWs*>(workspace);
   hipError_t e = hipMemsetAsync(ws, 0, sizeof(SampleWs), st);
   if (e != hipSuccess) return -(int)e;
-  int blocks = (int)(m_cap / 1024 + 1);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sample_hist_hi_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
-  hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws->hist_hi, n_keep, (const int32_t*)nullptr,
-                     &ws->thr_hi, &ws->need_lo);
-  hipLaunchKernelGGL(sample_hist_lo_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
-  hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws->hist_lo, 0, &ws->need_lo, &ws->thr_lo,
-                     &ws->need_tie);
+  int blocks = (int)(m_cap / 2048 + 1);
+  if (blocks > 1024) blocks = 1024;
+  for (int pass = 0; pass < 3; ++pass) {
+    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, pass, ws);
+    hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws, pass, n_keep);
+  }
   hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
   hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws, n_keep, mask);
   CNRMA_LAUNCH_CHECK();

@@ -147,10 +147,11 @@ class _March:
              self.vs, *self.org, self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow), stream())
         return cnt, wsum, kept, overflow
 
-    def emit_rows(self, row_offset, m_cap, kept, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat,
+    def emit_rows(self, row_offset, n_out, kept, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat,
                   feat_stride, out_sample=None):
+        rec = torch.empty((int(n_out), 4), dtype=torch.int32, device=self.dev)
         call("cnrma_rma_neus_emit_rows_f32", ptr(self.pinv), ptr(self.feat), self.V, self.C, self.H, self.W, self.N,
-             self.t_one, ptr(row_offset), int(m_cap), ptr(kept), kept.shape[1], ptr(sel_index), ptr(w_div), float(add[0]),
+             self.t_one, ptr(row_offset), int(n_out), ptr(kept), kept.shape[1], ptr(sel_index), ptr(rec), ptr(w_div), float(add[0]),
              float(add[1]), float(add[2]), out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, ptr(out_sample),
              stream())
 
@@ -302,7 +303,7 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
     coords = torch.empty((Ms, 3), dtype=torch.float32, device=m.dev)
     feats = torch.empty((Ms, m.C), dtype=torch.float32, device=m.dev)
     if single_march:
-        m.emit_rows(off, M, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
+        m.emit_rows(off, Ms, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
     else:
         m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
     info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, count=cnt)

@@ -96,16 +96,17 @@ int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const floa
 /* Single-march variant of the NeuS pair (production path).  cnrma_rma_neus_march_f32 = phase 1 plus a per-ray record
  * of the kept samples: kept[ray][cap] x {int32 weight bits, int32 step} (8 bytes each), cap >= floor(1/thr) + 2 (a
  * ray's weights sum to <= 1, so it keeps at most 1/thr samples; overflow[0] counts violations and must read 0).
- * cnrma_rma_neus_emit_rows_f32 = phase 2 from those records: one lane group per SOURCE row m < M (M = row_offset[R],
- * read on the device; m_cap bounds the grid), rows dropped by sel_index exit immediately -- nothing is re-marched.
+ * cnrma_rma_neus_emit_rows_f32 = phase 2 from those records: a per-ray pass moves the records of the selected samples to
+ * their output position (records: scratch of 16 bytes x n_out), then one 8-lane group per OUTPUT row (n_out of them)
+ * writes the row -- nothing is re-marched.
  * Same destination description and arithmetic (place = o + d * (n * t_one)) as cnrma_rma_neus_emit_f32. */
 int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y, int Z,
                              float voxel_size, float ox, float oy, float oz, int n_steps, float t_one, float thr,
                              int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow, void* stream);
 int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
-                                 int n_steps, float t_one, const int32_t* row_offset, int64_t m_cap, const void* kept,
-                                 int cap, const int32_t* sel_index, const float* w_div, float addx, float addy,
-                                 float addz, float* out_xyz, int xyz_stride, float* out_w, int w_stride,
+                                 int n_steps, float t_one, const int32_t* row_offset, int64_t n_out, const void* kept,
+                                 int cap, const int32_t* sel_index, void* records, const float* w_div, float addx,
+                                 float addy, float addz, float* out_xyz, int xyz_stride, float* out_w, int w_stride,
                                  float* out_feat, int feat_stride, int32_t* out_sample, void* stream);
 
 /* Device-side replacement of sample_points()'s np.random.choice(M, n_keep, replace=False)
