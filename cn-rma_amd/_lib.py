@@ -53,6 +53,9 @@ SIGNATURES = {
     "cnrma_sparse_prune_f32": (c_int, [P, P, L, P, I, P, P, P, P]),
     "cnrma_rowmax_f32": (c_int, [P, L, P, I, P, P]),
     "cnrma_fcaf3d_decode_f32": (c_int, [P, P, I, L, I, P, P]),
+    "cnrma_fcaf3d_head_post_f32": (c_int, [P, I, P, L, I, I, P, F, P, P, P, P, P, P]),
+    "cnrma_fcaf3d_max_score_f32": (c_int, [P, P, L, I, P, P]),
+    "cnrma_fcaf3d_select_decode_f32": (c_int, [P, L, P, P, P, P, I, I, I, P, P, P]),
     "cnrma_fcaf3d_scores_f32": (c_int, [P, P, L, I, P, P, P]),
 }
 

@@ -143,6 +143,7 @@ class _March:
         wsum = torch.empty(self.R, dtype=torch.float64, device=self.dev)
         kept = torch.empty((self.R, cap, 2), dtype=torch.int32, device=self.dev)
         overflow = torch.empty(1, dtype=torch.int32, device=self.dev)
+        self._overflow = overflow
         call("cnrma_rma_neus_march_f32", ptr(self.pinv), ptr(self.tsdf), self.V, self.H, self.W, self.X, self.Y, self.Z,
              self.vs, *self.org, self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow), stream())
         return cnt, wsum, kept, overflow

@@ -49,13 +49,24 @@ class CoordMap:
         self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
 
 
+_OFFSETS = {}
+
+
+def _offsets_tensor(kernel_size, stride, device):
+    key = (kernel_size, stride, device)
+    if key not in _OFFSETS:
+        _OFFSETS[key] = torch.tensor(kernel_offsets(kernel_size, stride), dtype=torch.int32, device=device)
+    return _OFFSETS[key]
+
+
 class CoordSet:
-    def __init__(self, coords, stride, cmap=None):
+    def __init__(self, coords, stride, cmap=None, n_batch=1):
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
         self.C = coords.contiguous()
         self.n = coords.shape[0]
         self.stride = int(stride)
         self.device = coords.device
+        self.n_batch = n_batch     # number of scenes in the tensor (the reference is structurally 1 per GPU)
         self._map = cmap
         self._nbr = {}        # (kernel_size, id(out CoordSet)) -> nbr table
         self._children = {}   # new_stride -> CoordSet
@@ -80,14 +91,14 @@ class CoordSet:
             call("cnrma_sparse_stride_coords", ptr(self.C), self.n, None, ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
                  ptr(n_out), ptr(ws), stream())
             n = int(n_out.item())
-            self._children[ns] = CoordSet(out[:n], ns, m)
+            self._children[ns] = CoordSet(out[:n], ns, m, self.n_batch)
         return self._children[ns]
 
     def neighbours(self, out_set, kernel_size, offset_stride):
         """nbr[No][K]: row of `self` at out_coord + offset_k (or -1)."""
         key = (kernel_size, offset_stride, id(out_set))
         if key not in self._nbr:
-            offs = torch.tensor(kernel_offsets(kernel_size, offset_stride), dtype=torch.int32, device=self.device)
+            offs = _offsets_tensor(kernel_size, offset_stride, self.device)
             K = offs.shape[0]
             nbr = torch.empty((out_set.n, K), dtype=torch.int32, device=self.device)
             m = self.cmap
@@ -130,11 +141,10 @@ class SparseTensor:
 
     @property
     def decomposition_permutations(self):
-        b = self.cs.C[:, 0]
-        nb = int(b.max().item()) + 1 if self.cs.n else 0
-        if nb <= 1:
+        if self.cs.n_batch <= 1:
             return [torch.arange(self.cs.n, device=self.device)]
-        return [torch.nonzero(b == i).squeeze(1) for i in range(nb)]
+        b = self.cs.C[:, 0]
+        return [torch.nonzero(b == i).squeeze(1) for i in range(self.cs.n_batch)]
 
     @property
     def decomposed_coordinates(self):
@@ -179,7 +189,7 @@ def sparse_collate(list_of_coords_feats, voxel_size):
         return parts[0][0]
     C = torch.cat([p[0].C for p in parts])
     F = torch.cat([p[0].F for p in parts])
-    return SparseTensor(F, CoordSet(C, 1))
+    return SparseTensor(F, CoordSet(C, 1, None, len(parts)))
 
 
 def fold_bn(bn, bias=None):
@@ -275,7 +285,7 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None):
     if n:
         call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, Cin, half, ptr(w), Cout, ptr(scale),
              ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
-    return SparseTensor(out_f, CoordSet(out_c, half))
+    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch))
 
 
 def max_pool(x, kernel_size=2, stride=2):
@@ -320,7 +330,7 @@ def union_add(a, b):
     call("cnrma_sparse_union_add_f32", ptr(a.C), ptr(a.F.contiguous()), na, None, ptr(b.C), ptr(b.F.contiguous()), nb,
          None, C, ptr(m.keys), ptr(m.vals), m.cap, ptr(out_c), ptr(out_f), ptr(n_out), ptr(ws), stream())
     n = int(n_out.item())
-    return SparseTensor(out_f[:n], CoordSet(out_c[:n], a.cs.stride, m))
+    return SparseTensor(out_f[:n], CoordSet(out_c[:n], a.cs.stride, m, max(a.cs.n_batch, b.cs.n_batch)))
 
 
 def interpolate(score, query_coords):
@@ -349,7 +359,53 @@ def prune(x, keep_mask):
     if n:
         call("cnrma_sparse_prune_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, C, ptr(sel), ptr(out_c), ptr(out_f),
              stream())
-    return SparseTensor(out_f, CoordSet(out_c, x.cs.stride))
+    return SparseTensor(out_f, CoordSet(out_c, x.cs.stride, None, x.cs.n_batch))
+
+
+def head_post(y, coords, n_reg, n_cls, scale, voxel_size):
+    """tail of FCAF3DHead.forward_single over the fused head GEMM output y [n, >= 1+R+n_cls] (one kernel)."""
+    _lib.require_gpu()
+    n, ldy = y.shape
+    dev = y.device
+    cen = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    box = torch.empty((n, n_reg), dtype=torch.float32, device=dev)
+    cls = torch.empty((n, n_cls), dtype=torch.float32, device=dev)
+    mx = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    pts = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    if n:
+        call("cnrma_fcaf3d_head_post_f32", ptr(y), ldy, ptr(coords), n, n_reg, n_cls, ptr(scale.detach().view(1)),
+             float(voxel_size), ptr(cen), ptr(box), ptr(cls), ptr(mx), ptr(pts), stream())
+    return cen, box, cls, mx, pts
+
+
+def max_scores(cls_score, centerness):
+    n, nc = cls_score.shape
+    mx = torch.empty(n, dtype=torch.float32, device=cls_score.device)
+    if n:
+        call("cnrma_fcaf3d_max_score_f32", ptr(cls_score.contiguous()), ptr(centerness.contiguous()), n, nc, ptr(mx), stream())
+    return mx
+
+
+def select_decode(ids, cls_score, centerness, bbox_pred, points, yaw_parametrization="fcaf3d"):
+    """scores (sigmoid(cls)*sigmoid(ctr)) and decoded boxes of the rows `ids` (None = all rows) in one kernel."""
+    n, R = bbox_pred.shape
+    nc = cls_score.shape[1]
+    k = n if ids is None else ids.shape[0]
+    if R == 6:
+        mode, W = 0, 6
+    elif yaw_parametrization == "naive":
+        mode, W = 3, 7
+    elif yaw_parametrization == "sin-cos":
+        mode, W = 2, 7
+    else:
+        mode, W = 1, 7
+    scores = torch.empty((k, nc), dtype=torch.float32, device=bbox_pred.device)
+    boxes = torch.empty((k, W), dtype=torch.float32, device=bbox_pred.device)
+    if k:
+        call("cnrma_fcaf3d_select_decode_f32", ptr(ids.contiguous()) if ids is not None else None, k,
+             ptr(cls_score.contiguous()), ptr(centerness.contiguous()), ptr(bbox_pred.contiguous()),
+             ptr(points.contiguous().float()), nc, R, mode, ptr(scores), ptr(boxes), stream())
+    return boxes, scores
 
 
 def row_max(feats):

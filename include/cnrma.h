@@ -272,6 +272,20 @@ int cnrma_rowmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C
  * ---------------------------------------------------------------------------------------------------------- */
 int cnrma_fcaf3d_decode_f32(const float* points_xyz, const float* reg, int R, int64_t n, int yaw_mode,
                             float* boxes, void* stream);
+/* fused variants used by the production path:
+ * head_post: tail of FCAF3DHead.forward_single (fcaf3d_head.py:276-298) over the fused head GEMM output
+ *   y[n][ldy] = [centerness | reg(R) | cls(n_cls) | pad] -> centerness[n], bbox_pred[n][R] (exp(scale*reg[:6]), raw
+ *   angles), cls[n][n_cls], max_cls[n], points[n][3] = coords[:,1:] * voxel_size; scale = DEVICE scalar (Scale layer).
+ * max_score: max_c sigmoid(cls)*sigmoid(centerness), the top-k key of :250-253.
+ * select_decode: for the rows ids[0..k) (int64, NULL = identity): scores (:249) and decoded boxes (:300-349). */
+int cnrma_fcaf3d_head_post_f32(const float* y, int ldy, const int32_t* coords, int64_t n, int R, int n_cls,
+                               const float* scale, float voxel_size, float* centerness, float* bbox_pred, float* cls,
+                               float* max_cls, float* points, void* stream);
+int cnrma_fcaf3d_max_score_f32(const float* cls, const float* centerness, int64_t n, int n_cls, float* max_score,
+                               void* stream);
+int cnrma_fcaf3d_select_decode_f32(const int64_t* ids, int64_t k, const float* cls, const float* centerness,
+                                   const float* reg, const float* points_xyz, int n_cls, int R, int yaw_mode,
+                                   float* scores, float* boxes, void* stream);
 int cnrma_fcaf3d_scores_f32(const float* cls, const float* centerness, int64_t n, int n_cls, float* scores,
                             float* max_score, void* stream);
 

@@ -140,27 +140,30 @@ class FCAF3DHead(nn.Module):
         return self._fused_head
 
     def forward_single(self, x, scale):
-        if self.training:
-            centerness = self.centerness_conv(x).F
-            cls_score = self.cls_conv(x).F
-            reg_final = self.reg_conv(x).F
-        else:
-            w, b = self._head_weights()
-            y = S.conv(x, w, kernel_size=1, shift=b).F
-            n_out = 1 + self.n_reg_outs + self.n_classes
-            centerness, reg_final, cls_score = y[:, :1], y[:, 1:1 + self.n_reg_outs], y[:, 1 + self.n_reg_outs:n_out]
-        prune_scores = S.SparseTensor(S.row_max(cls_score.contiguous()), x.cs)           # :279-282
-        reg_distance = torch.exp(scale(reg_final[:, :6]))                                  # :284
-        bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)                     # :285-286
-        perms = x.decomposition_permutations
-        if len(perms) == 1:
-            centernesses, bbox_preds, cls_scores = [centerness], [bbox_pred], [cls_score]
-        else:
+        if self.training or x.cs.n_batch > 1:
+            if self.training:
+                centerness = self.centerness_conv(x).F
+                cls_score = self.cls_conv(x).F
+                reg_final = self.reg_conv(x).F
+            else:
+                w, b = self._head_weights()
+                y = S.conv(x, w, kernel_size=1, shift=b).F
+                n_out = 1 + self.n_reg_outs + self.n_classes
+                centerness, reg_final, cls_score = y[:, :1], y[:, 1:1 + self.n_reg_outs], y[:, 1 + self.n_reg_outs:n_out]
+            prune_scores = S.SparseTensor(S.row_max(cls_score.contiguous()), x.cs)           # :279-282
+            reg_distance = torch.exp(scale(reg_final[:, :6]))                                  # :284
+            bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)                     # :285-286
+            perms = x.decomposition_permutations
             centernesses = [centerness[p] for p in perms]
             bbox_preds = [bbox_pred[p] for p in perms]
             cls_scores = [cls_score[p] for p in perms]
-        points = [c * self.voxel_size for c in x.decomposed_coordinates]                   # :294-296
-        return centernesses, bbox_preds, cls_scores, points, prune_scores
+            points = [c * self.voxel_size for c in x.decomposed_coordinates]                   # :294-296
+            return centernesses, bbox_preds, cls_scores, points, prune_scores
+        # single scene, eval: the three 1x1 convolutions are ONE GEMM and the whole tail is one kernel
+        w, b = self._head_weights()
+        y = S.conv(x, w, kernel_size=1, shift=b).F
+        cen, box, cls, mx, pts = S.head_post(y, x.C, self.n_reg_outs, self.n_classes, scale.scale, self.voxel_size)
+        return [cen], [box], [cls], [pts], S.SparseTensor(mx, x.cs)
 
     # ---- decoding (reference :217-271, :300-349) -----------------------------------------------------------------
     def _bbox_pred_to_bbox(self, points, bbox_pred):
@@ -172,11 +175,12 @@ class FCAF3DHead(nn.Module):
         mlvl_bboxes, mlvl_scores = [], []
         nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
         for centerness, bbox_pred, cls_score, point in zip(centernesses, bbox_preds, cls_scores, points):
-            scores, max_scores = S.class_scores(cls_score, centerness)                      # :249-250
-            if len(scores) > nms_pre > 0:
+            ids = None
+            if len(cls_score) > nms_pre > 0:
+                max_scores = S.max_scores(cls_score, centerness)                            # :249-250 (ranking key only)
                 _, ids = max_scores.topk(nms_pre)                                           # :252-256
-                bbox_pred, scores, point = bbox_pred[ids], scores[ids], point[ids]
-            mlvl_bboxes.append(self._bbox_pred_to_bbox(point, bbox_pred))
+            boxes, scores = S.select_decode(ids, cls_score, centerness, bbox_pred, point, self.yaw_parametrization)
+            mlvl_bboxes.append(boxes)
             mlvl_scores.append(scores)
         bboxes, scores = torch.cat(mlvl_bboxes), torch.cat(mlvl_scores)
         if save_path is not None:

@@ -197,6 +197,30 @@ def test_decode_and_scores_vs_reference_golden(device):
     assert torch.allclose(s, exp, atol=1e-6) and torch.allclose(mx, exp.max(dim=1)[0], atol=1e-6)
 
 
+def test_fused_head_post_and_select_decode(device):
+    from cnrma_amd import sparse as S
+    z = np.load(os.path.join(GOLDEN, "decode.npz"))
+    g = torch.Generator().manual_seed(5)
+    n, R, nc = 1000, 8, 17
+    y = torch.randn(n, 28, generator=g).to(device)
+    coords = torch.randint(-300, 300, (n, 4), generator=g, dtype=torch.int32).to(device)
+    scale = torch.tensor(1.37, device=device)
+    cen, box, cls, mx, pts = S.head_post(y, coords, R, nc, scale, 0.01)
+    assert torch.equal(cen, y[:, :1]) and torch.equal(cls, y[:, 1 + R:1 + R + nc])
+    assert torch.allclose(box[:, :6], torch.exp(y[:, 1:7] * scale), rtol=1e-6) and torch.equal(box[:, 6:], y[:, 7:9])
+    assert torch.equal(mx[:, 0], cls.max(dim=1)[0]) and torch.equal(pts, coords[:, 1:] * 0.01)
+    # select + decode against the reference's golden decode vectors, through a permutation
+    for nreg, yaw in ((6, "fcaf3d"), (8, "fcaf3d"), (8, "sin-cos"), (7, "naive")):
+        pred = t(z[f"pred_{nreg}_{yaw}"], device)
+        m = pred.shape[0]
+        ids = torch.randperm(m, generator=g)[:100].to(device)
+        c2, ct = torch.randn(m, nc, generator=g).to(device), torch.randn(m, 1, generator=g).to(device)
+        boxes, scores = S.select_decode(ids, c2, ct, pred, t(z["points"], device), yaw)
+        np.testing.assert_allclose(boxes.cpu().numpy(), z[f"box_{nreg}_{yaw}"][ids.cpu().numpy()], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(scores, (torch.sigmoid(c2) * torch.sigmoid(ct))[ids], atol=1e-6)
+        assert torch.allclose(S.max_scores(c2, ct), (torch.sigmoid(c2) * torch.sigmoid(ct)).max(dim=1)[0], atol=1e-6)
+
+
 def _randomise(module, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
