@@ -39,6 +39,8 @@ SIGNATURES = {
     "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, P]),
     "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, P, P, P]),
     "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
+    "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, P]),
+    "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, P]),
     "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
     "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_conv_prepare_weights": (c_int, [P, I, I, I, P, P]),
@@ -94,8 +96,12 @@ def ptr(t):
 
 
 def stream():
+    """raw hipStream_t of torch's current stream on the current device (fast path: no Stream object is built)"""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 def call(name, *args):
@@ -105,7 +111,14 @@ def call(name, *args):
     return rc
 
 
+_gpu_ok = False
+
+
 def require_gpu():
+    global _gpu_ok
+    if _gpu_ok:
+        return
     import torch
     if not torch.cuda.is_available():
         raise CnrmaError("cn-rma_amd needs a HIP device (MI355X); the product path has no CPU implementation")
+    _gpu_ok = True

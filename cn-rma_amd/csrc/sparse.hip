@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
+#include <cstdlib>
 
 namespace {
 
@@ -258,6 +259,71 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
   int4 c = reinterpret_cast<const int4*>(out_coords)[o];
   int64_t s = hash_find(keys, cap, coord_key(c.x, c.y + offsets[k * 3], c.z + offsets[k * 3 + 1], c.w + offsets[k * 3 + 2]));
   nbr[t] = s >= 0 ? vals[s] : -1;
+}
+
+// stride-1, odd kernel: the neighbour relation is symmetric (nbr[o][k] = i  <=>  nbr[i][K-1-k] = o), so only the
+// first K/2 offsets are looked up and both entries are written; the centre is the row itself.  nbr must be
+// pre-filled with -1.
+__global__ __launch_bounds__(256) void kernel_map_symmetric_kernel(const int32_t* __restrict__ coords, int64_t n_cap,
+                                                                   const int32_t* __restrict__ n_dev,
+                                                                   const uint64_t* __restrict__ keys,
+                                                                   const int32_t* __restrict__ vals, int64_t cap,
+                                                                   const int32_t* __restrict__ offsets, int K,
+                                                                   int32_t* __restrict__ nbr) {
+  const int half = K / 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = live_rows(n_cap, n_dev);
+  if (t >= n * (half + 1)) return;
+  const int64_t o = t / (half + 1);
+  const int k = (int)(t - o * (half + 1));
+  if (k == half) { nbr[o * K + half] = (int32_t)o; return; }
+  int4 c = reinterpret_cast<const int4*>(coords)[o];
+  int64_t s = hash_find(keys, cap, coord_key(c.x, c.y + offsets[k * 3], c.z + offsets[k * 3 + 1], c.w + offsets[k * 3 + 2]));
+  if (s >= 0) {
+    const int32_t i = vals[s];
+    nbr[o * K + k] = i;
+    nbr[(int64_t)i * K + (K - 1 - k)] = (int32_t)o;
+  }
+}
+
+// strided maps (stride-2 conv k3 / k1, pooling k2), driven from the INPUT side: an input at p can only feed the
+// outputs o = p - off*s that lie on the coarse lattice -- 1, 2, 4 or 8 candidates for k3 (3.4 on average instead
+// of 27 probes per output), exactly one for k2 (its parent) and for k1 (itself, if on the lattice).
+// Lookups go to the OUTPUT coordinate map; nbr must be pre-filled with -1.
+__global__ __launch_bounds__(256) void kernel_map_strided_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
+                                                                 const int32_t* __restrict__ n_dev, int s, int ksize,
+                                                                 const uint64_t* __restrict__ out_keys,
+                                                                 const int32_t* __restrict__ out_vals, int64_t cap,
+                                                                 int32_t* __restrict__ nbr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= live_rows(n_cap, n_dev)) return;
+  const int4 c = reinterpret_cast<const int4*>(in_coords)[i];
+  const int s2 = 2 * s;
+  auto fl = [s2](int p) { int q = p / s2; if ((p % s2 != 0) && (p < 0)) --q; return q * s2; };
+  const int px = fl(c.y), py = fl(c.z), pz = fl(c.w);              // parent site
+  const int ox = (c.y - px) / s, oy = (c.z - py) / s, oz = (c.w - pz) / s;   // 0 or 1: position inside the parent cell
+  if (ksize == 2) {
+    const int64_t slot = hash_find(out_keys, cap, coord_key(c.x, px, py, pz));
+    if (slot >= 0) nbr[(int64_t)out_vals[slot] * 8 + (ox + 2 * oy + 4 * oz)] = (int32_t)i;
+    return;
+  }
+  if (ksize == 1) {
+    if (ox | oy | oz) return;
+    const int64_t slot = hash_find(out_keys, cap, coord_key(c.x, px, py, pz));
+    if (slot >= 0) nbr[out_vals[slot]] = (int32_t)i;
+    return;
+  }
+  // ksize == 3: per axis the offset (in units of s) from the output to this input is 0 when the input sits on the
+  // lattice, else +1 (output = parent) or -1 (output = parent + 2s)
+  const int nx = ox ? 2 : 1, ny = oy ? 2 : 1, nz = oz ? 2 : 1;
+  for (int a = 0; a < nx; ++a)
+    for (int b = 0; b < ny; ++b)
+      for (int d = 0; d < nz; ++d) {
+        const int offx = ox ? (a == 0 ? 1 : -1) : 0, offy = oy ? (b == 0 ? 1 : -1) : 0, offz = oz ? (d == 0 ? 1 : -1) : 0;
+        const int qx = c.y - offx * s, qy = c.z - offy * s, qz = c.w - offz * s;
+        const int64_t slot = hash_find(out_keys, cap, coord_key(c.x, qx, qy, qz));
+        if (slot >= 0) nbr[(int64_t)out_vals[slot] * 27 + ((offx + 1) + 3 * (offy + 1) + 9 * (offz + 1))] = (int32_t)i;
+      }
 }
 
 // ================================================================================================================
@@ -835,6 +901,12 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   else if (no_cap < 16384) { shape = T64x64; bm = 64; bn = 64; }
   else if (Cout >= 128) { shape = T128x128; bm = 128; bn = 128; }
   else { shape = T128x64; bm = 128; bn = 64; }
+  if (const char* ov = getenv("CNRMA_CONV_SHAPE")) {          // tuning aid (not used by the product path)
+    const int v = atoi(ov);
+    if (Cout > 32 && v == 0) { shape = T64x64; bm = 64; bn = 64; }
+    if (Cout > 32 && v == 1) { shape = T128x64; bm = 128; bn = 64; }
+    if (Cout > 32 && v == 2) { shape = T128x128; bm = 128; bn = 128; }
+  }
   if (slices == 1 && workspace != nullptr) {
     p.splits = choose_splits(no_cap, Cout, K, bm, bn, ws_bytes);
     p.k_per_split = (int)ceil_div(K, p.splits);
@@ -1161,6 +1233,34 @@ extern "C" int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap
   if (no_cap <= 0 || K <= 0) return CNRMA_EINVAL;
   hipLaunchKernelGGL(kernel_map_kernel, dim3((unsigned)ceil_div(no_cap * K, 256)), dim3(256), 0, as_stream(stream),
                      out_coords, no_cap, no_dev, in_hash_keys, in_hash_vals, hash_cap, offsets, K, nbr);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t n_cap, const int32_t* n_dev,
+                                                 const uint64_t* hash_keys, const int32_t* hash_vals, int64_t hash_cap,
+                                                 const int32_t* offsets, int K, int32_t* nbr, void* stream) {
+  if (n_cap <= 0 || K <= 0 || (K & 1) == 0) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(nbr, 0xFF, (size_t)n_cap * K * sizeof(int32_t), st);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(kernel_map_symmetric_kernel, dim3((unsigned)ceil_div(n_cap * (K / 2 + 1), 256)), dim3(256), 0, st,
+                     coords, n_cap, n_dev, hash_keys, hash_vals, hash_cap, offsets, K, nbr);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev,
+                                               int in_stride, int kernel_size, const uint64_t* out_hash_keys,
+                                               const int32_t* out_hash_vals, int64_t hash_cap, int32_t* nbr,
+                                               int64_t no_cap, void* stream) {
+  if (n_cap <= 0 || no_cap <= 0 || in_stride <= 0 || kernel_size < 1 || kernel_size > 3) return CNRMA_EINVAL;
+  const int K = kernel_size * kernel_size * kernel_size;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(nbr, 0xFF, (size_t)no_cap * K * sizeof(int32_t), st);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(kernel_map_strided_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, st, in_coords,
+                     n_cap, n_dev, in_stride, kernel_size, out_hash_keys, out_hash_vals, hash_cap, nbr);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

@@ -85,8 +85,10 @@ def projection_inverse(projections, stride):
     one matrix at a time, exactly as ray_marching.py:96-102 does, so that it is bit-identical to the reference's
     CPU run.  (V 4x4 LAPACK calls: microseconds; this is the only host arithmetic on the path.)"""
     p = scale_projection(projections.detach().to("cpu", torch.float32), stride)
-    last = torch.tensor([[0.0, 0.0, 0.0, 1.0]])
-    return torch.stack([torch.inverse(torch.cat((p[v], last), dim=0)) for v in range(p.shape[0])], dim=0)
+    last = torch.tensor([[[0.0, 0.0, 0.0, 1.0]]]).expand(p.shape[0], 1, 4)
+    # one batched call: on CPU torch loops LAPACK getrf/getri over the matrices, i.e. bit-identical to the reference's
+    # per-matrix loop (checked against the golden proj_inv in tests/test_oracle_cpu.py)
+    return torch.inverse(torch.cat((p, last), dim=1))
 
 
 def ray_params(proj_inv, H, W):

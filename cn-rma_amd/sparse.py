@@ -94,16 +94,30 @@ class CoordSet:
             self._children[ns] = CoordSet(out[:n], ns, m, self.n_batch)
         return self._children[ns]
 
-    def neighbours(self, out_set, kernel_size, offset_stride):
-        """nbr[No][K]: row of `self` at out_coord + offset_k (or -1)."""
+    def neighbours(self, out_set, kernel_size, offset_stride, method="auto"):
+        """nbr[No][K]: row of `self` at out_coord + offset_k (or -1).  method: "generic" probes every (output, offset)
+        pair; "auto" uses the symmetric builder for stride-1 odd kernels on one set and the input-driven builder for
+        the stride-2 maps (identical tables, 2-7x fewer probes)."""
         key = (kernel_size, offset_stride, id(out_set))
         if key not in self._nbr:
             offs = _offsets_tensor(kernel_size, offset_stride, self.device)
             K = offs.shape[0]
             nbr = torch.empty((out_set.n, K), dtype=torch.int32, device=self.device)
-            m = self.cmap
-            call("cnrma_sparse_kernel_map", ptr(out_set.C), out_set.n, None, ptr(m.keys), ptr(m.vals), m.cap, ptr(offs),
-                 K, ptr(nbr), stream())
+            strided = out_set is not self and out_set.stride == 2 * self.stride and offset_stride == self.stride
+            if out_set.n == 0 or self.n == 0:
+                nbr.fill_(-1)
+            elif method == "auto" and out_set is self and kernel_size % 2 == 1 and kernel_size > 1:
+                m = self.cmap
+                call("cnrma_sparse_kernel_map_symmetric", ptr(self.C), self.n, None, ptr(m.keys), ptr(m.vals), m.cap,
+                     ptr(offs), K, ptr(nbr), stream())
+            elif method == "auto" and strided and kernel_size in (1, 2, 3):
+                m = out_set.cmap
+                call("cnrma_sparse_kernel_map_strided", ptr(self.C), self.n, None, self.stride, kernel_size, ptr(m.keys),
+                     ptr(m.vals), m.cap, ptr(nbr), out_set.n, stream())
+            else:
+                m = self.cmap
+                call("cnrma_sparse_kernel_map", ptr(out_set.C), out_set.n, None, ptr(m.keys), ptr(m.vals), m.cap,
+                     ptr(offs), K, ptr(nbr), stream())
             self._nbr[key] = (nbr, out_set)   # keep out_set alive so that id() stays unique
         return self._nbr[key][0]
 

@@ -197,6 +197,18 @@ int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int
                             const uint64_t* in_hash_keys, const int32_t* in_hash_vals, int64_t hash_cap,
                             const int32_t* offsets, int K, int32_t* nbr, void* stream);
 
+/* Faster builders of the SAME table for the two structured cases (results identical to cnrma_sparse_kernel_map):
+ * _symmetric: stride-1 odd kernel on one coordinate set -- nbr[o][k] = i <=> nbr[i][K-1-k] = o, half the probes;
+ * _strided:   stride-2 maps (conv k3 / k1, pooling k2) driven from the input side: an input can only feed the
+ *             outputs on the coarse lattice around it (3.4 probes per input for k3, 1 for k2/k1, instead of K per
+ *             output); probes go to the OUTPUT set's map.  in_stride = tensor stride of the input. */
+int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t n_cap, const int32_t* n_dev,
+                                      const uint64_t* hash_keys, const int32_t* hash_vals, int64_t hash_cap,
+                                      const int32_t* offsets, int K, int32_t* nbr, void* stream);
+int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int in_stride,
+                                    int kernel_size, const uint64_t* out_hash_keys, const int32_t* out_hash_vals,
+                                    int64_t hash_cap, int32_t* nbr, int64_t no_cap, void* stream);
+
 /* fused sparse convolution, output-stationary gather-GEMM on fp32 MFMA:
  *   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift + residual[o] )
  * W[K][Cin][Cout] (ME "kernel" layout), scale/shift per output channel (folded BatchNorm / bias; NULL = 1 / 0),

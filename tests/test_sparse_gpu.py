@@ -122,6 +122,23 @@ def test_bf16x6_is_fp32_grade_on_wide_dynamic_range(device):
     assert (np.abs(y6 - ref) / (mag + 1e-30)).max() < 2e-6
 
 
+@pytest.mark.parametrize("ts", [1, 4])
+def test_structured_kernel_maps_equal_generic(device, ts):
+    """the symmetric (stride-1) and input-driven (stride-2 conv k3/k1, pool k2) builders give the generic table"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(ts)
+    c, _ = rand_sparse(rng, n=20000, span=16, C=1, ts=ts, batch=2)
+    cs = S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), ts, n_batch=2)
+    child = cs.strided(2)
+    for ksize, out in ((3, cs), (3, child), (2, child), (1, child)):
+        fast = cs.neighbours(out, ksize, ts, method="auto").clone()
+        cs._nbr.clear()
+        ref = cs.neighbours(out, ksize, ts, method="generic").clone()
+        cs._nbr.clear()
+        assert torch.equal(fast, ref), (ksize, out is cs)
+        assert (ref >= 0).any()
+
+
 def test_conv_fused_epilogue(device):
     from cnrma_amd import sparse as S
     rng = np.random.RandomState(5)
