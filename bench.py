@@ -89,8 +89,11 @@ class KernelProfile:
             d["ms"] += ms
             d["n"] += 1
             if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
-                # args: in, Cin, nbr, K, W, Cout, scale, shift, res, act, out, no_cap, no_dev, stream
-                d["flops"] += 2.0 * args[3] * args[1] * args[5] * args[11]      # dense-K upper bound (executed MFMA work)
+                if name == "cnrma_sparse_conv_f32":   # in, Cin, nbr, K, W, Cout, scale, shift, res, act, out, no_cap, ...
+                    cin, k, cout, rows = args[1], args[3], args[5], args[11]
+                else:                                 # in, in_split, zero_row, Cin, nbr, K, Wsplit, Cout, ..., out, out_split, no_cap
+                    cin, k, cout, rows = args[3], args[5], args[7], args[14]
+                d["flops"] += 2.0 * k * cin * cout * rows      # dense-K upper bound (executed MFMA work)
         return agg
 
 

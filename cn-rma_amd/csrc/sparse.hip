@@ -355,7 +355,28 @@ struct ConvArgs {
   int splits;        // > 1: split over kernel offsets, raw partial sums go to slab[z]
   int k_per_split;
   float* slab;       // [splits][no_cap][Cout]
+  // pre-split bf16 companions of the features: [rows + 1][C/8][3 planes][8] (hi/mid/lo of 8 channels = 48 B), the
+  // extra last row is all zeros and stands in for missing neighbours (no select in the gather)
+  const uint16_t* in_split; int64_t in_zero_row;
+  uint16_t* out_split; int64_t out_zero_row;
 };
+
+// exact 3-way split by truncation: h = top 8 significant bits of a, m = next 8, l = last 8 (a == h + m + l)
+__device__ __forceinline__ void split3_trunc(float a, uint16_t& h, uint16_t& m, uint16_t& l) {
+  const uint32_t uh = __float_as_uint(a) & 0xFFFF0000u;
+  const float r1 = a - __uint_as_float(uh);
+  const uint32_t um = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(um);
+  h = (uint16_t)(uh >> 16); m = (uint16_t)(um >> 16); l = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
+// one output element into the split companion (column `col` of row `row`)
+__device__ __forceinline__ void store_split(uint16_t* sp, int64_t row, int C, int col, float v) {
+  uint16_t h, m, l;
+  split3_trunc(v, h, m, l);
+  uint16_t* q = sp + (row * (C >> 3) + (col >> 3)) * 24 + (col & 7);
+  q[0] = h; q[8] = m; q[16] = l;
+}
 
 // FAST: Cin % 32 == 0 and Cout % 4 == 0 and Cout >= 4 -- every staging load is an unconditional 16-byte load with
 // a clamped address and a select afterwards (no per-element branches: hipcc would wait vmcnt(0) inside each one and
@@ -599,16 +620,38 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 constexpr int LDK = 40;
 
-__device__ __forceinline__ void split3(const float4& v, bf16x4_t& h, bf16x4_t& m, bf16x4_t& l) {
-  const float a[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 hh = (__bf16)a[j];
-    const float r1 = a[j] - (float)hh;       // exact
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;         // exact
-    h[j] = hh; m[j] = mm; l[j] = (__bf16)r2;
+__device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint2& l) {
+  uint16_t hh[4], mm[4], ll[4];
+  split3_trunc(v.x, hh[0], mm[0], ll[0]);
+  split3_trunc(v.y, hh[1], mm[1], ll[1]);
+  split3_trunc(v.z, hh[2], mm[2], ll[2]);
+  split3_trunc(v.w, hh[3], mm[3], ll[3]);
+  h = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
+  m = make_uint2((uint32_t)mm[0] | ((uint32_t)mm[1] << 16), (uint32_t)mm[2] | ((uint32_t)mm[3] << 16));
+  l = make_uint2((uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16));
+}
+
+// fp32 [N][C] -> split companion [N+1][C/8][3][8] bf16 (+ the zero row at index n_cap); one lane per 8 channels
+__global__ __launch_bounds__(256) void split_features_kernel(const float* __restrict__ in, int64_t n_cap,
+                                                             const int32_t* __restrict__ n_dev, int C,
+                                                             uint16_t* __restrict__ out) {
+  const int64_t n = live_rows(n_cap, n_dev);
+  const int G = C >> 3;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < G) {                                           // zero row
+    uint4* z = reinterpret_cast<uint4*>(out + (n_cap * G + t) * 24);
+    z[0] = make_uint4(0, 0, 0, 0); z[1] = make_uint4(0, 0, 0, 0); z[2] = make_uint4(0, 0, 0, 0);
   }
+  if (t >= n * G) return;
+  const float4 a = *reinterpret_cast<const float4*>(in + t * 8);
+  const float4 b = *reinterpret_cast<const float4*>(in + t * 8 + 4);
+  uint2 h0, m0, l0, h1, m1, l1;
+  split3(a, h0, m0, l0);
+  split3(b, h1, m1, l1);
+  uint4* q = reinterpret_cast<uint4*>(out + t * 24);
+  q[0] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  q[1] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+  q[2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
 // W fp32 [K][Cin][Cout] -> Wt bf16 [3 planes][K][Cout][Cin]
@@ -621,20 +664,83 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
     const int co = (int)(q % Cout);
     const int k = (int)(q / Cout);
     const float a = w[((int64_t)k * Cin + cin) * Cout + co];
-    const __bf16 hh = (__bf16)a;
-    const float r1 = a - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;
-    wt[t] = hh;
-    wt[total + t] = mm;
-    wt[2 * total + t] = (__bf16)r2;
+    uint16_t hh, mm, ll;
+    split3_trunc(a, hh, mm, ll);
+    uint16_t* o = reinterpret_cast<uint16_t*>(wt);
+    o[t] = hh;
+    o[total + t] = mm;
+    o[2 * total + t] = ll;
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES>
+// prefetch registers of the A operand + their staging code, one specialisation per input format (keeps the unused
+// format's registers out of the kernel; plain members instead of lambda-captured arrays so they stay in VGPRs)
+template <bool IN_SPLIT, int N> struct AStageRegs;
+
+template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 channels) per task, split at the LDS store
+  float4 r[N];
+  unsigned ok;
+  __device__ __forceinline__ void load(const float* __restrict__ in, const uint16_t*, int64_t, int tid,
+                                       const int32_t* srcs, int cin0, int, int Cin) {
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int kc = (tid + i * 256) & 7;
+      const int32_t src = srcs[i];
+      r[i] = *reinterpret_cast<const float4*>(in + (int64_t)(src < 0 ? 0 : src) * Cin + cin0 + kc * 4);
+      ok |= (src >= 0 ? 1u : 0u) << i;
+    }
+  }
+  __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, kc = idx & 7;
+      float4 v = r[i];
+      const bool k = (ok >> i) & 1u;
+      v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
+      uint2 h, m, l;
+      split3(v, h, m, l);
+      *reinterpret_cast<uint2*>(a0 + row * LDK + kc * 4) = h;
+      *reinterpret_cast<uint2*>(a1 + row * LDK + kc * 4) = m;
+      *reinterpret_cast<uint2*>(a2 + row * LDK + kc * 4) = l;
+    }
+  }
+};
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // first-class vector: stays in VGPRs across the loop
+
+template <int N> struct AStageRegs<true, N> {         // pre-split companion: (row, 8 channels) per task, 3 x 16 B
+  u32x4_t h[N], m[N], l[N];
+  __device__ __forceinline__ void load(const float*, const uint16_t* __restrict__ in_split, int64_t zero_row, int tid,
+                                       const int32_t* srcs, int cin0, int G8, int) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int g = (tid + i * 256) & 3;
+      const int32_t src = srcs[i];
+      const int64_t srow = src < 0 ? zero_row : (int64_t)src;             // missing neighbour -> the all-zero row
+      const u32x4_t* q = reinterpret_cast<const u32x4_t*>(in_split + (srow * G8 + (cin0 >> 3) + g) * 24);
+      h[i] = q[0]; m[i] = q[1]; l[i] = q[2];
+    }
+  }
+  __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 2, g = idx & 3;
+      *reinterpret_cast<u32x4_t*>(a0 + row * LDK + g * 8) = h[i];
+      *reinterpret_cast<u32x4_t*>(a1 + row * LDK + g * 8) = m[i];
+      *reinterpret_cast<u32x4_t*>(a2 + row * LDK + g * 8) = l[i];
+    }
+  }
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT>
 __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-  constexpr int A_ITERS = BM * (BK / 4) / 256;          // float4 gathers per thread
+  // staging tasks per stage: fp32 input = (row, 4 channels) -> 8 per row; pre-split input = (row, 8 channels) -> 4 per row
+  constexpr int ROW_SHIFT = IN_SPLIT ? 2 : 3;
+  constexpr int A_ITERS = (BM << ROW_SHIFT) / 256;
   constexpr int B_CHUNKS = 3 * BN * (BK / 8);           // 16-byte (8 x bf16) chunks over the 3 planes
   constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
   static_assert(WAVES_M * WAVES_N == 4 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
@@ -678,7 +784,7 @@ __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, con
   auto load_src = [&](int k, int32_t* dst) {
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      const int row = (tid + i * 256) >> 3;
+      const int row = (tid + i * 256) >> ROW_SHIFT;
       int32_t v = -1;
       if (row < rows_here && k >= 0) v = p.nbr ? p.nbr[(tile0 + row) * K + k] : (int32_t)(tile0 + row);
       dst[i] = v;
@@ -693,19 +799,16 @@ __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, con
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  float4 ra[A_ITERS];
+  AStageRegs<IN_SPLIT, A_ITERS> areg;
   uint4 rb[B_ITERS];
-  unsigned a_ok = 0, b_ok = 0;
+  unsigned b_ok = 0;
+  const int G8 = Cin >> 3;
+  const float* in_f32 = p.in;
+  const uint16_t* in_sp = p.in_split;
+  const int64_t in_zero = p.in_zero_row;
   auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
-    a_ok = 0; b_ok = 0;
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int idx = tid + i * 256;
-      const int kc = idx & 7;
-      const int32_t src = srcs[i];
-      ra[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)(src < 0 ? 0 : src) * Cin + cin0 + kc * 4);
-      a_ok |= (src >= 0 ? 1u : 0u) << i;
-    }
+    b_ok = 0;
+    areg.load(in_f32, in_sp, in_zero, tid, srcs, cin0, G8, Cin);
     const __bf16* Wk = Wz + (int64_t)k * Cout * Cin;
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
@@ -720,19 +823,7 @@ __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, con
     }
   };
   auto store_stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int idx = tid + i * 256;
-      const int row = idx >> 3, kc = idx & 7;
-      float4 v = ra[i];
-      const bool ok = (a_ok >> i) & 1u;
-      v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
-      bf16x4_t h, m, l;
-      split3(v, h, m, l);
-      *reinterpret_cast<bf16x4_t*>(&As[0][row * LDK + kc * 4]) = h;
-      *reinterpret_cast<bf16x4_t*>(&As[1][row * LDK + kc * 4]) = m;
-      *reinterpret_cast<bf16x4_t*>(&As[2][row * LDK + kc * 4]) = l;
-    }
+    areg.store(tid, &As[0][0], &As[1][0], &As[2][0]);
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       const int idx = tid + i * 256;
@@ -796,6 +887,9 @@ __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, con
     cin0 = ncin;
   }
 
+  if (p.out_split && p.splits <= 1 && blockIdx.x == 0 && blockIdx.y == 0 && zs == 0) {
+    for (int i = tid; i < (Cout >> 3) * 24; i += 256) p.out_split[p.out_zero_row * (Cout >> 3) * 24 + i] = 0;
+  }
   const bool partial = p.splits > 1;
   float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
   const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
@@ -830,7 +924,10 @@ __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, con
           v = v + sh;
           if constexpr (HAS_RES) v = v + res[q];
           v = apply_act(v, act);
-          if (col_ok && row < n_live) dst[(out_base + row) * Cout + col] = v;
+          if (col_ok && row < n_live) {
+            dst[(out_base + row) * Cout + col] = v;
+            if (!partial && p.out_split) store_split(p.out_split, out_base + row, Cout, col, v);
+          }
         }
       }
     }
@@ -840,6 +937,8 @@ __global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, con
 // reduce the split-K slabs in a fixed order and apply the fused epilogue
 __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  if (p.out_split && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < (p.Cout >> 3) * 24; i += 256) p.out_split[p.out_zero_row * (p.Cout >> 3) * 24 + i] = 0;
   const int64_t total = n_live * p.Cout;
   const int64_t slab_stride = p.no_cap * p.Cout;
   for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (int64_t)gridDim.x * blockDim.x * 4) {
@@ -858,6 +957,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
         if (p.shift) x = x + p.shift[col + j];
         if (p.residual) x = x + p.residual[t + j];
         v[j] = apply_act(x, p.act);
+        if (p.out_split) store_split(p.out_split, t / p.Cout, p.Cout, col + j, v[j]);
       }
       *reinterpret_cast<float4*>(p.out + t) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
@@ -890,10 +990,15 @@ int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes
 
 int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float* weight, int Cout, const float* scale,
                 const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
-                int slices, void* workspace, size_t ws_bytes, hipStream_t st, const void* weight_split = nullptr) {
+                int slices, void* workspace, size_t ws_bytes, hipStream_t st, const void* weight_split = nullptr,
+                const void* in_split = nullptr, int64_t in_zero_row = 0, void* out_split = nullptr,
+                int64_t out_zero_row = 0) {
   if (Cin <= 0 || Cout <= 0 || K <= 0 || K > 27 || no_cap <= 0) return CNRMA_EINVAL;
+  if (out_split != nullptr && (Cout % 8 != 0 || weight_split == nullptr)) return CNRMA_EINVAL;
+  if (in_split != nullptr && (Cin % 32 != 0 || weight_split == nullptr)) return CNRMA_EINVAL;
   ConvArgs p{in, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out, no_cap, no_dev, slices, 1, K,
-             reinterpret_cast<float*>(workspace)};
+             reinterpret_cast<float*>(workspace), reinterpret_cast<const uint16_t*>(in_split), in_zero_row,
+             reinterpret_cast<uint16_t*>(out_split), out_zero_row};
   int bm, bn;
   // tile choice: wide tiles for wide layers; 64x64 tiles for short layers (more blocks, less row padding)
   enum { T128x128, T128x64, T64x64, T128x32 } shape;
@@ -920,8 +1025,14 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     const __bf16* wt = reinterpret_cast<const __bf16*>(weight_split);
 #define CNRMA_CONV6_LAUNCH(WM, WN, TM_, TN_)                                                                       \
   do {                                                                                                             \
-    if (has_res) hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true>), grid, dim3(256), 0, st, p, wt);   \
-    else hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false>), grid, dim3(256), 0, st, p, wt);  \
+    if (has_res && in_split)                                                                                       \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, true>), grid, dim3(256), 0, st, p, wt); \
+    else if (has_res)                                                                                              \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false>), grid, dim3(256), 0, st, p, wt); \
+    else if (in_split)                                                                                             \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, true>), grid, dim3(256), 0, st, p, wt); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false>), grid, dim3(256), 0, st, p, wt); \
   } while (0)
     switch (shape) {
       case T128x128: CNRMA_CONV6_LAUNCH(2, 2, 2, 2); break;
@@ -1291,13 +1402,38 @@ extern "C" int cnrma_sparse_conv_prepare_weights(const float* weight, int K, int
   return 0;
 }
 
-extern "C" int cnrma_sparse_conv_bf16x6(const float* in_feats, int Cin, const int32_t* nbr, int K,
-                                        const void* weight_split, int Cout, const float* scale, const float* shift,
-                                        const float* residual, int act, float* out_feats, int64_t no_cap,
-                                        const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream) {
-  if (weight_split == nullptr || Cin % 32 != 0) return CNRMA_EINVAL;
+extern "C" int cnrma_sparse_conv_bf16x6(const float* in_feats, const void* in_split, int64_t in_zero_row, int Cin,
+                                        const int32_t* nbr, int K, const void* weight_split, int Cout,
+                                        const float* scale, const float* shift, const float* residual, int act,
+                                        float* out_feats, void* out_split, int64_t no_cap, const int32_t* no_dev,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (weight_split == nullptr || Cin % 32 != 0 || (in_feats == nullptr && in_split == nullptr)) return CNRMA_EINVAL;
   return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
-                     workspace, workspace_bytes, as_stream(stream), weight_split);
+                     workspace, workspace_bytes, as_stream(stream), weight_split, in_split, in_zero_row, out_split,
+                     no_cap);
+}
+
+extern "C" int cnrma_sparse_split_features(const float* feats, int64_t n_cap, const int32_t* n_dev, int C,
+                                           void* out_split, void* stream) {
+  if (n_cap <= 0 || C <= 0 || C % 8 != 0) return CNRMA_EINVAL;
+  const int64_t work = n_cap * (C / 8);
+  hipLaunchKernelGGL(split_features_kernel, dim3((unsigned)ceil_div(work > C / 8 ? work : C / 8, 256)), dim3(256), 0,
+                     as_stream(stream), feats, n_cap, n_dev, C, reinterpret_cast<uint16_t*>(out_split));
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_convtr_gen_bf16x6(const int32_t* in_coords, const float* in_feats, const void* in_split,
+                                              int64_t n_cap, const int32_t* n_dev, int Cin, int half_stride,
+                                              const void* weight_split, int Cout, const float* scale,
+                                              const float* shift, int act, int32_t* out_coords, float* out_feats,
+                                              void* out_split, void* stream) {
+  if (n_cap <= 0 || half_stride <= 0 || weight_split == nullptr || Cin % 32 != 0) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(convtr_coords_kernel, dim3((unsigned)ceil_div(n_cap * 8, 256)), dim3(256), 0, st, in_coords,
+                     n_cap, n_dev, half_stride, out_coords);
+  return launch_conv(in_feats, Cin, nullptr, 1, nullptr, Cout, scale, shift, nullptr, act, out_feats, n_cap, n_dev, 8,
+                     nullptr, 0, st, weight_split, in_split, n_cap, out_split, 8 * n_cap);
 }
 
 extern "C" int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap,

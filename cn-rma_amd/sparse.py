@@ -125,10 +125,20 @@ class CoordSet:
 class SparseTensor:
     """features F [N,C] fp32 on a CoordSet; mirrors the attributes of ME.SparseTensor the reference touches."""
 
-    def __init__(self, features, coord_set):
+    def __init__(self, features, coord_set, split=None):
         assert features.shape[0] == coord_set.n
         self.F = features
         self.cs = coord_set
+        self._split = split       # bf16 [n+1, C/8, 3, 8] companion (hi/mid/lo pieces), filled by conv epilogues
+
+    def split(self):
+        """pre-split bf16 companion of the features for the bf16x6 convolutions (built on demand, cached)"""
+        if self._split is None:
+            n, C = self.F.shape
+            sp = torch.empty((n + 1, C // 8, 3, 8), dtype=torch.bfloat16, device=self.F.device)
+            call("cnrma_sparse_split_features", ptr(self.F.contiguous()), max(n, 1), None, C, ptr(sp), stream()) if n else sp.zero_()
+            self._split = sp
+        return self._split
 
     @property
     def C(self):
@@ -232,6 +242,7 @@ def _workspace(nbytes, device):
 # "bf16x6": fp32-grade result on the bf16 matrix cores (3-way exact operand split, 6 partial products);
 # "f32":    v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).  Layers with Cin % 32 != 0 always use "f32".
 CONV_PRECISION = "bf16x6"
+PRESPLIT = False     # carry bf16 hi/mid/lo companions of the features between convolutions (see conv())
 
 
 def split_weights(weight):
@@ -270,6 +281,7 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
     else:
         nbr = in_cs.neighbours(out_cs, kernel_size, in_cs.stride)
     out = torch.empty((out_cs.n, Cout), dtype=torch.float32, device=x.device)
+    out_split = None
     if out_cs.n:
         res = residual.F.contiguous() if isinstance(residual, SparseTensor) else residual
         if res is not None:
@@ -277,15 +289,21 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
         ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(out_cs.n, Cout, K)
         ws = _workspace(ws_bytes, x.device) if ws_bytes else None
         if (precision or CONV_PRECISION) == "bf16x6" and Cin % 32 == 0:
-            call("cnrma_sparse_conv_bf16x6", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(split_weights(weight)), Cout,
-                 ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
+            # pre-split companions (PRESPLIT): measured on MI355X at the ScanNet shape they do not pay -- the kernel is
+            # bound by L2->LDS gather traffic, not by the in-loop split (5.6 ms either way) -- so they are off by default
+            in_split = x.split() if (PRESPLIT or x._split is not None) else None
+            if PRESPLIT and Cout % 8 == 0:
+                out_split = torch.empty((out_cs.n + 1, Cout // 8, 3, 8), dtype=torch.bfloat16, device=x.device)
+            call("cnrma_sparse_conv_bf16x6", ptr(x.F.contiguous()), ptr(in_split), x.cs.n, Cin, ptr(nbr), K, ptr(split_weights(weight)),
+                 Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_split), out_cs.n, None, ptr(ws),
+                 ws_bytes, stream())
         else:
             call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
                  ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
-    return SparseTensor(out, out_cs)
+    return SparseTensor(out, out_cs, out_split)
 
 
-def conv_transpose_generative(x, weight, scale=None, shift=None, act=None):
+def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, precision=None):
     """MinkowskiGenerativeConvolutionTranspose(k=2, s=2): 8 children per parent at half the tensor stride;
     out row k*N + i = in[i] @ W[k] (k decodes with x fastest)."""
     _lib.require_gpu()
@@ -296,10 +314,19 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None):
     half = x.cs.stride // 2
     out_c = torch.empty((8 * n, 4), dtype=torch.int32, device=x.device)
     out_f = torch.empty((8 * n, Cout), dtype=torch.float32, device=x.device)
+    out_split = None
     if n:
-        call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, Cin, half, ptr(w), Cout, ptr(scale),
-             ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
-    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch))
+        if (precision or CONV_PRECISION) == "bf16x6" and Cin % 32 == 0:
+            if PRESPLIT and Cout % 8 == 0:
+                out_split = torch.empty((8 * n + 1, Cout // 8, 3, 8), dtype=torch.bfloat16, device=x.device)
+            in_split = x.split() if (PRESPLIT or x._split is not None) else None
+            call("cnrma_sparse_convtr_gen_bf16x6", ptr(x.C), ptr(x.F.contiguous()), ptr(in_split), n, None, Cin, half,
+                 ptr(split_weights(weight)), Cout, ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f),
+                 ptr(out_split), stream())
+        else:
+            call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, Cin, half, ptr(w), Cout,
+                 ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
+    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch), out_split)
 
 
 def max_pool(x, kernel_size=2, stride=2):

@@ -228,10 +228,23 @@ int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, in
  * cnrma_sparse_conv_prepare_weights: weight fp32 [K][Cin][Cout] -> weight_split bf16 [3][K][Cout][Cin]
  * (6*K*Cin*Cout bytes), done once per layer.  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
 int cnrma_sparse_conv_prepare_weights(const float* weight, int K, int Cin, int Cout, void* weight_split, void* stream);
-int cnrma_sparse_conv_bf16x6(const float* in_feats, int Cin, const int32_t* nbr, int K, const void* weight_split,
-                             int Cout, const float* scale, const float* shift, const float* residual, int act,
-                             float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
-                             size_t workspace_bytes, void* stream);
+/* Pre-split feature companions: a feature matrix [N][C] (C % 8 == 0) can carry its bf16 split
+ * [N+1][C/8][3 planes][8] (48 bytes per 8 channels; row N is all zeros and stands in for missing neighbours).
+ * cnrma_sparse_split_features builds one; the bf16x6 convolutions read it (in_split, may be NULL: then the fp32
+ * features are split while they are staged) and write the companion of their OUTPUT in the epilogue (out_split, may be
+ * NULL; [no_cap+1] rows), so chains of convolutions never re-split and the gathers carry no VALU work. */
+int cnrma_sparse_split_features(const float* feats, int64_t n_cap, const int32_t* n_dev, int C, void* out_split,
+                                void* stream);
+int cnrma_sparse_conv_bf16x6(const float* in_feats, const void* in_split, int64_t in_zero_row, int Cin,
+                             const int32_t* nbr, int K, const void* weight_split, int Cout, const float* scale,
+                             const float* shift, const float* residual, int act, float* out_feats, void* out_split,
+                             int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes,
+                             void* stream);
+/* generative transpose (k2 s2) on the same path: weight_split from prepare_weights(K = 8); out_split has 8*n_cap+1 rows */
+int cnrma_sparse_convtr_gen_bf16x6(const int32_t* in_coords, const float* in_feats, const void* in_split, int64_t n_cap,
+                                   const int32_t* n_dev, int Cin, int half_stride, const void* weight_split, int Cout,
+                                   const float* scale, const float* shift, int act, int32_t* out_coords,
+                                   float* out_feats, void* out_split, void* stream);
 
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */

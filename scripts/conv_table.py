@@ -18,7 +18,7 @@ tot = 0
 for name, a, e0, e1 in prof.records:
     ms = e0.elapsed_time(e1)
     if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
-        rows, cin, cout, K = a[11], a[1], a[5], a[3]
+        rows, cin, cout, K = (a[11], a[1], a[5], a[3]) if name == "cnrma_sparse_conv_f32" else (a[14], a[3], a[7], a[5])
         fl = 2.0 * K * cin * cout * rows
         tot += ms
         print(f"conv rows={rows:7d} Cin={cin:4d} Cout={cout:4d} K={K:2d} {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s")

@@ -98,6 +98,39 @@ def test_conv_vs_oracle(device, cin, cout, k, stride, ts, precision):
     assert out.cs.stride == ts * stride
 
 
+def test_presplit_companions_give_identical_results(device):
+    """bf16x6 with pre-split feature companions (read + written by the conv epilogue) == bf16x6 splitting in the loop"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(11)
+    c, f = rand_sparse(rng, n=5000, span=10, C=64)
+    W1 = (rng.randn(27, 64, 128) / 40).astype(np.float32)
+    W2 = (rng.randn(27, 128, 64) / 60).astype(np.float32)
+    Wt = (rng.randn(8, 64, 32) / 20).astype(np.float32)
+    outs = []
+    for flag in (False, True):
+        S.PRESPLIT = flag
+        try:
+            x = to_st(c, f, 2, device)
+            y = S.conv(x, torch.from_numpy(W1).to(device), 3, 1, act="relu")
+            z = S.conv(y, torch.from_numpy(W2).to(device), 3, 1)
+            u = S.conv_transpose_generative(z, torch.from_numpy(Wt).to(device), act="elu")
+            assert (y._split is not None) == flag and (u._split is not None) == flag
+            outs.append((y.F.clone(), z.F.clone(), u.F.clone()))
+        finally:
+            S.PRESPLIT = False
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)            # the truncation split is exact and deterministic: bit-identical paths
+    # the companion written by the epilogue reconstructs the fp32 features exactly: h + m + l == x
+    S.PRESPLIT = True
+    try:
+        y = S.conv(to_st(c, f, 2, device), torch.from_numpy(W1).to(device), 3, 1, act="relu")
+    finally:
+        S.PRESPLIT = False
+    sp = y._split[:-1].float()                       # [n, C/8, 3, 8]
+    rec = (sp[:, :, 0] + sp[:, :, 1] + sp[:, :, 2]).reshape(y.F.shape)
+    assert torch.equal(rec, y.F) and float(y._split[-1].float().abs().max()) == 0.0
+
+
 def test_bf16x6_is_fp32_grade_on_wide_dynamic_range(device):
     """the 3-way bf16 split must hold fp32 accuracy for operands spanning many binades (bf16 keeps fp32's exponent)"""
     from cnrma_amd import sparse as S
