@@ -101,7 +101,12 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
   constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   const int lane = threadIdx.x & 63;
-  const int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  // XCD-aware block -> voxel-chunk map: blocks are dealt round-robin over the 8 XCDs, so block b works on chunk
+  // (b % 8) * ceil(nb / 8) + b / 8 -- every XCD owns one contiguous x-slab of the grid and its private L2 only has to
+  // hold the image band that slab projects to (speed only: any placement is correct)
+  const int64_t nb = gridDim.x, per = (nb + 7) / 8;
+  const int64_t chunk = ((int64_t)blockIdx.x % 8) * per + (int64_t)blockIdx.x / 8;
+  const int64_t wave_base = (chunk * blockDim.x + threadIdx.x) - lane;
   if (wave_base >= G) return;
   const int64_t g = wave_base + lane;
   const int c0 = blockIdx.y * (4 * LPV);
@@ -154,7 +159,7 @@ template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
                       hipStream_t st) {
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  dim3 grid((unsigned)ceil_div(G, 256), (unsigned)ceil_div(p.C, 4 * LPV));
+  dim3 grid((unsigned)(ceil_div(ceil_div(G, 256), 8) * 8), (unsigned)ceil_div(p.C, 4 * LPV));   // multiple of 8 (XCD map)
   hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count);
   CNRMA_LAUNCH_CHECK();
   return 0;

@@ -978,8 +978,8 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
 int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes) {
   if (K <= 1) return 1;
   const int64_t tiles = ceil_div(rows, bm) * ceil_div(Cout, bn);
-  if (tiles >= 512) return 1;
-  int s = (int)ceil_div(1024, tiles);
+  if (tiles >= 384) return 1;
+  int s = (int)ceil_div(768, tiles);
   if (s > K) s = K;
   const size_t per = (size_t)rows * Cout * sizeof(float);
   if (per == 0) return 1;
@@ -1100,6 +1100,24 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ no_dev) {
   const int64_t n = live_rows(no_cap, no_dev);
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((C & 3) == 0) {                                   // 4 channels per lane: C/4 lanes share one row's neighbour list
+    const int c4 = C >> 2;
+    if (t >= n * c4) return;
+    const int64_t o = t / c4;
+    const int c = (int)(t - o * c4);
+    float4 m = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+      const int32_t s = nbr[o * K + k];
+      if (s >= 0) {
+        const float4 v = reinterpret_cast<const float4*>(in)[(int64_t)s * c4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        any = true;
+      }
+    }
+    reinterpret_cast<float4*>(out)[t] = any ? m : make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   if (t >= n * C) return;
   const int64_t o = t / C;
   const int c = (int)(t - o * C);
@@ -1458,14 +1476,14 @@ extern "C" int cnrma_sparse_maxpool_f32(const float* in_feats, int C, const int3
   return 0;
 }
 
-extern "C" size_t cnrma_instnorm_workspace_bytes(int C) { return (size_t)(256 * 2 * C + 2 * C) * sizeof(double); }
+extern "C" size_t cnrma_instnorm_workspace_bytes(int C) { return (size_t)(1024 * 2 * C + 2 * C) * sizeof(double); }
 
 extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, int C,
                                          const float* weight, const float* bias, float eps, int relu,
                                          float* out_feats, double* stats_ws, void* stream) {
   if (n_cap <= 0 || C <= 0 || C > 256) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  const int nblk = 256;
+  const int nblk = 1024;
   double* part = stats_ws + 2 * C;
   hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, in_feats, n_cap, n_dev, C, part);
   hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, st, part, nblk, C, n_cap,
