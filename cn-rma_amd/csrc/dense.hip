@@ -101,12 +101,11 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
   constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   const int lane = threadIdx.x & 63;
-  // XCD-aware block -> voxel-chunk map: blocks are dealt round-robin over the 8 XCDs, so block b works on chunk
-  // (b % 8) * ceil(nb / 8) + b / 8 -- every XCD owns one contiguous x-slab of the grid and its private L2 only has to
-  // hold the image band that slab projects to (speed only: any placement is correct)
-  const int64_t nb = gridDim.x, per = (nb + 7) / 8;
-  const int64_t chunk = ((int64_t)blockIdx.x % 8) * per + (int64_t)blockIdx.x / 8;
-  const int64_t wave_base = (chunk * blockDim.x + threadIdx.x) - lane;
+  // NOTE (measured): giving every XCD one contiguous x-slab of the grid (chunk = (b % 8) * nb/8 + b / 8) cuts the
+  // HBM fetch (each private L2 then holds only its image band) but runs 17 % SLOWER: the frustum makes slabs unequal
+  // and the static map cannot rebalance.  The round-robin interleave below keeps the XCDs evenly loaded; the kernel
+  // is bound by the L1 gather path, not by HBM.
+  const int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
   if (wave_base >= G) return;
   const int64_t g = wave_base + lane;
   const int c0 = blockIdx.y * (4 * LPV);
@@ -159,7 +158,7 @@ template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
                       hipStream_t st) {
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  dim3 grid((unsigned)(ceil_div(ceil_div(G, 256), 8) * 8), (unsigned)ceil_div(p.C, 4 * LPV));   // multiple of 8 (XCD map)
+  dim3 grid((unsigned)ceil_div(G, 256), (unsigned)ceil_div(p.C, 4 * LPV));
   hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count);
   CNRMA_LAUNCH_CHECK();
   return 0;
