@@ -60,6 +60,8 @@ SIGNATURES = {
     "cnrma_fcaf3d_head_post_f32": (c_int, [P, I, P, L, I, I, P, F, P, P, P, P, P, P]),
     "cnrma_fcaf3d_max_score_f32": (c_int, [P, P, L, I, P, P]),
     "cnrma_fcaf3d_select_decode_f32": (c_int, [P, L, P, P, P, P, I, I, I, P, P, P]),
+    "cnrma_nms_mask_f32": (c_int, [P, I, F, I, P, P]),
+    "cnrma_box_iou_f32": (c_int, [P, I, P, I, I, I, P, P]),
     "cnrma_fcaf3d_scores_f32": (c_int, [P, P, L, I, P, P, P]),
 }
 

@@ -314,6 +314,17 @@ int cnrma_fcaf3d_select_decode_f32(const int64_t* ids, int64_t k, const float* c
 int cnrma_fcaf3d_scores_f32(const float* cls, const float* centerness, int64_t n, int n_cls, float* scores,
                             float* max_score, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * "next" row 1: offline 3D NMS   replaces mmdet3d's pcdet_nms_gpu / pcdet_nms_normal_gpu as called by
+ * post_process/nms_bbox.py:17-58 (third-party OpenPCDet iou3d_nms semantics: bird's-eye-view IoU, greedy in score order).
+ * boxes_sorted [n][7] = (x, y, z, dx, dy, dz, heading), already in descending score order; rotated = 0 ignores heading.
+ * mask [n][ceil(n/64)] uint64: bit j of row i set when j > i and IoU(i, j) > iou_thr (the host does the greedy scan).
+ * cnrma_box_iou_f32: pairwise IoU matrix [na][nb]; mode3d = 1 multiplies the BEV overlap by the height overlap
+ * (the IoU used by the mAP evaluation of post_process/evaluate_bbox.py through mmdet3d's indoor_eval).
+ * ---------------------------------------------------------------------------------------------------------- */
+int cnrma_nms_mask_f32(const float* boxes_sorted, int n, float iou_thr, int rotated, uint64_t* mask, void* stream);
+int cnrma_box_iou_f32(const float* a, int na, const float* b, int nb, int rotated, int mode3d, float* iou, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
