@@ -146,6 +146,15 @@ __device__ __forceinline__ uint32_t row_hash(uint32_t seed, uint32_t i) {
   return x;
 }
 
+// selection key of row i: a hash (random subset) or the order-preserving image of a float score, inverted so that the
+// LARGEST scores get the SMALLEST keys (top-k selection); ties are broken by index in both cases
+__device__ __forceinline__ uint32_t select_key(const float* __restrict__ scores, uint32_t seed, uint32_t i) {
+  if (scores == nullptr) return row_hash(seed, i);
+  const uint32_t u = __float_as_uint(scores[i]);
+  const uint32_t ordered = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending in the float order
+  return ~ordered;
+}
+
 struct SampleWs {          // sampler workspace (int32 words)
   int32_t hist[3][2048];   // digit histograms: bits 31..21, 20..10, 9..0 of the key (within the selected prefix)
   int32_t prefix[3];       // selected digit per pass
@@ -164,14 +173,14 @@ __device__ __forceinline__ bool key_matches(uint32_t k, int pass, const int32_t*
 }
 
 // block-private LDS histogram of one digit, flushed with (contiguous) global atomics
-__global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restrict__ m_dev, uint32_t seed, int pass,
-                                                          SampleWs* __restrict__ ws) {
+__global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
+                                                          uint32_t seed, int pass, SampleWs* __restrict__ ws) {
   __shared__ int h[2048];
   for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
   __syncthreads();
   const int64_t M = m_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t k = row_hash(seed, (uint32_t)i);
+    const uint32_t k = select_key(scores, seed, (uint32_t)i);
     if (key_matches(k, pass, ws->prefix)) atomicAdd(&h[key_digit(k, pass)], 1);
   }
   __syncthreads();
@@ -191,20 +200,20 @@ __global__ __launch_bounds__(1024) void sample_find_kernel(SampleWs* __restrict_
   if (threadIdx.x == 0 && pass == 0) ws->need[0] = n_keep;
 }
 
-__global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
-                                                          SampleWs* __restrict__ ws) {
+__global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
+                                                          uint32_t seed, SampleWs* __restrict__ ws) {
   const int64_t M = m_dev[0];
   const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    if (row_hash(seed, (uint32_t)i) == key) {
+    if (select_key(scores, seed, (uint32_t)i) == key) {
       const int slot = atomicAdd(&ws->tie_count, 1);
       if (slot < 256) ws->tie_idx[slot] = (int32_t)i;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, uint32_t seed,
-                                                          const SampleWs* __restrict__ ws, int n_keep,
+__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
+                                                          uint32_t seed, const SampleWs* __restrict__ ws, int n_keep,
                                                           uint8_t* __restrict__ mask) {
   const int64_t M = m_dev[0];
   __shared__ int32_t tie_bound;     // rows with the threshold key are kept when their index <= tie_bound
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
   const bool all = M <= n_keep;
   const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t k = row_hash(seed, (uint32_t)i);
+    const uint32_t k = select_key(scores, seed, (uint32_t)i);
     mask[i] = (all || k < key || (k == key && (int32_t)i <= tie_bound)) ? 1 : 0;
   }
 }
@@ -232,24 +241,36 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
 
 extern "C" size_t cnrma_sample_workspace_bytes(void) { return sizeof(SampleWs); }
 
-// mask[0..M) (M = m_dev[0] <= m_cap, read on the device): exactly min(M, n_keep) ones, uniformly random subset
-extern "C" int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask,
-                                 void* workspace, void* stream) {
+static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, int n_keep, uint32_t seed,
+                      uint8_t* mask, void* workspace, hipStream_t st) {
   if (m_cap <= 0 || n_keep <= 0 || m_cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
-  hipStream_t st = as_stream(stream);
   SampleWs* ws = reinterpret_cast<SampleWs*>(workspace);
   hipError_t e = hipMemsetAsync(ws, 0, sizeof(SampleWs), st);
   if (e != hipSuccess) return -(int)e;
   int blocks = (int)(m_cap / 2048 + 1);
   if (blocks > 1024) blocks = 1024;
   for (int pass = 0; pass < 3; ++pass) {
-    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, pass, ws);
+    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, ws);
     hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws, pass, n_keep);
   }
-  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws);
-  hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, seed, ws, n_keep, mask);
+  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws);
+  hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws, n_keep, mask);
   CNRMA_LAUNCH_CHECK();
   return 0;
+}
+
+// mask[0..M) (M = m_dev[0] <= m_cap, read on the device): exactly min(M, n_keep) ones, uniformly random subset
+extern "C" int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask,
+                                 void* workspace, void* stream) {
+  return run_select(m_dev, nullptr, m_cap, n_keep, seed, mask, workspace, as_stream(stream));
+}
+
+// mask[0..n): ones at the min(n, k) rows with the LARGEST scores (ties by smaller index) -- the keep-set of
+// torch.topk(scores, k) without the sort; n = n_dev[0] read on the device
+extern "C" int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, uint8_t* mask,
+                                   void* workspace, void* stream) {
+  if (scores == nullptr) return CNRMA_EINVAL;
+  return run_select(n_dev, scores, n_cap, k, 0u, mask, workspace, as_stream(stream));
 }
 
 extern "C" size_t cnrma_scan_workspace_bytes(int64_t n) {

@@ -449,6 +449,22 @@ def select_decode(ids, cls_score, centerness, bbox_pred, points, yaw_parametriza
     return boxes, scores
 
 
+def topk_mask(scores, k):
+    """uint8 keep-mask of the k largest scores (ties -> smaller index): row set of torch.topk(scores, k), no sort"""
+    _lib.require_gpu()
+    scores = scores.contiguous().view(-1).float()
+    n = scores.numel()
+    mask = torch.empty(n, dtype=torch.uint8, device=scores.device)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=scores.device) if n not in _NDEV else _NDEV[n]
+    _NDEV[n] = n_dev
+    ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=scores.device)
+    call("cnrma_topk_mask_f32", ptr(scores), ptr(n_dev), n, int(k), ptr(mask), ptr(ws), stream())
+    return mask
+
+
+_NDEV = {}
+
+
 def row_max(feats):
     n, C = feats.shape
     out = torch.empty((n, 1), dtype=torch.float32, device=feats.device)

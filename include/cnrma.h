@@ -116,6 +116,11 @@ int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, 
 size_t cnrma_sample_workspace_bytes(void);
 int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask, void* workspace,
                       void* stream);
+/* keep-mask of the k largest scores (ties -> smaller index): the row set of torch.topk(scores, k) as used by the
+ * pts_threshold pruning (fcaf3d_head.py:131-137) and nms_pre (:252-256), by 3-pass radix select instead of a sort.
+ * n = n_dev[0] (device); workspace: cnrma_sample_workspace_bytes(). */
+int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, uint8_t* mask,
+                        void* workspace, void* stream);
 
 /* a6  depth variant   replaces ray_projection_depth()  ray_marching.py:809-956
  * Every ray emits exactly NUM = max(1, 2*select_grids) candidate slots; count[ray] = number of slots with

@@ -119,11 +119,15 @@ class FCAF3DHead(nn.Module):
             if all(len(p) <= self.pts_threshold for p in perms):
                 return x                                # the top-k keeps every row: pruning is the identity
             interpolated = scores.features_at_coordinates(x.C.float())
-            mask = torch.zeros(len(interpolated), dtype=torch.bool, device=x.device)
-            for p in perms:
-                k = min(len(p), self.pts_threshold)
-                ids = torch.topk(interpolated[p].squeeze(1), k, sorted=False).indices
-                mask[p[ids]] = True
+            if len(perms) == 1:
+                # single scene: radix-select keep-mask instead of torch.topk's sort (same row set; ties by index)
+                mask = S.topk_mask(interpolated, self.pts_threshold)
+            else:
+                mask = torch.zeros(len(interpolated), dtype=torch.bool, device=x.device)
+                for p in perms:
+                    k = min(len(p), self.pts_threshold)
+                    ids = torch.topk(interpolated[p].squeeze(1), k, sorted=False).indices
+                    mask[p[ids]] = True
         return self.pruning(x, mask)
 
     def _head_weights(self):

@@ -271,6 +271,24 @@ def test_fused_head_post_and_select_decode(device):
         assert torch.allclose(S.max_scores(c2, ct), (torch.sigmoid(c2) * torch.sigmoid(ct)).max(dim=1)[0], atol=1e-6)
 
 
+def test_topk_mask_matches_torch_topk(device):
+    from cnrma_amd import sparse as S
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(270_336, generator=g).to(device)
+    x[::7] = x[3]                                           # many exact ties
+    x[5] = float("-inf"); x[6] = 0.0; x[8] = -0.0
+    for k in (1, 1000, 200_000, 270_335, 270_336, 300_000):
+        m = S.topk_mask(x, k).bool()
+        assert int(m.sum()) == min(k, x.numel())
+        if k < x.numel():
+            kth = torch.topk(x, k).values[-1]
+            assert bool((x[m] >= kth).all()) and bool((x[~m] <= kth).all())
+            # ties on the threshold value are resolved towards the smaller index
+            tie = torch.nonzero(x == kth).squeeze(1)
+            kept = m[tie]
+            assert bool((kept[:-1] >= kept[1:]).all()) if len(tie) > 1 else True
+
+
 def _randomise(module, seed):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
