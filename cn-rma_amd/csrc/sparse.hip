@@ -222,8 +222,10 @@ int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, i
     hipLaunchKernelGGL((uniq_sortkey_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
                        batch_id, w.flag, w.key_a, w.val_a);
     size_t tmp = w.sort_tmp_bytes;
+    // batch id sits in bits 48..63 and dead rows carry the all-ones key: for batch 0 bits [0, 49) order everything
+    const int end_bit = batch_id == 0 ? 49 : 64;
     hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, tmp, w.key_a, w.key_b, w.val_a, w.val_b, (int)n_cap,
-                                                       0, 64, st);
+                                                       0, end_bit, st);
     if (e2 != hipSuccess) return -(int)e2;
     hipLaunchKernelGGL((uniq_write_sorted_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, vs, new_stride,
                        batch_id, w.val_b, n_out, w.slot, vals, out_coords, out_src);
@@ -1159,18 +1161,27 @@ __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __re
   }
 }
 
-__global__ void colstats_final_kernel(const double* __restrict__ part, int nblk, int C, int64_t n_cap,
-                                      const int32_t* __restrict__ n_dev, double* __restrict__ stats) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one block per channel: 256 lanes add the per-block partials in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void colstats_final_kernel(const double* __restrict__ part, int nblk, int C, int64_t n_cap,
+                                                             const int32_t* __restrict__ n_dev, double* __restrict__ stats) {
+  const int c = blockIdx.x;
+  __shared__ double ss[256], qq[256];
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 2 * C + c]; q += part[(int64_t)b * 2 * C + C + c]; }
-  const double n = (double)live_rows(n_cap, n_dev);
-  const double mean = s / n;
-  double var = q / n - mean * mean;   // biased variance
-  if (var < 0.0) var = 0.0;
-  stats[c] = mean;
-  stats[C + c] = var;
+  for (int b = threadIdx.x; b < nblk; b += 256) { s += part[(int64_t)b * 2 * C + c]; q += part[(int64_t)b * 2 * C + C + c]; }
+  ss[threadIdx.x] = s; qq[threadIdx.x] = q;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) { ss[threadIdx.x] += ss[threadIdx.x + d]; qq[threadIdx.x] += qq[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n = (double)live_rows(n_cap, n_dev);
+    const double mean = ss[0] / n;
+    double var = qq[0] / n - mean * mean;   // biased variance
+    if (var < 0.0) var = 0.0;
+    stats[c] = mean;
+    stats[C + c] = var;
+  }
 }
 
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ in, int64_t n_cap,
@@ -1486,8 +1497,7 @@ extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, c
   const int nblk = 1024;
   double* part = stats_ws + 2 * C;
   hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, in_feats, n_cap, n_dev, C, part);
-  hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, st, part, nblk, C, n_cap,
-                     n_dev, stats_ws);
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n_cap, n_dev, stats_ws);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, st, in_feats, n_cap,
                      n_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
   CNRMA_LAUNCH_CHECK();
