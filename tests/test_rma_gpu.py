@@ -211,3 +211,49 @@ def test_dense_vs_oracle_at_scannet_shape(device):
     v2, c2 = rma.backproject_accum(rma.to_nhwc(feat.to(device)), proj, sc["dims"], 0.04, sc["origin"], sc["stride"])
     assert torch.equal(c2.cpu().to(torch.int64), cnt)
     assert count_mismatch(v2, vol) == 0
+
+
+def test_baseline_config0_plumbing_vs_oracle(device):
+    """BASELINE.json configs[0]: 4 views, 64 ch, 128x128 maps (stride 1) -> 64^3 grid, the reference's CPU-runnable case:
+    dense volume bit-exact, aggregated points (places bit-exact, features 1e-4), selection + voxelisation identical."""
+    from cnrma_amd import rma, synth
+    from cnrma_amd import sparse as S
+    from oracle import rma_oracle as O
+    sc = synth.make_scene("P", seed=0)
+    proj, feat, tsdf = sc["projection"][:, 0], sc["features"][:, 0], sc["tsdf"][0, 0]
+    vol, cnt = O.backproject_accum(sc["dims"], 0.04, sc["origin"], proj, feat, sc["stride"])
+    pts = O.aggregate_rma(proj, feat, tsdf, sc["dims"], 0.04, sc["origin"], sc["stride"])
+    nhwc = rma.to_nhwc(feat.to(device))
+    v2, c2 = rma.backproject_accum(nhwc, proj, sc["dims"], 0.04, sc["origin"], sc["stride"])
+    assert torch.equal(c2.cpu().long(), cnt) and count_mismatch(v2, vol) == 0
+    pinv = rma.projection_inverse(proj, sc["stride"]).to(device)
+    got, info = rma.aggregate_rows(nhwc, pinv, tsdf.to(device), sc["dims"], 0.04, sc["origin"])
+    assert info["M"] == pts.shape[0]
+    assert count_mismatch(got[:, :3], pts[:, :3]) == 0
+    np.testing.assert_allclose(got[:, 3:].cpu().numpy(), pts[:, 3:].numpy(), rtol=TOL, atol=TOL)
+    np.random.seed(11)
+    mask = O.sample_mask_numpy(pts.shape[0], 100000)
+    c, f, _ = rma.aggregate_points(nhwc, pinv, tsdf.to(device), sc["dims"], 0.04, sc["origin"], offset=(0.1, -0.2, 0.3), mask=mask)
+    co, fo = O.select_rows(pts, (0.1, -0.2, 0.3), mask)
+    assert count_mismatch(c, co) == 0
+    st, src = S.voxelize(c, f, 0.01, row_order="first")
+    Cq, Fq, first = O.voxelize(co, fo, 0.01)
+    assert torch.equal(st.C.cpu(), Cq) and torch.equal(src.cpu().long(), first)
+
+
+def test_scannet_test_grid_256_vs_oracle(device):
+    """ray_marching_scannet.py test shape (grid 256x256x96): indexing at the largest configured grid, 2 views"""
+    from cnrma_amd import rma, synth
+    from oracle import rma_oracle as O
+    sc = synth.make_scene("St", seed=2, boxes=3, V=2)
+    proj, feat, tsdf = sc["projection"][:, 0], sc["features"][:, 0], sc["tsdf"][0, 0]
+    vol, cnt = O.backproject_accum(sc["dims"], 0.04, sc["origin"], proj, feat, sc["stride"])
+    raw = O.aggregate_rma(proj, feat, tsdf, sc["dims"], 0.04, sc["origin"], sc["stride"], return_raw=True)[1]
+    nhwc = rma.to_nhwc(feat.to(device))
+    v2, c2 = rma.backproject_accum(nhwc, proj, sc["dims"], 0.04, sc["origin"], sc["stride"])
+    assert torch.equal(c2.cpu().long(), cnt) and count_mismatch(v2, vol) == 0
+    pinv = rma.projection_inverse(proj, sc["stride"]).to(device)
+    rows, per_view = rma.rma_view_rows(nhwc, pinv, tsdf.to(device), sc["dims"], 0.04, sc["origin"], 300, 0.05)
+    assert rows.shape[0] == raw.shape[0]
+    assert count_mismatch(rows[:, :3], raw[:, :3]) == 0 and count_mismatch(rows[:, 4:], raw[:, 4:]) == 0
+    np.testing.assert_allclose(rows[:, 3].cpu().numpy(), raw[:, 3].numpy(), rtol=1e-6)
