@@ -161,6 +161,23 @@ def run_decode(head_mod):
     print("decode.npz written")
 
 
+def run_point_transforms(tr):
+    """a8 train path: the point helpers of fcaf3d_transforms.py:152-200 on seeded points"""
+    g = torch.Generator().manual_seed(9)
+    pts = torch.randn(64, 11, generator=g)
+    out = dict(points=pts.numpy())
+    out["rot"] = tr.rotate_points(pts.clone(), 0.0731).numpy()
+    out["flip_h"] = tr.flip_points(pts.clone(), "horizontal").numpy()
+    out["flip_v"] = tr.flip_points(pts.clone(), "vertical").numpy()
+    out["scale"] = tr.scale_points(pts.clone(), 1.0625).numpy()
+    out["trans"] = tr.translate_points(pts.clone(), np.array([0.1, -0.05, 0.2], dtype=np.float32)).numpy()
+    np.random.seed(21)
+    mask = tr.sample_points(torch.zeros(1000, 3), max_points=123)
+    out["sample_mask_seed21"] = mask.numpy()
+    np.savez_compressed(os.path.join(HERE, "point_transforms.npz"), **out)
+    print("point_transforms.npz written")
+
+
 def main():
     torch.set_num_threads(8)
     rm, head, tr, ts = R.load_reference()
@@ -174,6 +191,7 @@ def main():
     P[0, 0, :, :3] = -P[0, 0, :, :3]            # mirror the camera through its centre: every ray leaves the grid
     run_scene(rm, tr, "edge_empty_view", sc)
     run_decode(head)
+    run_point_transforms(tr)
 
 
 if __name__ == "__main__":

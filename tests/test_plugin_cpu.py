@@ -71,6 +71,19 @@ def test_sample_points_uses_numpy_global_rng_like_reference():
     assert bool(sample_points(pts, max_points=5000).all())
 
 
+def test_point_transform_helpers_match_reference_golden():
+    from projects.mvsdetection.datasets.pipelines import fcaf3d_transforms as T
+    z = np.load(os.path.join(ROOT, "tests", "golden", "point_transforms.npz"))
+    pts = torch.from_numpy(z["points"])
+    assert torch.equal(T.rotate_points(pts.clone(), 0.0731), torch.from_numpy(z["rot"]))
+    assert torch.equal(T.flip_points(pts.clone(), "horizontal"), torch.from_numpy(z["flip_h"]))
+    assert torch.equal(T.flip_points(pts.clone(), "vertical"), torch.from_numpy(z["flip_v"]))
+    assert torch.equal(T.scale_points(pts.clone(), 1.0625), torch.from_numpy(z["scale"]))
+    assert torch.equal(T.translate_points(pts.clone(), np.array([0.1, -0.05, 0.2], dtype=np.float32)), torch.from_numpy(z["trans"]))
+    np.random.seed(21)
+    assert (T.sample_points(torch.zeros(1000, 3), max_points=123).numpy() == z["sample_mask_seed21"]).all()
+
+
 def test_coordinates_order():
     from projects.mvsdetection.datasets.tsdf import coordinates
     c = coordinates((2, 3, 4))
