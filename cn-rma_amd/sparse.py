@@ -231,11 +231,13 @@ _WS = {}
 
 
 def _workspace(nbytes, device):
-    """grow-only scratch buffer per device (stream-ordered reuse: every user is enqueued on the same stream)"""
-    buf = _WS.get(device)
+    """grow-only scratch buffer per (device, stream): reuse is stream-ordered, so concurrent streams (several scenes in
+    flight on one GPU) must not share it"""
+    key = (device, stream())
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 

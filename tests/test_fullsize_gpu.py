@@ -107,3 +107,41 @@ def test_conv_is_linear_at_full_size(scene, device):
     fz = S.conv(S.SparseTensor(2.0 * x - 0.5 * y, cs), W, 3, 1).F
     assert torch.allclose(fz, 2.0 * fx - 0.5 * fy, rtol=1e-4, atol=1e-4)
     assert torch.equal(S.conv(S.SparseTensor(x, cs), W, 3, 1).F, fx)                              # deterministic
+
+
+def test_concurrent_scenes_on_separate_streams_match_sequential(scene, device):
+    """bench.py keeps several scenes in flight (one host thread + HIP stream each): the results must be those of the
+    sequential run (per-stream workspaces, shared read-only caches)."""
+    import threading
+    import bench
+    from cnrma_amd import pipeline, rma
+    s = scene
+    backbone, head = bench.build_model(32, device)
+    cfg = pipeline.SceneConfig(s["sc"]["dims"], stride=4, max_points=500_000, sampler="device")
+    feat = s["sc"]["features"][:, 0].to(device)
+    full, info = rma.aggregate_rows(s["nhwc"], s["pinv"], s["tsdf"], s["sc"]["dims"], 0.04, s["sc"]["origin"])
+    mask = rma.sample_mask_device(torch.tensor([info["M"]], dtype=torch.int32, device=device), info["M"], 500_000, seed=9)
+    ref = pipeline.forward_scene(cfg, backbone, head, feat, s["proj"], s["tsdf"], mask=mask)
+    torch.cuda.synchronize()
+    n_threads, per_thread = 3, 2
+    outs, errs = [[] for _ in range(n_threads)], []
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_threads)]
+
+    def worker(w):
+        try:
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(streams[w]):
+                for _ in range(per_thread):
+                    o = pipeline.forward_scene(cfg, backbone, head, feat, s["proj"], s["tsdf"], mask=mask)
+                    outs[w].append((o["bboxes"].clone(), o["scores"].clone()))
+                streams[w].synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(n_threads)]
+    [t.start() for t in ts]
+    [t.join(timeout=120) for t in ts]
+    assert not errs, errs
+    for w in range(n_threads):
+        assert len(outs[w]) == per_thread
+        for b, sc in outs[w]:
+            assert torch.equal(b, ref["bboxes"]) and torch.equal(sc, ref["scores"])
