@@ -25,6 +25,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (= vector peak)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+# HBM-side traffic of the dominant kernel from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
+# this same command at workload S: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md
+# "HBM") + WRITE_SIZE, KB -> bytes), all sparse_conv_bf16x6 launches of one scene / launches per scene
+PMC_CONV_TRAFFIC_S = dict(bytes_per_launch=(2 * 4805.0e6 * 1.024 + 1140.0e6 * 1.024) / 47.0,
+                          source="profiles/r01_final_pmc_FETCH_SIZE.csv + r01_final_pmc_WRITE_SIZE.csv")
 
 
 def parse():
@@ -55,6 +60,7 @@ def build_model(C, device, n_classes=18, n_reg=6):
 class KernelProfile:
     """per C-ABI call HIP-event timing on the launch stream (each timed entry point is exactly one kernel)"""
     TIMED = ("cnrma_backproject_accum_f32", "cnrma_rma_neus_count_f32", "cnrma_rma_neus_emit_f32",
+             "cnrma_rma_neus_march_f32", "cnrma_sparse_kernel_map_symmetric", "cnrma_sparse_kernel_map_strided",
              "cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_convtr_gen_f32", "cnrma_nchw_to_nhwc_f32",
              "cnrma_sparse_kernel_map", "cnrma_sparse_maxpool_f32")
 
@@ -266,7 +272,9 @@ def main():
             ach = 6.0 * c["flops"] / 1e9 / c["ms"]
             result["roofline"] = {"kernel": "sparse_conv_bf16x6_kernel (cnrma_sparse_conv_bf16x6)", "bound": "mfma",
                                   "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                  "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                                  "traffic": PMC_CONV_TRAFFIC_S["bytes_per_launch"] if args.workload == "S" else None,
+                                  "traffic_source": PMC_CONV_TRAFFIC_S["source"] if args.workload == "S" else None,
                                   "note": "fp32-grade conv as 6 bf16 MFMA products per operand pair (3-way exact split); "
                                           "achieved = executed bf16 matrix flops (6 x 2*K*Cin*Cout*rows per launch) / "
                                           "launch time, averaged over the launches of one scene; fp32-equivalent rate = "

@@ -22,4 +22,4 @@ for _ in range(N):
 pr.disable()
 torch.cuda.synchronize()
 print("ms/scene", (time.perf_counter() - t0) / N * 1e3)
-st = pstats.Stats(pr); st.sort_stats("cumulative").print_stats(45)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
