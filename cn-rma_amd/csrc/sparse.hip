@@ -11,7 +11,6 @@
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
-#include <cstdlib>
 
 namespace {
 
@@ -1008,12 +1007,6 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   else if (no_cap < 16384) { shape = T64x64; bm = 64; bn = 64; }
   else if (Cout >= 128) { shape = T128x128; bm = 128; bn = 128; }
   else { shape = T128x64; bm = 128; bn = 64; }
-  if (const char* ov = getenv("CNRMA_CONV_SHAPE")) {          // tuning aid (not used by the product path)
-    const int v = atoi(ov);
-    if (Cout > 32 && v == 0) { shape = T64x64; bm = 64; bn = 64; }
-    if (Cout > 32 && v == 1) { shape = T128x64; bm = 128; bn = 64; }
-    if (Cout > 32 && v == 2) { shape = T128x128; bm = 128; bn = 128; }
-  }
   if (slices == 1 && workspace != nullptr) {
     p.splits = choose_splits(no_cap, Cout, K, bm, bn, ws_bytes);
     p.k_per_split = (int)ceil_div(K, p.splits);
