@@ -25,3 +25,11 @@ for name, a, e0, e1 in prof.records:
     else:
         print(f"{name} {ms:.3f} ms")
 print("conv total", tot)
+
+import collections, json
+agg = collections.defaultdict(list)
+for name, a, e0, e1 in prof.records:
+    if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
+        rows, cin, cout, K = (a[11], a[1], a[5], a[3]) if name == "cnrma_sparse_conv_f32" else (a[14], a[3], a[7], a[5])
+        agg[(rows // 1000, cin, cout, K)].append(e0.elapsed_time(e1))
+print("SUMMARY", json.dumps({f"{k[0]}k_{k[1]}_{k[2]}_K{k[3]}": round(sum(v) / len(v), 3) for k, v in sorted(agg.items())}))
