@@ -1,0 +1,78 @@
+"""GPU test of the drop-in boundary: the registered RayMarching detector (reference API: forward(return_loss=False, **data)
+-> [{}], raw boxes dumped to {save_path}/{scene}/{scene}_bbox_raw.npz) against the oracle / the scene pipeline."""
+import os
+import runpy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import count_mismatch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(tmp_path, dims, device, max_points):
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model
+    cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+    m = dict(cfg["model"])
+    m.update(save_path=str(tmp_path / "results"), voxel_dim_test=list(dims), voxel_dim_train=list(dims), max_points=max_points)
+    m["detection_backbone"] = dict(type="FCAF3DBackbone", in_channels=8, depth=34)
+    model = build_model(m)
+    torch.manual_seed(0)
+    model.detection_backbone.init_weights()
+    model.detection_head.init_weights()
+    return model.to(device).eval()
+
+
+def test_raymarching_forward_test_matches_oracle_and_pipeline(device, tmp_path):
+    from cnrma_amd import pipeline, synth
+    from oracle import rma_oracle as O
+    sc = synth.make_scene("tiny", seed=0)
+    V = sc["features"].shape[0]
+    model = _model(tmp_path, sc["dims"], device, max_points=400)
+    feats = [sc["features"][:, 0].to(device)]                                 # per sample: [V, C, H', W']
+    data = dict(features=feats, projection=[sc["projection"][:, 0].to(device)], tsdf=sc["tsdf"].to(device),
+                offset=[torch.tensor([0.25, -0.5, 0.125], device=device)], scene=["scene0000_00"])
+    np.random.seed(3)
+    with torch.no_grad():
+        ret = model(return_loss=False, **data)
+    assert ret == [{}]                                                       # reference contract (ray_marching.py:521)
+    # dense half: volume / valid as the reference leaves them on the module (B x C x X x Y x Z, B x 1 x X x Y x Z bool)
+    vol, cnt = O.backproject_accum(sc["dims"], 0.04, sc["origin"], sc["projection"][:, 0], sc["features"][:, 0], sc["stride"])
+    assert count_mismatch(model.volume[0], vol) == 0 and torch.equal(model.valid[0, 0].cpu(), cnt > 0)
+    # aggregated points == oracle
+    pts = O.aggregate_rma(sc["projection"][:, 0], sc["features"][:, 0], sc["tsdf"][0, 0], sc["dims"], 0.04, sc["origin"], sc["stride"])
+    got = model.points_detection[0].cpu()
+    assert count_mismatch(got[:, :3], pts[:, :3]) == 0
+    np.testing.assert_allclose(got[:, 3:].numpy(), pts[:, 3:].numpy(), rtol=1e-4, atol=1e-4)
+    # raw boxes dumped with the reference's file layout and keys; same as the fused scene pipeline given the same mask
+    z = np.load(tmp_path / "results" / "scene0000_00" / "scene0000_00_bbox_raw.npz")
+    assert set(z.files) == {"bboxes", "scores"} and z["bboxes"].shape[1] == 6 and z["scores"].shape[1] == 18
+    np.random.seed(3)
+    mask = O.sample_mask_numpy(pts.shape[0], 400)
+    cfg = pipeline.SceneConfig(sc["dims"], stride=sc["stride"], max_points=400, sampler="numpy")
+    out = pipeline.forward_scene(cfg, model.detection_backbone, model.detection_head, sc["features"][:, 0].to(device),
+                                 sc["projection"][:, 0], sc["tsdf"][0, 0].to(device), offset=(0.25, -0.5, 0.125), mask=mask)
+    np.testing.assert_allclose(z["bboxes"], out["bboxes"].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(z["scores"], out["scores"].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_module_level_functions_keep_the_reference_signatures(device):
+    from cnrma_amd import synth
+    from oracle import rma_oracle as O
+    from projects.mvsdetection.models import ray_marching as RM
+    sc = synth.make_scene("tiny", seed=2)
+    proj = O.scale_projection(sc["projection"][0], sc["stride"]).to(device)          # [B=1,3,4]
+    feat = sc["features"][0].to(device)                                             # [B=1,C,H,W]
+    vol, valid = RM.backproject(sc["dims"], 0.04, torch.tensor(sc["origin"]).view(1, 3), proj, feat)
+    ov, ovalid, _, _ = O.backproject_view(sc["dims"], 0.04, sc["origin"], proj[0].cpu(), feat[0].cpu())
+    assert tuple(vol.shape) == (1, feat.shape[1], *sc["dims"]) and tuple(valid.shape) == (1, 1, *sc["dims"])
+    assert count_mismatch(vol[0].reshape(feat.shape[1], -1), ov) == 0
+    assert torch.equal(valid[0, 0].reshape(-1).cpu(), ovalid)
+    o, d = RM.get_ray_parameter(proj, feat)
+    oo, od = O.ray_params(proj[0].cpu(), feat.shape[2], feat.shape[3])
+    assert tuple(o.shape) == (1, 3, feat.shape[2] * feat.shape[3])
+    assert count_mismatch(d[0], od) == 0 and count_mismatch(o[0, :, 0], oo) == 0
