@@ -151,13 +151,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks for a 1-GPU box: run the N-rank code path with all ranks on device 0 over gloo (RCCL refuses two
+    # ranks on one device).  Never set by the driver; the numbers of such a run are meaningless.
+    backend = os.environ.get("CNRMA_BENCH_BACKEND", "nccl")
+    if os.environ.get("CNRMA_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     from cnrma_amd import _lib, pipeline, rma, synth
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=device if backend == "nccl" else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     V, C, H, W, dims, stride = synth.SHAPES[args.workload]
