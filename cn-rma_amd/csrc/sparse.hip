@@ -737,7 +737,7 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
 };
 
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT>
-__global__ __launch_bounds__(256) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
+__global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   // staging tasks per stage: fp32 input = (row, 4 channels) -> 8 per row; pre-split input = (row, 8 channels) -> 4 per row
   constexpr int ROW_SHIFT = IN_SPLIT ? 2 : 3;
