@@ -1001,11 +1001,16 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
              reinterpret_cast<float*>(workspace), reinterpret_cast<const uint16_t*>(in_split), in_zero_row,
              reinterpret_cast<uint16_t*>(out_split), out_zero_row};
   int bm, bn;
-  // tile choice: wide tiles for wide layers; 64x64 tiles for short layers (more blocks, less row padding)
-  enum { T128x128, T128x64, T64x64, T128x32 } shape;
+  // tile choice (measured per layer class on MI355X at the ScanNet shape): wide tiles for wide long
+  // layers; 64-row tiles for short layers (more blocks, less row padding) and for the 32-channel stem
+  enum { T128x128, T128x64, T64x64, T128x32, T64x128 } shape;
+  const bool six = weight_split != nullptr && Cin % 32 == 0;
   if (Cout <= 32) { shape = T128x32; bm = 128; bn = 32; }
-  else if (no_cap < 16384) { shape = T64x64; bm = 64; bn = 64; }
+  else if (six && no_cap < 1000 && Cout >= 256) { shape = T64x128; bm = 64; bn = 128; }
+  else if (no_cap < 4000) { shape = T64x64; bm = 64; bn = 64; }
+  else if (no_cap < 16384) { if (six) { shape = T128x64; bm = 128; bn = 64; } else { shape = T64x64; bm = 64; bn = 64; } }
   else if (Cout >= 128) { shape = T128x128; bm = 128; bn = 128; }
+  else if (six && Cin <= 32) { shape = T64x64; bm = 64; bn = 64; }
   else { shape = T128x64; bm = 128; bn = 64; }
   if (slices == 1 && workspace != nullptr) {
     p.splits = choose_splits(no_cap, Cout, K, bm, bn, ws_bytes);
@@ -1034,6 +1039,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
       case T128x64: CNRMA_CONV6_LAUNCH(4, 1, 1, 2); break;
       case T64x64: CNRMA_CONV6_LAUNCH(2, 2, 1, 1); break;
       case T128x32: CNRMA_CONV6_LAUNCH(4, 1, 1, 1); break;
+      case T64x128: CNRMA_CONV6_LAUNCH(2, 2, 1, 2); break;
     }
 #undef CNRMA_CONV6_LAUNCH
     if (p.splits > 1) {
@@ -1060,6 +1066,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     case T128x64: CNRMA_CONV_LAUNCH(4, 1, 1, 2); break;
     case T64x64: CNRMA_CONV_LAUNCH(2, 2, 1, 1); break;
     case T128x32: CNRMA_CONV_LAUNCH(4, 1, 1, 1); break;
+    default: return CNRMA_EINVAL;
   }
 #undef CNRMA_CONV_LAUNCH
   if (p.splits > 1) {
