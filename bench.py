@@ -57,11 +57,17 @@ def build_model(C, device, n_classes=18, n_reg=6):
     return backbone.to(device).eval(), head.to(device).eval()
 
 
+# positions of (Cin, K, Cout, rows) in the argument lists of the convolution entry points
+CONV_ARGS = {"cnrma_sparse_conv_f32": (1, 3, 5, 11), "cnrma_sparse_conv_bf16x6": (3, 5, 7, 14),
+             "cnrma_sparse_conv_f16x3": (2, 4, 6, 13)}
+
+
 class KernelProfile:
     """per C-ABI call HIP-event timing on the launch stream (each timed entry point is exactly one kernel)"""
     TIMED = ("cnrma_backproject_accum_f32", "cnrma_rma_neus_count_f32", "cnrma_rma_neus_emit_f32",
              "cnrma_rma_neus_march_f32", "cnrma_sparse_kernel_map_symmetric", "cnrma_sparse_kernel_map_strided",
-             "cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_convtr_gen_f32", "cnrma_nchw_to_nhwc_f32",
+             "cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_conv_f16x3", "cnrma_sparse_convtr_gen_f32",
+             "cnrma_nchw_to_nhwc_f32",
              "cnrma_sparse_kernel_map", "cnrma_sparse_maxpool_f32")
 
     def __init__(self):
@@ -96,11 +102,8 @@ class KernelProfile:
             d = agg.setdefault(name, dict(ms=0.0, n=0, flops=0.0))
             d["ms"] += ms
             d["n"] += 1
-            if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
-                if name == "cnrma_sparse_conv_f32":   # in, Cin, nbr, K, W, Cout, scale, shift, res, act, out, no_cap, ...
-                    cin, k, cout, rows = args[1], args[3], args[5], args[11]
-                else:                                 # in, in_split, zero_row, Cin, nbr, K, Wsplit, Cout, ..., out, out_split, no_cap
-                    cin, k, cout, rows = args[3], args[5], args[7], args[14]
+            if name in CONV_ARGS:
+                cin, k, cout, rows = (args[i] for i in CONV_ARGS[name])
                 d["flops"] += 2.0 * k * cin * cout * rows      # dense-K upper bound (executed MFMA work)
         return agg
 
@@ -265,14 +268,28 @@ def main():
                                                    GBps=dense_bytes / 1e6 / dense_ms,
                                                    frac_hbm=dense_bytes / 1e6 / dense_ms / HBM_PEAK_GBS)
         for name, mult, peak in (("cnrma_sparse_conv_f32", 1.0, MFMA_F32_PEAK_TFLOPS),
-                                 ("cnrma_sparse_conv_bf16x6", 6.0, MFMA_BF16_PEAK_TFLOPS)):
+                                 ("cnrma_sparse_conv_bf16x6", 6.0, MFMA_BF16_PEAK_TFLOPS),
+                                 ("cnrma_sparse_conv_f16x3", 3.0, MFMA_BF16_PEAK_TFLOPS)):
             if name in agg:
                 c = agg[name]
                 kern[name].update(fp32_equiv_TFLOP=c["flops"] / reps / 1e12, fp32_equiv_TFLOPps=c["flops"] / 1e9 / c["ms"],
                                   executed_matrix_TFLOPps=mult * c["flops"] / 1e9 / c["ms"],
                                   frac_mfma_peak=mult * c["flops"] / 1e9 / c["ms"] / peak)
         dominant = max(kern, key=lambda k: kern[k]["ms_per_scene"])
-        if dominant == "cnrma_sparse_conv_bf16x6":
+        if dominant == "cnrma_sparse_conv_f16x3":
+            c = agg[dominant]
+            ach = 3.0 * c["flops"] / 1e9 / c["ms"]
+            result["roofline"] = {"kernel": "sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_f16x3)", "bound": "mfma",
+                                  "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                                  "traffic": PMC_CONV_TRAFFIC_S["bytes_per_launch"] if args.workload == "S" else None,
+                                  "traffic_source": PMC_CONV_TRAFFIC_S["source"] if args.workload == "S" else None,
+                                  "note": "22-bit conv as 3 fp16 MFMA products per operand pair (2-way split under a "
+                                          "per-tensor power-of-two scale); achieved = executed fp16 matrix flops "
+                                          "(3 x 2*K*Cin*Cout*rows per launch) / launch time, averaged over the launches "
+                                          "of one scene; peak = dense fp16/bf16 MFMA 2.5 PFLOP/s; fp32-equivalent rate = "
+                                          f"{c['flops'] / 1e9 / c['ms']:.1f} TFLOP/s vs 157.3 fp32-MFMA peak"}
+        elif dominant == "cnrma_sparse_conv_bf16x6":
             c = agg[dominant]
             ach = 6.0 * c["flops"] / 1e9 / c["ms"]
             result["roofline"] = {"kernel": "sparse_conv_bf16x6_kernel (cnrma_sparse_conv_bf16x6)", "bound": "mfma",

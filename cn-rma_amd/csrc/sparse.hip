@@ -360,6 +360,9 @@ struct ConvArgs {
   // extra last row is all zeros and stands in for missing neighbours (no select in the gather)
   const uint16_t* in_split; int64_t in_zero_row;
   uint16_t* out_split; int64_t out_zero_row;
+  // f16x3: upper bounds of |features| / |weights| (device scalars) that fix the power-of-two operand scales, and the
+  // running maximum of |outputs| for the consumers of this layer (atomicMax on the bit pattern; pre-zeroed by the host)
+  const float* in_amax; const float* w_amax; float* out_amax;
 };
 
 // exact 3-way split by truncation: h = top 8 significant bits of a, m = next 8, l = last 8 (a == h + m + l)
@@ -632,6 +635,104 @@ __device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint
   l = make_uint2((uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16));
 }
 
+// ---- f16x3: a * 2^s = h + m with h, m fp16 (round to nearest): |a 2^s - h - m| <= 2^-22 |a 2^s|; the products hh, hm, mh
+// are exact in fp32, the dropped mm term is <= 2^-22 |ab|.  The power-of-two scale (from an upper bound of the
+// tensor's magnitude) keeps the largest operand at 2^13..2^14: no overflow, and every element down to 2^-17 of the
+// largest keeps its 22 bits before m runs into fp16 subnormals.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float f16_scale_for(float amax) {
+  if (!(amax > 0.0f) || !(amax < 3.0e38f)) return 1.0f;
+  int e;
+  (void)frexpf(amax, &e);                                  // amax < 2^e
+  int sh = 14 - e;
+  sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+  return ldexpf(1.0f, sh);
+}
+
+__device__ __forceinline__ void split2_f16(float x, uint16_t& h, uint16_t& m) {
+  const _Float16 hh = (_Float16)x;
+  const float r = x - (float)hh;                            // exact
+  const _Float16 mm = (_Float16)r;
+  h = __builtin_bit_cast(uint16_t, hh);
+  m = __builtin_bit_cast(uint16_t, mm);
+}
+
+__device__ __forceinline__ void split2(const float4& v, uint2& h, uint2& m) {
+  uint16_t hh[4], mm[4];
+  split2_f16(v.x, hh[0], mm[0]);
+  split2_f16(v.y, hh[1], mm[1]);
+  split2_f16(v.z, hh[2], mm[2]);
+  split2_f16(v.w, hh[3], mm[3]);
+  h = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
+  m = make_uint2((uint32_t)mm[0] | ((uint32_t)mm[1] << 16), (uint32_t)mm[2] | ((uint32_t)mm[3] << 16));
+}
+
+// A tensor's magnitude bound lives in AMAX_SLOTS words, one per 64-byte line: a block publishes ONE candidate (wave
+// shuffle + LDS), into the slot its block index hashes to, and only when it beats the value currently visible (the
+// maximum is monotone, so a stale read only costs a redundant atomic).  Thousands of same-address atomics per launch
+// serialise at the memory side (measured: +1.1 ms per scene with one atomic per wave on a single word).
+constexpr int AMAX_SLOTS = 64, AMAX_STRIDE = 16;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float read_amax(const float* slots) {            // every lane returns the bound
+  return wave_max(slots[(threadIdx.x & 63) * AMAX_STRIDE]);
+}
+
+// v >= 0 (uint order == float order); blockDim.x == 256, every thread of the block calls it; sh4: 4 floats of LDS
+__device__ __forceinline__ void block_amax_publish(float* slots, float v, float* sh4) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
+    const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (AMAX_SLOTS - 1);
+    unsigned* d = reinterpret_cast<unsigned*>(slots + slot * AMAX_STRIDE);
+    const unsigned bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, bits);
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ in, int64_t n_cap,
+                                                     const int32_t* __restrict__ n_dev, int C, float* __restrict__ out) {
+  const int64_t total = live_rows(n_cap, n_dev) * C;
+  float mx = 0.0f;
+  for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (t + 3 < total && (C & 3) == 0) {
+      const float4 v = *reinterpret_cast<const float4*>(in + t);
+      mx = fmaxf(fmaxf(mx, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+    } else {
+      for (int j = 0; j < 4 && t + j < total; ++j) mx = fmaxf(mx, fabsf(in[t + j]));
+    }
+  }
+  __shared__ float sh4[4];
+  block_amax_publish(out, mx, sh4);
+}
+
+// W fp32 [K][Cin][Cout] -> Wt fp16 [2 planes][K][Cout][Cin] scaled by f16_scale_for(*amax), + trailer float = *amax
+__global__ __launch_bounds__(256) void prep_weights_f16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int K,
+                                                               int Cin, int Cout, const float* __restrict__ amax) {
+  const int64_t total = (int64_t)K * Cin * Cout;
+  const float am = read_amax(amax);
+  const float sc = f16_scale_for(am);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(wt + 2 * total) = am;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int cin = (int)(t % Cin);
+    const int64_t q = t / Cin;
+    const int co = (int)(q % Cout);
+    const int k = (int)(q / Cout);
+    uint16_t hh, mm;
+    split2_f16(w[((int64_t)k * Cin + cin) * Cout + co] * sc, hh, mm);
+    wt[t] = hh;
+    wt[total + t] = mm;
+  }
+}
+
 // fp32 [N][C] -> split companion [N+1][C/8][3][8] bf16 (+ the zero row at index n_cap); one lane per 8 channels
 __global__ __launch_bounds__(256) void split_features_kernel(const float* __restrict__ in, int64_t n_cap,
                                                              const int32_t* __restrict__ n_dev, int C,
@@ -692,7 +793,8 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
       ok |= (src >= 0 ? 1u : 0u) << i;
     }
   }
-  __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2) const {
+  template <int MODE>
+  __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2, float a_scale) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int idx = tid + i * 256;
@@ -700,11 +802,19 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
       float4 v = r[i];
       const bool k = (ok >> i) & 1u;
       v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
-      uint2 h, m, l;
-      split3(v, h, m, l);
-      *reinterpret_cast<uint2*>(a0 + row * LDK + kc * 4) = h;
-      *reinterpret_cast<uint2*>(a1 + row * LDK + kc * 4) = m;
-      *reinterpret_cast<uint2*>(a2 + row * LDK + kc * 4) = l;
+      if constexpr (MODE == 0) {
+        uint2 h, m, l;
+        split3(v, h, m, l);
+        *reinterpret_cast<uint2*>(a0 + row * LDK + kc * 4) = h;
+        *reinterpret_cast<uint2*>(a1 + row * LDK + kc * 4) = m;
+        *reinterpret_cast<uint2*>(a2 + row * LDK + kc * 4) = l;
+      } else {
+        v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
+        uint2 h, m;
+        split2(v, h, m);
+        *reinterpret_cast<uint2*>(a0 + row * LDK + kc * 4) = h;
+        *reinterpret_cast<uint2*>(a1 + row * LDK + kc * 4) = m;
+      }
     }
   }
 };
@@ -724,7 +834,8 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
       h[i] = q[0]; m[i] = q[1]; l[i] = q[2];
     }
   }
-  __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2) const {
+  template <int MODE>
+  __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2, float) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int idx = tid + i * 256;
@@ -736,17 +847,20 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
   }
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT>
+// MODE 0 = bf16x6 (3 planes, 6 products), MODE 1 = f16x3 (2 planes, 3 products, power-of-two operand scales)
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT, int MODE>
 __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  constexpr int NP = MODE == 0 ? 3 : 2;
+  static_assert(MODE == 0 || !IN_SPLIT, "companions exist for bf16x6 only");
   // staging tasks per stage: fp32 input = (row, 4 channels) -> 8 per row; pre-split input = (row, 8 channels) -> 4 per row
   constexpr int ROW_SHIFT = IN_SPLIT ? 2 : 3;
   constexpr int A_ITERS = (BM << ROW_SHIFT) / 256;
-  constexpr int B_CHUNKS = 3 * BN * (BK / 8);           // 16-byte (8 x bf16) chunks over the 3 planes
+  constexpr int B_CHUNKS = NP * BN * (BK / 8);          // 16-byte (8 x 16-bit) chunks over the planes
   constexpr int B_ITERS = (B_CHUNKS + 255) / 256;
   static_assert(WAVES_M * WAVES_N == 4 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
-  __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * LDK];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * LDK];
+  __shared__ __attribute__((aligned(16))) __bf16 As[NP][BM * LDK];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[NP][BN * LDK];
   __shared__ unsigned mask_s;
 
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
@@ -759,6 +873,11 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout : 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid / WAVES_N, wc = wid % WAVES_N;
+  float a_scale = 1.0f, out_scale = 1.0f;
+  if constexpr (MODE == 1) {
+    a_scale = f16_scale_for(read_amax(p.in_amax));
+    out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));          // powers of two: exact
+  }
 
   int k_lo = 0, k_hi = K;
   if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
@@ -824,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
     }
   };
   auto store_stage = [&]() {
-    areg.store(tid, &As[0][0], &As[1][0], &As[2][0]);
+    areg.template store<MODE>(tid, &As[0][0], &As[1][0], &As[NP - 1][0], a_scale);
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       const int idx = tid + i * 256;
@@ -860,28 +979,50 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
     const int b_off = (wc * (32 * TN) + (lane & 31)) * LDK + (lane >> 5) * 8;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
-      bf16x8_t af[TM][3], bf[TN][3];
+      if constexpr (MODE == 0) {
+        bf16x8_t af[TM][3], bf[TN][3];
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) af[a][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][a_off + a * 32 * LDK + ks]);
+          for (int pl = 0; pl < 3; ++pl) af[a][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][a_off + a * 32 * LDK + ks]);
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bf[b][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][b_off + b * 32 * LDK + ks]);
+          for (int pl = 0; pl < 3; ++pl) bf[b][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][b_off + b * 32 * LDK + ks]);
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x16 c = acc[a][b];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);   // l*h
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);   // h*l
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);   // m*m
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);   // m*h
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);   // h*m
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);   // h*h
-          acc[a][b] = c;
-        }
+          for (int b = 0; b < TN; ++b) {
+            f32x16 c = acc[a][b];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], c, 0, 0, 0);   // l*h
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], c, 0, 0, 0);   // h*l
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], c, 0, 0, 0);   // m*m
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], c, 0, 0, 0);   // m*h
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], c, 0, 0, 0);   // h*m
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);   // h*h
+            acc[a][b] = c;
+          }
+      } else {
+        f16x8_t af[TM][2], bf[TN][2];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) af[a][pl] = *reinterpret_cast<const f16x8_t*>(&As[pl][a_off + a * 32 * LDK + ks]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) bf[b][pl] = *reinterpret_cast<const f16x8_t*>(&Bs[pl][b_off + b * 32 * LDK + ks]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            f32x16 c = acc[a][b];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][1], bf[b][0], c, 0, 0, 0);    // m*h
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][1], c, 0, 0, 0);    // h*m
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][0], c, 0, 0, 0);    // h*h
+            acc[a][b] = c;
+          }
+      }
     }
     __syncthreads();
     k = nk;
@@ -896,6 +1037,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
   const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
   const int act = partial ? 0 : p.act;
+  float mx = 0.0f;                                                     // largest |output| of this lane (f16x3 consumers)
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
@@ -921,6 +1063,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
         for (int q = 0; q < 4; ++q) {
           const int64_t row = row0 + q + 8 * rg;
           float v = acc[a][b][rg * 4 + q];
+          if constexpr (MODE == 1) v = v * out_scale;                  // undo the operand scales (a power of two)
           v = v * sc;
           v = v + sh;
           if constexpr (HAS_RES) v = v + res[q];
@@ -928,10 +1071,15 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
           if (col_ok && row < n_live) {
             dst[(out_base + row) * Cout + col] = v;
             if (!partial && p.out_split) store_split(p.out_split, out_base + row, Cout, col, v);
+            mx = fmaxf(mx, fabsf(v));
           }
         }
       }
     }
+  }
+  if (!partial && p.out_amax != nullptr) {
+    __syncthreads();                                                   // the A image is no longer read: reuse 16 bytes
+    block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(&As[0][0]));
   }
 }
 
@@ -942,6 +1090,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
     for (int i = threadIdx.x; i < (p.Cout >> 3) * 24; i += 256) p.out_split[p.out_zero_row * (p.Cout >> 3) * 24 + i] = 0;
   const int64_t total = n_live * p.Cout;
   const int64_t slab_stride = p.no_cap * p.Cout;
+  float mx = 0.0f;
   for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (int64_t)gridDim.x * blockDim.x * 4) {
     if ((p.Cout & 3) == 0) {
       float4 s = *reinterpret_cast<const float4*>(p.slab + t);
@@ -958,6 +1107,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
         if (p.shift) x = x + p.shift[col + j];
         if (p.residual) x = x + p.residual[t + j];
         v[j] = apply_act(x, p.act);
+        mx = fmaxf(mx, fabsf(v[j]));
         if (p.out_split) store_split(p.out_split, t / p.Cout, p.Cout, col + j, v[j]);
       }
       *reinterpret_cast<float4*>(p.out + t) = make_float4(v[0], v[1], v[2], v[3]);
@@ -969,9 +1119,15 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
         if (p.scale) x = x * p.scale[col];
         if (p.shift) x = x + p.shift[col];
         if (p.residual) x = x + p.residual[t + j];
-        p.out[t + j] = apply_act(x, p.act);
+        x = apply_act(x, p.act);
+        mx = fmaxf(mx, fabsf(x));
+        p.out[t + j] = x;
       }
     }
+  }
+  if (p.out_amax != nullptr) {
+    __shared__ float sh4[4];
+    block_amax_publish(p.out_amax, mx, sh4);
   }
 }
 
@@ -993,13 +1149,18 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
                 const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
                 int slices, void* workspace, size_t ws_bytes, hipStream_t st, const void* weight_split = nullptr,
                 const void* in_split = nullptr, int64_t in_zero_row = 0, void* out_split = nullptr,
-                int64_t out_zero_row = 0) {
+                int64_t out_zero_row = 0, int mode = 0, const float* in_amax = nullptr, float* out_amax = nullptr) {
   if (Cin <= 0 || Cout <= 0 || K <= 0 || K > 27 || no_cap <= 0) return CNRMA_EINVAL;
   if (out_split != nullptr && (Cout % 8 != 0 || weight_split == nullptr)) return CNRMA_EINVAL;
   if (in_split != nullptr && (Cin % 32 != 0 || weight_split == nullptr)) return CNRMA_EINVAL;
   ConvArgs p{in, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out, no_cap, no_dev, slices, 1, K,
              reinterpret_cast<float*>(workspace), reinterpret_cast<const uint16_t*>(in_split), in_zero_row,
-             reinterpret_cast<uint16_t*>(out_split), out_zero_row};
+             reinterpret_cast<uint16_t*>(out_split), out_zero_row, in_amax, nullptr, out_amax};
+  if (mode == 1) {
+    if (weight_split == nullptr || in_amax == nullptr || in_split != nullptr || out_split != nullptr) return CNRMA_EINVAL;
+    p.w_amax = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(weight_split) +
+                                              2 * (int64_t)(slices > 1 ? slices : 1) * K * Cin * Cout);
+  }
   int bm, bn;
   // tile choice (measured per layer class on MI355X at the ScanNet shape): wide tiles for wide long
   // layers; 64-row tiles for short layers (more blocks, less row padding) and for the 32-channel stem
@@ -1025,14 +1186,18 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     const __bf16* wt = reinterpret_cast<const __bf16*>(weight_split);
 #define CNRMA_CONV6_LAUNCH(WM, WN, TM_, TN_)                                                                       \
   do {                                                                                                             \
-    if (has_res && in_split)                                                                                       \
-      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, true>), grid, dim3(256), 0, st, p, wt); \
+    if (mode == 1 && has_res)                                                                                      \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 1>), grid, dim3(256), 0, st, p, wt);  \
+    else if (mode == 1)                                                                                            \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 1>), grid, dim3(256), 0, st, p, wt); \
+    else if (has_res && in_split)                                                                                  \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, true, 0>), grid, dim3(256), 0, st, p, wt);   \
     else if (has_res)                                                                                              \
-      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false>), grid, dim3(256), 0, st, p, wt); \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 0>), grid, dim3(256), 0, st, p, wt);  \
     else if (in_split)                                                                                             \
-      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, true>), grid, dim3(256), 0, st, p, wt); \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, true, 0>), grid, dim3(256), 0, st, p, wt);  \
     else                                                                                                           \
-      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false>), grid, dim3(256), 0, st, p, wt); \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 0>), grid, dim3(256), 0, st, p, wt); \
   } while (0)
     switch (shape) {
       case T128x128: CNRMA_CONV6_LAUNCH(2, 2, 2, 2); break;
@@ -1440,6 +1605,68 @@ extern "C" int cnrma_sparse_conv_bf16x6(const float* in_feats, const void* in_sp
   return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
                      workspace, workspace_bytes, as_stream(stream), weight_split, in_split, in_zero_row, out_split,
                      no_cap);
+}
+
+extern "C" int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out_amax,
+                                void* stream) {
+  if (n_cap <= 0 || C <= 0 || out_amax == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(out_amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
+  if (e != hipSuccess) return -(int)e;
+  int64_t blocks = ceil_div(n_cap * C / 4 + 1, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, n_cap, n_dev, C, out_amax);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t cnrma_amax_bytes(void) { return sizeof(float) * AMAX_SLOTS * AMAX_STRIDE; }
+
+extern "C" size_t cnrma_sparse_conv_f16_weight_bytes(int K, int Cin, int Cout) {
+  return (size_t)2 * K * Cin * Cout * sizeof(uint16_t) + 64 + sizeof(float) * AMAX_SLOTS * AMAX_STRIDE;
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K, int Cin, int Cout, void* weight_split,
+                                                     void* stream) {
+  if (K <= 0 || Cin <= 0 || Cout <= 0 || weight_split == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int64_t total = (int64_t)K * Cin * Cout;
+  uint16_t* wt = reinterpret_cast<uint16_t*>(weight_split);
+  float* amax = reinterpret_cast<float*>(wt + 2 * total) + 16;       // slot scratch behind the 64-byte trailer
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
+  if (e != hipSuccess) return -(int)e;
+  int64_t blocks = ceil_div(total / 4 + 1, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, total, nullptr, 1, amax);
+  blocks = ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, wt, K, Cin, Cout, amax);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_f16x3(const float* in_feats, const float* in_amax, int Cin, const int32_t* nbr, int K,
+                                       const void* weight_split, int Cout, const float* scale, const float* shift,
+                                       const float* residual, int act, float* out_feats, float* out_amax,
+                                       int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  if (weight_split == nullptr || Cin % 32 != 0 || in_feats == nullptr || in_amax == nullptr) return CNRMA_EINVAL;
+  return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
+                     workspace, workspace_bytes, as_stream(stream), weight_split, nullptr, 0, nullptr, 0, 1, in_amax,
+                     out_amax);
+}
+
+extern "C" int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax,
+                                             int64_t n_cap, const int32_t* n_dev, int Cin, int half_stride,
+                                             const void* weight_split, int Cout, const float* scale,
+                                             const float* shift, int act, int32_t* out_coords, float* out_feats,
+                                             float* out_amax, void* stream) {
+  if (n_cap <= 0 || half_stride <= 0 || weight_split == nullptr || Cin % 32 != 0 || in_amax == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(convtr_coords_kernel, dim3((unsigned)ceil_div(n_cap * 8, 256)), dim3(256), 0, st, in_coords,
+                     n_cap, n_dev, half_stride, out_coords);
+  return launch_conv(in_feats, Cin, nullptr, 1, nullptr, Cout, scale, shift, nullptr, act, out_feats, n_cap, n_dev, 8,
+                     nullptr, 0, st, weight_split, nullptr, 0, nullptr, 0, 1, in_amax, out_amax);
 }
 
 extern "C" int cnrma_sparse_split_features(const float* feats, int64_t n_cap, const int32_t* n_dev, int C,

@@ -96,7 +96,7 @@ class MinkowskiReLU(nn.Module):
         super().__init__()
 
     def forward(self, x):
-        return S.SparseTensor(torch.relu(x.F), x.cs)
+        return S.SparseTensor(torch.relu(x.F), x.cs, None, x.amax)
 
 
 class MinkowskiELU(nn.Module):

@@ -18,6 +18,9 @@ neighbour tables / strided children (what ME's CoordinateManager caches); a Spar
 """
 import itertools
 
+import os
+import threading
+
 import torch
 
 from . import _lib
@@ -125,11 +128,22 @@ class CoordSet:
 class SparseTensor:
     """features F [N,C] fp32 on a CoordSet; mirrors the attributes of ME.SparseTensor the reference touches."""
 
-    def __init__(self, features, coord_set, split=None):
+    def __init__(self, features, coord_set, split=None, amax=None):
         assert features.shape[0] == coord_set.n
         self.F = features
         self.cs = coord_set
         self._split = split       # bf16 [n+1, C/8, 3, 8] companion (hi/mid/lo pieces), filled by conv epilogues
+        self.amax = amax          # device scalar: an upper bound of |F| (f16x3 convolutions scale their operands by it)
+
+    def absmax(self):
+        """upper bound of |F| as a device scalar: the producing kernel's running maximum, or one pass over F"""
+        if self.amax is None:
+            n, C = self.F.shape
+            out = torch.zeros(_AMAX_WORDS, dtype=torch.float32, device=self.F.device)
+            if n:
+                call("cnrma_absmax_f32", ptr(self.F.contiguous()), n, None, C, ptr(out), stream())
+            self.amax = out
+        return self.amax
 
     def split(self):
         """pre-split bf16 companion of the features for the bf16x6 convolutions (built on demand, cached)"""
@@ -241,10 +255,51 @@ def _workspace(nbytes, device):
     return buf
 
 
-# "bf16x6": fp32-grade result on the bf16 matrix cores (3-way exact operand split, 6 partial products);
+# "f16x3":  22-bit operands on the fp16 matrix cores: a 2^s = h + m (two fp16 pieces, power-of-two scale from the tensor's
+#           magnitude), products hh + hm + mh in fp32 -- relative error <= 3 x 2^-22 per product, below the rounding noise
+#           of an fp32 accumulation of the same length; half the matrix work and 2/3 of the LDS traffic of "bf16x6";
+# "bf16x6": 24-bit operands on the bf16 matrix cores (3-way exact operand split, 6 partial products);
 # "f32":    v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).  Layers with Cin % 32 != 0 always use "f32".
-CONV_PRECISION = "bf16x6"
+CONV_PRECISION = "f16x3"
 PRESPLIT = False     # carry bf16 hi/mid/lo companions of the features between convolutions (see conv())
+
+
+_tls = threading.local()
+_AMAX_WORDS = 64 * 16          # cnrma_amax_bytes() / 4
+
+
+def _amax_slot(device):
+    """a zeroed magnitude bound (cnrma_amax_bytes: 64 words, one per 64-byte line) for a kernel's running |output|
+    maximum: bounds are carved from a chunk of 64 that is zeroed once (one memset per 64 convolutions) and never reused,
+    so a tensor's bound stays valid as long as it lives"""
+    pool = getattr(_tls, "amax_pool", None)
+    key = (device, stream())
+    if pool is None or pool[0] != key or pool[2] >= 64:
+        pool = [key, torch.zeros(64 * _AMAX_WORDS, dtype=torch.float32, device=device), 0]
+        _tls.amax_pool = pool
+    i = pool[2]
+    pool[2] = i + 1
+    return pool[1][i * _AMAX_WORDS:(i + 1) * _AMAX_WORDS]
+
+
+def split_weights_f16(weight):
+    """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> fp16 [2,K,Cout,Cin] (hi / lo pieces of weight * 2^s) + a trailer word
+    holding max|weight| (the kernel derives s from it).  Cached on the weight tensor like split_weights()."""
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    hit = getattr(weight, "_cnrma_split_f16", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    w = weight.detach().contiguous().float()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, Cin, Cout = w.shape
+    ws = torch.empty(_lib.load().cnrma_sparse_conv_f16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+    call("cnrma_sparse_conv_prepare_weights_f16", ptr(w), K, Cin, Cout, ptr(ws), stream())
+    try:
+        weight._cnrma_split_f16 = (tag, ws)
+    except AttributeError:
+        pass
+    return ws
 
 
 def split_weights(weight):
@@ -290,7 +345,14 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             assert res.shape == out.shape
         ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(out_cs.n, Cout, K)
         ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-        if (precision or CONV_PRECISION) == "bf16x6" and Cin % 32 == 0:
+        prec = precision or CONV_PRECISION
+        if prec == "f16x3" and Cin % 32 == 0:
+            out_amax = _amax_slot(x.device)
+            call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
+                 ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),
+                 out_cs.n, None, ptr(ws), ws_bytes, stream())
+            return SparseTensor(out, out_cs, None, out_amax)
+        if prec == "bf16x6" and Cin % 32 == 0:
             # pre-split companions (PRESPLIT): measured on MI355X at the ScanNet shape they do not pay -- the kernel is
             # bound by L2->LDS gather traffic, not by the in-loop split (5.6 ms either way) -- so they are off by default
             in_split = x.split() if (PRESPLIT or x._split is not None) else None
@@ -317,8 +379,15 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
     out_c = torch.empty((8 * n, 4), dtype=torch.int32, device=x.device)
     out_f = torch.empty((8 * n, Cout), dtype=torch.float32, device=x.device)
     out_split = None
+    out_amax = None
     if n:
-        if (precision or CONV_PRECISION) == "bf16x6" and Cin % 32 == 0:
+        prec = precision or CONV_PRECISION
+        if prec == "f16x3" and Cin % 32 == 0:
+            out_amax = _amax_slot(x.device)
+            call("cnrma_sparse_convtr_gen_f16x3", ptr(x.C), ptr(x.F.contiguous()), ptr(x.absmax()), n, None, Cin, half,
+                 ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f),
+                 ptr(out_amax), stream())
+        elif prec == "bf16x6" and Cin % 32 == 0:
             if PRESPLIT and Cout % 8 == 0:
                 out_split = torch.empty((8 * n + 1, Cout // 8, 3, 8), dtype=torch.bfloat16, device=x.device)
             in_split = x.split() if (PRESPLIT or x._split is not None) else None
@@ -328,7 +397,7 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
         else:
             call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, Cin, half, ptr(w), Cout,
                  ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
-    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch), out_split)
+    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch), out_split, out_amax)
 
 
 def max_pool(x, kernel_size=2, stride=2):
@@ -340,7 +409,7 @@ def max_pool(x, kernel_size=2, stride=2):
     if out_cs.n:
         call("cnrma_sparse_maxpool_f32", ptr(x.F.contiguous()), C, ptr(nbr), nbr.shape[1], ptr(out), out_cs.n, None,
              stream())
-    return SparseTensor(out, out_cs)
+    return SparseTensor(out, out_cs, None, x.amax)       # a maximum over a subset: the input's bound still holds
 
 
 def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
@@ -402,7 +471,7 @@ def prune(x, keep_mask):
     if n:
         call("cnrma_sparse_prune_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, C, ptr(sel), ptr(out_c), ptr(out_f),
              stream())
-    return SparseTensor(out_f, CoordSet(out_c, x.cs.stride, None, x.cs.n_batch))
+    return SparseTensor(out_f, CoordSet(out_c, x.cs.stride, None, x.cs.n_batch), None, x.amax)
 
 
 def head_post(y, coords, n_reg, n_cls, scale, voxel_size):

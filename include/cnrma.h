@@ -251,6 +251,31 @@ int cnrma_sparse_convtr_gen_bf16x6(const int32_t* in_coords, const float* in_fea
                                    const float* scale, const float* shift, int act, int32_t* out_coords,
                                    float* out_feats, void* out_split, void* stream);
 
+/* 22-bit convolution on the fp16 matrix cores ("f16x3"): each operand is scaled by a power of two taken from an upper
+ * bound of its tensor's magnitude (so that the largest element sits at 2^13..2^14) and split into two fp16 pieces
+ * a 2^s = h + m (round to nearest: |a 2^s - h - m| <= 2^-22 |a 2^s|); the products hh + hm + mh are accumulated in fp32 and
+ * the scales are removed in the epilogue (exact).  Relative error <= 3 x 2^-22 per product -- below the rounding noise
+ * of an fp32 accumulation of the same length -- at half the matrix-pipe cycles and 2/3 of the LDS traffic of bf16x6.
+ * Needs Cin % 32 == 0.  A magnitude bound ("amax") is cnrma_amax_bytes() bytes of device memory: 64 words, one per
+ * 64-byte line, whose maximum is the bound (blocks publish into the slot their index hashes to: same-address atomics
+ * would serialise).  in_amax: bound >= max|in_feats| (cnrma_absmax_f32, or the out_amax of the producing convolution);
+ * out_amax (may be NULL): zeroed by the caller, receives max|out_feats|.
+ * cnrma_sparse_conv_prepare_weights_f16: weight fp32 [K][Cin][Cout] -> fp16 [2][K][Cout][Cin] of weight * 2^s + a trailer
+ * holding max|weight| (cnrma_sparse_conv_f16_weight_bytes bytes in all), done once per layer. */
+size_t cnrma_amax_bytes(void);
+int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out_amax, void* stream);
+size_t cnrma_sparse_conv_f16_weight_bytes(int K, int Cin, int Cout);
+int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K, int Cin, int Cout, void* weight_split,
+                                          void* stream);
+int cnrma_sparse_conv_f16x3(const float* in_feats, const float* in_amax, int Cin, const int32_t* nbr, int K,
+                            const void* weight_split, int Cout, const float* scale, const float* shift,
+                            const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
+                            const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
+int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax, int64_t n_cap,
+                                  const int32_t* n_dev, int Cin, int half_stride, const void* weight_split, int Cout,
+                                  const float* scale, const float* shift, int act, int32_t* out_coords,
+                                  float* out_feats, float* out_amax, void* stream);
+
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */
 int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap, const int32_t* n_dev,

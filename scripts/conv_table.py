@@ -17,8 +17,8 @@ prof.uninstall(); torch.cuda.synchronize()
 tot = 0
 for name, a, e0, e1 in prof.records:
     ms = e0.elapsed_time(e1)
-    if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
-        rows, cin, cout, K = (a[11], a[1], a[5], a[3]) if name == "cnrma_sparse_conv_f32" else (a[14], a[3], a[7], a[5])
+    if name in bench.CONV_ARGS:
+        cin, K, cout, rows = (a[i] for i in bench.CONV_ARGS[name])
         fl = 2.0 * K * cin * cout * rows
         tot += ms
         print(f"conv rows={rows:7d} Cin={cin:4d} Cout={cout:4d} K={K:2d} {ms:8.3f} ms {fl/ms/1e9:7.1f} TF/s")
@@ -29,7 +29,7 @@ print("conv total", tot)
 import collections, json
 agg = collections.defaultdict(list)
 for name, a, e0, e1 in prof.records:
-    if name in ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6"):
-        rows, cin, cout, K = (a[11], a[1], a[5], a[3]) if name == "cnrma_sparse_conv_f32" else (a[14], a[3], a[7], a[5])
+    if name in bench.CONV_ARGS:
+        cin, K, cout, rows = (a[i] for i in bench.CONV_ARGS[name])
         agg[(rows // 1000, cin, cout, K)].append(e0.elapsed_time(e1))
 print("SUMMARY", json.dumps({f"{k[0]}k_{k[1]}_{k[2]}_K{k[3]}": round(sum(v) / len(v), 3) for k, v in sorted(agg.items())}))

@@ -86,7 +86,7 @@ def test_voxelize_duplicates_negative_and_first_wins(device):
 @pytest.mark.parametrize("cin,cout,k,stride,ts", [(32, 64, 3, 1, 1), (64, 64, 3, 1, 2), (32, 64, 3, 2, 1), (64, 128, 3, 2, 4),
                                                    (64, 128, 1, 2, 2), (128, 25, 1, 1, 1), (5, 7, 3, 1, 1), (48, 96, 3, 1, 1),
                                                    (256, 256, 3, 1, 2), (8, 3, 1, 1, 1)])
-@pytest.mark.parametrize("precision", ["f32", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x6", "f16x3"])
 def test_conv_vs_oracle(device, cin, cout, k, stride, ts, precision):
     from cnrma_amd import sparse as S
     rng = np.random.RandomState(cin + cout + k)
@@ -94,7 +94,7 @@ def test_conv_vs_oracle(device, cin, cout, k, stride, ts, precision):
     W = (rng.randn(k ** 3, cin, cout) / np.sqrt(cin * k ** 3)).astype(np.float32)
     out = S.conv(to_st(c, f, ts, device), torch.from_numpy(W).to(device), k, stride, precision=precision)
     oc, of = SO.conv(c, f, W, k, stride, ts)
-    check(out, oc, of, tol=2e-6 if precision == "bf16x6" or True else TOL)   # both paths are fp32-grade
+    check(out, oc, of, tol=2e-6)   # all three paths are fp32-grade at this length (f16x3: 22-bit operands)
     assert out.cs.stride == ts * stride
 
 
@@ -111,9 +111,9 @@ def test_presplit_companions_give_identical_results(device):
         S.PRESPLIT = flag
         try:
             x = to_st(c, f, 2, device)
-            y = S.conv(x, torch.from_numpy(W1).to(device), 3, 1, act="relu")
-            z = S.conv(y, torch.from_numpy(W2).to(device), 3, 1)
-            u = S.conv_transpose_generative(z, torch.from_numpy(Wt).to(device), act="elu")
+            y = S.conv(x, torch.from_numpy(W1).to(device), 3, 1, act="relu", precision="bf16x6")
+            z = S.conv(y, torch.from_numpy(W2).to(device), 3, 1, precision="bf16x6")
+            u = S.conv_transpose_generative(z, torch.from_numpy(Wt).to(device), act="elu", precision="bf16x6")
             assert (y._split is not None) == flag and (u._split is not None) == flag
             outs.append((y.F.clone(), z.F.clone(), u.F.clone()))
         finally:
@@ -123,7 +123,7 @@ def test_presplit_companions_give_identical_results(device):
     # the companion written by the epilogue reconstructs the fp32 features exactly: h + m + l == x
     S.PRESPLIT = True
     try:
-        y = S.conv(to_st(c, f, 2, device), torch.from_numpy(W1).to(device), 3, 1, act="relu")
+        y = S.conv(to_st(c, f, 2, device), torch.from_numpy(W1).to(device), 3, 1, act="relu", precision="bf16x6")
     finally:
         S.PRESPLIT = False
     sp = y._split[:-1].float()                       # [n, C/8, 3, 8]
@@ -141,6 +141,7 @@ def test_bf16x6_is_fp32_grade_on_wide_dynamic_range(device):
     x = to_st(c, f, 1, device)
     y6 = S.conv(x, torch.from_numpy(W).to(device), 3, 1, precision="bf16x6").F.cpu().numpy().astype(np.float64)
     y32 = S.conv(x, torch.from_numpy(W).to(device), 3, 1, precision="f32").F.cpu().numpy().astype(np.float64)
+    y16 = S.conv(x, torch.from_numpy(W).to(device), 3, 1, precision="f16x3").F.cpu().numpy().astype(np.float64)
     _, ref = SO.conv(c, f, W, 3, 1, 1)
     # error relative to sum |a||b| (the natural scale of a dot product's rounding error)
     look = SO.Lookup(c)
@@ -151,8 +152,14 @@ def test_bf16x6_is_fp32_grade_on_wide_dynamic_range(device):
         mag[m] += np.abs(f[idx[m]].astype(np.float64)) @ np.abs(W[k].astype(np.float64))
     e6 = np.abs(y6 - ref).max() / mag.max()
     e32 = np.abs(y32 - ref).max() / mag.max()
+    e16 = np.abs(y16 - ref).max() / mag.max()
+    print("max error / max sum|a||b|: bf16x6 %.2e  f32 %.2e  f16x3 %.2e" % (e6, e32, e16))
+    print("max over outputs of error / sum|a||b|: bf16x6 %.2e  f16x3 %.2e" % (
+        (np.abs(y6 - ref) / (mag + 1e-30)).max(), (np.abs(y16 - ref) / (mag + 1e-30)).max()))
     assert e6 < 4e-7 and e32 < 4e-7, (e6, e32)
     assert (np.abs(y6 - ref) / (mag + 1e-30)).max() < 2e-6
+    # f16x3: 22-bit operands under ONE power-of-two scale per tensor: full accuracy relative to the tensor's magnitude
+    assert e16 < 8e-7, e16
 
 
 @pytest.mark.parametrize("ts", [1, 4])
