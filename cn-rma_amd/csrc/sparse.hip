@@ -1162,17 +1162,25 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
                                               2 * (int64_t)(slices > 1 ? slices : 1) * K * Cin * Cout);
   }
   int bm, bn;
-  // tile choice (measured per layer class on MI355X at the ScanNet shape): wide tiles for wide long
-  // layers; 64-row tiles for short layers (more blocks, less row padding) and for the 32-channel stem
+  // tile choice, measured per layer class and precision on MI355X at the ScanNet shape: f16x3 tiles
+  // need fewer registers and less LDS (4-7 blocks per CU), which moves the optimum to 64-row tiles almost everywhere
   enum { T128x128, T128x64, T64x64, T128x32, T64x128 } shape;
   const bool six = weight_split != nullptr && Cin % 32 == 0;
-  if (Cout <= 32) { shape = T128x32; bm = 128; bn = 32; }
-  else if (six && no_cap < 1000 && Cout >= 256) { shape = T64x128; bm = 64; bn = 128; }
-  else if (no_cap < 4000) { shape = T64x64; bm = 64; bn = 64; }
-  else if (no_cap < 16384) { if (six) { shape = T128x64; bm = 128; bn = 64; } else { shape = T64x64; bm = 64; bn = 64; } }
-  else if (Cout >= 128) { shape = T128x128; bm = 128; bn = 128; }
-  else if (six && Cin <= 32) { shape = T64x64; bm = 64; bn = 64; }
-  else { shape = T128x64; bm = 128; bn = 64; }
+  auto pick = [&](int sh) {
+    static const int bms[] = {128, 128, 64, 128, 64}, bns[] = {128, 64, 64, 32, 128};
+    shape = (decltype(shape))sh; bm = bms[sh]; bn = bns[sh];
+  };
+  if (Cout <= 32) pick(T128x32);
+  else if (six && mode == 1) {
+    if (Cout >= 128) pick(no_cap >= 16384 && no_cap < 100000 ? T128x128 : (no_cap < 1000 && Cout < 256 ? T64x64 : T64x128));
+    else pick(no_cap >= 100000 && Cin > 32 ? T128x64 : T64x64);
+  }
+  else if (six && no_cap < 1000 && Cout >= 256) pick(T64x128);
+  else if (no_cap < 4000) pick(T64x64);
+  else if (no_cap < 16384) pick(six ? T128x64 : T64x64);
+  else if (Cout >= 128) pick(T128x128);
+  else if (six && Cin <= 32) pick(T64x64);
+  else pick(T128x64);
   if (slices == 1 && workspace != nullptr) {
     p.splits = choose_splits(no_cap, Cout, K, bm, bn, ws_bytes);
     p.k_per_split = (int)ceil_div(K, p.splits);
