@@ -28,8 +28,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 # HBM-side traffic of the dominant kernel from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
 # this same command at workload S: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md
 # "HBM") + WRITE_SIZE, KB -> bytes), all sparse_conv_bf16x6 launches of one scene / launches per scene
-PMC_CONV_TRAFFIC_S = dict(bytes_per_launch=(2 * 4805.0e6 * 1.024 + 1140.0e6 * 1.024) / 47.0,
-                          source="profiles/r01_final_pmc_FETCH_SIZE.csv + r01_final_pmc_WRITE_SIZE.csv")
+PMC_CONV_TRAFFIC_S = dict(bytes_per_launch=(2 * 4107.7e6 * 1.024 + 1254.5e6 * 1.024) / 51.0,
+                          source="profiles/r01_f16x3_pmc_FETCH_SIZE.csv + r01_f16x3_pmc_WRITE_SIZE.csv")
+PMC_CONV_TRAFFIC_S_BF16X6 = dict(bytes_per_launch=(2 * 4805.0e6 * 1.024 + 1140.0e6 * 1.024) / 47.0,
+                                 source="profiles/r01_final_pmc_FETCH_SIZE.csv + r01_final_pmc_WRITE_SIZE.csv")
 
 
 def parse():
@@ -295,8 +297,8 @@ def main():
             result["roofline"] = {"kernel": "sparse_conv_bf16x6_kernel (cnrma_sparse_conv_bf16x6)", "bound": "mfma",
                                   "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                                  "traffic": PMC_CONV_TRAFFIC_S["bytes_per_launch"] if args.workload == "S" else None,
-                                  "traffic_source": PMC_CONV_TRAFFIC_S["source"] if args.workload == "S" else None,
+                                  "traffic": PMC_CONV_TRAFFIC_S_BF16X6["bytes_per_launch"] if args.workload == "S" else None,
+                                  "traffic_source": PMC_CONV_TRAFFIC_S_BF16X6["source"] if args.workload == "S" else None,
                                   "note": "fp32-grade conv as 6 bf16 MFMA products per operand pair (3-way exact split); "
                                           "achieved = executed bf16 matrix flops (6 x 2*K*Cin*Cout*rows per launch) / "
                                           "launch time, averaged over the launches of one scene; fp32-equivalent rate = "
