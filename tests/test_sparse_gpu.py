@@ -374,3 +374,65 @@ def test_fcaf3d_forward_vs_oracle(device, n_reg, yaw):
     ok = np.isfinite(b_exp[o2]).all(axis=1) & (np.abs(b_exp[o2]).max(axis=1) < 1e4)
     assert ok.sum() > 0
     np.testing.assert_allclose(b_got[o1][ok], b_exp[o2][ok], rtol=1e-3, atol=1e-3)
+
+
+def _amax(t):
+    return float(t.amax.max()) if t.amax is not None else None
+
+
+def test_f16x3_magnitude_bounds_travel_with_the_tensors(device):
+    """every producer hands its consumers a bound >= max|F| (conv epilogue, split-K reduce, generative transpose,
+    pooling / pruning pass-through, absmax pass for the rest), and the bound is tight (it IS the maximum)"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(21)
+    c, f = rand_sparse(rng, n=6000, span=12, C=64)
+    x = to_st(c, f, 2, device)
+    assert x.amax is None
+    W1 = torch.from_numpy((rng.randn(27, 64, 128) / 30).astype(np.float32)).to(device)
+    W2 = torch.from_numpy((rng.randn(27, 128, 64) / 40).astype(np.float32)).to(device)
+    Wt = torch.from_numpy((rng.randn(8, 64, 32) / 8).astype(np.float32)).to(device)
+    y = S.conv(x, W1, 3, 1, act="relu", precision="f16x3")               # 6000 rows: split over kernel offsets
+    assert abs(float(x.amax.max()) - float(x.F.abs().max())) == 0.0       # absmax pass on first use
+    z = S.conv(y, W2, 3, 2, precision="f16x3")
+    u = S.conv_transpose_generative(z, Wt, act="elu", precision="f16x3")
+    for t in (y, z, u):
+        assert _amax(t) == float(t.F.abs().max()), (_amax(t), float(t.F.abs().max()))
+    p = S.max_pool(y, 2, 2)
+    q = S.prune(y, torch.arange(y.cs.n, device=device) % 3 == 0)
+    assert p.amax is y.amax and q.amax is y.amax
+    # a chain whose magnitude grows by ~1e3 per layer stays accurate: the scales follow the bounds
+    big = torch.from_numpy((rng.randn(27, 64, 64) * 40).astype(np.float32)).to(device)
+    t16 = t32 = to_st(c, f, 2, device)
+    for _ in range(4):
+        t16 = S.conv(t16, big, 3, 1, precision="f16x3")
+        t32 = S.conv(t32, big, 3, 1, precision="f32")
+    rel = float((t16.F - t32.F).abs().max() / t32.F.abs().max())
+    assert float(t32.F.abs().max()) > 1e9 and rel < 5e-6, rel
+
+
+@pytest.mark.parametrize("fs,ws", [(1e-20, 1e15), (1e20, 1e-15), (3e-30, 1.0), (1.0, 2e25)])
+def test_f16x3_scales_are_exact_powers_of_two(device, fs, ws):
+    """operands far outside the fp16 range: the per-tensor scales are powers of two, so the result is the unscaled
+    result times fs*ws up to fp32 rounding of that factor"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(5)
+    c, f = rand_sparse(rng, n=3000, span=10, C=32)
+    W = (rng.randn(27, 32, 64) / 20).astype(np.float32)
+    ref = S.conv(to_st(c, f, 1, device), torch.from_numpy(W).to(device), 3, 1, precision="f32").F.double()
+    got = S.conv(to_st(c, (f * np.float32(fs)).astype(np.float32), 1, device),
+                 torch.from_numpy((W * np.float32(ws)).astype(np.float32)).to(device), 3, 1, precision="f16x3").F.double()
+    k = float(np.float32(fs)) * float(np.float32(ws))
+    err = float((got / k - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, err
+
+
+def test_f16x3_all_zero_and_empty_inputs(device):
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(2)
+    c, f = rand_sparse(rng, n=500, span=6, C=32)
+    W = torch.from_numpy(rng.randn(27, 32, 64).astype(np.float32)).to(device)
+    y = S.conv(to_st(c, np.zeros_like(f), 1, device), W, 3, 1, precision="f16x3")
+    assert float(y.F.abs().max()) == 0.0 and _amax(y) == 0.0
+    shift = torch.full((64,), 0.5, device=device)
+    y = S.conv(to_st(c, np.zeros_like(f), 1, device), W, 3, 1, shift=shift, precision="f16x3")
+    assert float((y.F - 0.5).abs().max()) == 0.0 and _amax(y) == 0.5
