@@ -17,6 +17,9 @@ REF = "/root/reference"
 
 class _Registry:
     def register_module(self, *a, **k):
+        if len(a) == 1 and isinstance(a[0], type) and not k:      # bare `@HEADS.register_module`
+            return a[0]
+
         def deco(cls):
             return cls
         return deco
@@ -105,6 +108,14 @@ def load_reference():
     tr = importlib.import_module("projects.mvsdetection.datasets.pipelines.fcaf3d_transforms")
     ts = importlib.import_module("projects.mvsdetection.datasets.tsdf")
     return rm, head, tr, ts
+
+
+def load_reference_atlas3d():
+    """Returns (backbone3d module, atlas_head module) of the reference (dense 3D U-Net + TSDF head)."""
+    install_stubs()
+    b3 = importlib.import_module("projects.mvsdetection.models.backbone3d")
+    ah = importlib.import_module("projects.mvsdetection.models.atlas_head")
+    return b3, ah
 
 
 def make_raymarching(rm, voxel_dim, voxel_size=0.04, origin=(0.0, 0.0, 0.0), stride=4, rtype="neus",

@@ -178,6 +178,38 @@ def run_point_transforms(tr):
     print("point_transforms.npz written")
 
 
+def run_atlas3d():
+    """dense 3D U-Net + TSDF head of the reference on a small random volume: parameters, input and outputs"""
+    b3, ah = R.load_reference_atlas3d()
+    out = {}
+    for tag, cond in (("plain", False), ("cond", True)):
+        torch.manual_seed(11 + cond)
+        net = b3.AtlasBackbone3D(channels=[2, 4, 8, 16], layers_down=[1, 2, 1, 1], layers_up=[1, 2, 1], drop=0.0,
+                                 zero_init_residual=False, cond_proj=cond, norm="BN").eval()
+        head = ah.AtlasTSDFHead(input_channels=[2, 4, 8], n_scales=3, voxel_size=0.04, label_smoothing=1.05,
+                                sparse_threshold=[0.99, 0.99]).eval()
+        with torch.no_grad():
+            for m in net.modules():                       # non-trivial running statistics
+                if isinstance(m, torch.nn.BatchNorm3d):
+                    m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+                    m.weight.normal_(1, 0.2); m.bias.normal_(0, 0.2)
+            x = torch.randn(1, 2, 16, 16, 8)
+            x[:, :, :5] = 0                               # an unobserved slab (exercises the conditional projection)
+            feats = net(x)
+            tsdf, _ = head(feats)                          # decoder features are already coarse -> fine
+        out[f"{tag}_x"] = x.numpy()
+        for k, v in net.state_dict().items():
+            out[f"{tag}_net.{k}"] = v.numpy()
+        for k, v in head.state_dict().items():
+            out[f"{tag}_head.{k}"] = v.numpy()
+        for i, f in enumerate(feats):
+            out[f"{tag}_feat{i}"] = f.numpy()
+        for k, v in tsdf.items():
+            out[f"{tag}_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "atlas3d.npz"), **out)
+    print("atlas3d.npz", {k: v.shape for k, v in out.items() if "feat" in k or "tsdf" in k})
+
+
 def main():
     torch.set_num_threads(8)
     rm, head, tr, ts = R.load_reference()
@@ -192,7 +224,12 @@ def main():
     run_scene(rm, tr, "edge_empty_view", sc)
     run_decode(head)
     run_point_transforms(tr)
+    run_atlas3d()
 
+
+if __name__ == "__main__" and "--atlas3d" in sys.argv:
+    run_atlas3d()
+    sys.exit(0)
 
 if __name__ == "__main__":
     main()

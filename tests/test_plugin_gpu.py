@@ -76,3 +76,44 @@ def test_module_level_functions_keep_the_reference_signatures(device):
     oo, od = O.ray_params(proj[0].cpu(), feat.shape[2], feat.shape[3])
     assert tuple(o.shape) == (1, 3, feat.shape[2] * feat.shape[3])
     assert count_mismatch(d[0], od) == 0 and count_mismatch(o[0, :, 0], oo) == 0
+
+
+def test_raymarching_with_atlas3d_predicts_its_own_tsdf(device, tmp_path):
+    """config with backbone_3d + tsdf_head: dense unprojection -> 3D U-Net -> TSDF head ->
+    ray marching on the PREDICTED scene_tsdf_004 -> FCAF3D.  The TSDF used by the march equals the CPU evaluation
+    of the same torch modules on the same volume; the aggregated points equal the oracle's on that TSDF."""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model
+    from cnrma_amd import synth
+    from oracle import rma_oracle as O
+    sc = synth.make_scene("tiny", seed=5)
+    C = sc["features"].shape[2]
+    cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+    m = dict(cfg["model"])
+    m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
+             detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34),
+             backbone_3d=dict(type="AtlasBackbone3D", channels=[C, 16, 32], layers_down=[1, 1, 1], layers_up=[1, 1], drop=0.0,
+                              zero_init_residual=False, cond_proj=False, norm="BN"),
+             tsdf_head=dict(type="AtlasTSDFHead", input_channels=[C, 16], n_scales=2, voxel_size=0.04, label_smoothing=1.05,
+                            sparse_threshold=[0.99]))
+    torch.manual_seed(1)
+    model = build_model(m)
+    model.detection_head.init_weights()
+    model = model.to(device).eval()
+    data = dict(features=[sc["features"][:, 0].to(device)], projection=[sc["projection"][:, 0].to(device)],
+                offset=[torch.zeros(3, device=device)], scene=["s"])
+    with torch.no_grad():
+        assert model(return_loss=False, **data) == [{}]
+        vol = model.volume.cpu()
+        net, head = model.backbone3d.cpu().float(), model.tsdf_head.cpu()
+        tsdf_cpu = head(net(vol))[0]["scene_tsdf_004"]
+    assert tuple(tsdf_cpu.shape) == (1, 1, *sc["dims"])
+    # the march ran on the GPU prediction; rebuild it there and compare with the CPU evaluation of the same modules
+    model = model.to(device)
+    with torch.no_grad():
+        tsdf_gpu = model.tsdf_head(model.backbone3d(model.volume))[0]["scene_tsdf_004"].cpu()
+    np.testing.assert_allclose(tsdf_gpu.numpy(), tsdf_cpu.numpy(), rtol=1e-3, atol=2e-4)
+    pts = O.aggregate_rma(sc["projection"][:, 0], sc["features"][:, 0], tsdf_gpu[0, 0], sc["dims"], 0.04, sc["origin"], sc["stride"])
+    got = model.points_detection[0].cpu()
+    assert got.shape == pts.shape and count_mismatch(got[:, :3], pts[:, :3]) == 0
+    assert os.path.exists(tmp_path / "r" / "s" / "s_bbox_raw.npz")
