@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--workload", default="S", help="S = ScanNet config (40 views, 32ch 120x160 -> 192x192x80); St; tiny")
     ap.add_argument("--streams", type=int, default=3,
                     help="scenes in flight per GPU (each on its own HIP stream + host thread); 1 = strictly sequential")
+    ap.add_argument("--batch", type=int, default=2,
+                    help="scenes per sparse-network pass (their voxels are collated into one multi-scene tensor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -178,6 +180,8 @@ def main():
     backbone, head = build_model(C, device)
     cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
 
+    scene_in = dict(features=feat, projection=proj, tsdf=tsdf)
+
     def step():
         out = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
         dets = pipeline.gather_detections(out["bboxes"], out["scores"])
@@ -193,7 +197,7 @@ def main():
         latency-bound kernels of one scene overlap the big kernels of another (scenes are independent).  The RCCL
         all-gather of detections is issued by the main thread, in scene order, once the workers have joined
         (collectives of one communicator must not be enqueued concurrently from several threads)."""
-        if args.streams <= 1:
+        if args.streams <= 1 and args.batch <= 1:
             o = None
             for _ in range(n):
                 o, _ = step()
@@ -203,14 +207,21 @@ def main():
         last = [None] * args.streams
         errs = []
 
+        B = max(1, args.batch)
+        groups = [list(range(g, min(n, g + B))) for g in range(0, n, B)]       # scene ids per network pass
+
         def worker(w):
             try:
                 torch.cuda.set_device(local_rank)
                 with torch.cuda.stream(streams[w]):
-                    for i in range(w, n, args.streams):
-                        o = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
-                        dets[i] = (o["bboxes"], o["scores"])
-                        last[w] = o
+                    for g in groups[w::args.streams]:
+                        if B == 1:
+                            outs = [pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)]
+                        else:
+                            outs = pipeline.forward_scenes(cfg, backbone, head, [scene_in] * len(g))
+                        for i, o in zip(g, outs):
+                            dets[i] = (o["bboxes"], o["scores"])
+                        last[w] = outs[-1]
                     streams[w].synchronize()
             except Exception as e:          # noqa: BLE001
                 errs.append(e)
@@ -226,10 +237,11 @@ def main():
                 pipeline.gather_detections(b, sc_)
         return next(o for o in last if o is not None)
 
-    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if args.streams > 1 else []
+    args.streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if (args.streams > 1 or args.batch > 1) else []
     step()                                   # one sequential scene first: fills the weight / offset caches
     torch.cuda.synchronize()
-    out = run_steps(max(args.warmup, args.streams))
+    out = run_steps(max(args.warmup, args.streams * max(1, args.batch)))
     barrier()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
@@ -249,8 +261,10 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}), grid "
                                f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000, "
-                               f"FCAF3D MinkResNet34 + head (18 classes), 1 scene per GPU per step",
-                   "scenes_in_flight": args.streams, "M_rows": out["M"], "M_selected": out["M_selected"], "M_unique": out["M_unique"],
+                               f"FCAF3D MinkResNet34 + head (18 classes), 1 scene per GPU per step "
+                               f"({max(1, args.batch)} scenes share one sparse-network pass, {args.streams} passes in flight)",
+                   "scenes_in_flight": args.streams * max(1, args.batch), "scenes_per_network_pass": max(1, args.batch),
+                   "M_rows": out["M"], "M_selected": out["M_selected"], "M_unique": out["M_unique"],
                    "level_rows": out["level_rows"], "head_rows": out["head_rows"]},
     }
 

@@ -55,6 +55,36 @@ class StageTimer:
 
 
 @torch.no_grad()
+def forward_scenes(cfg, backbone, head, scenes):
+    """Several scenes through ONE sparse network pass.  scenes: list of dicts(features [V,C,H,W], projection [V,3,4],
+    tsdf [X,Y,Z], offset=(0,0,0)).  The geometric half (dense unprojection, ray marching, selection, voxelisation)
+    runs per scene; the scenes' voxels are then collated into one multi-scene sparse tensor (batch id = list index,
+    ray_marching.py:328-330 builds exactly that for B samples) for the backbone + neck/head, whose ~300 small launches
+    and split-K tails are thereby shared; decode is per scene.  Returns one dict per scene like forward_scene()."""
+    parts, infos = [], []
+    for sc_ in scenes:
+        feats = rma.to_nhwc(sc_["features"])
+        volume, count = rma.backproject_accum(feats, sc_["projection"], cfg.dims, cfg.voxel_size, cfg.origin, cfg.stride)
+        proj_inv = rma.projection_inverse(sc_["projection"], cfg.stride).to(feats.device, non_blocking=True)
+        coords, pfeats, info = rma.aggregate_points(
+            feats, proj_inv, sc_["tsdf"], cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
+            cfg.ray_marching_type, cfg.depth_points, offset=sc_.get("offset", (0.0, 0.0, 0.0)), max_points=cfg.max_points,
+            sampler=cfg.sampler, mask=sc_.get("mask"))
+        parts.append((coords, pfeats))
+        infos.append(dict(info, volume=volume, count=count))
+    x = S.sparse_collate(parts, cfg.voxel_size_fcaf3d)
+    levels = backbone(x)
+    cen, box, cls, pts, scn = map(list, head(levels, fused=True))
+    dets = head.get_bboxes_fused(cen, box, cls, pts, scn, len(scenes))
+    outs = []
+    for b, (bboxes, scores) in enumerate(dets):
+        outs.append(dict(bboxes=bboxes, scores=scores, M=infos[b]["M"], M_selected=infos[b]["M_selected"],
+                         M_unique=x.cs.batch_counts()[b], volume=infos[b]["volume"], count=infos[b]["count"],
+                         level_rows=[len(l) for l in levels], head_rows=[len(c[0]) for c in cen]))
+    return outs
+
+
+@torch.no_grad()
 def forward_scene(cfg, backbone, head, features_nchw, projections, tsdf, offset=(0.0, 0.0, 0.0), dense=True,
                   timing=False, mask=None, proj_inv=None):
     """One scene forward.  features_nchw [V,C,H,W] device fp32 (the 2D backbone's layout), projections [V,3,4]

@@ -70,10 +70,21 @@ class CoordSet:
         self.stride = int(stride)
         self.device = coords.device
         self.n_batch = n_batch     # number of scenes in the tensor (the reference is structurally 1 per GPU)
+        self.scene_major = n_batch <= 1   # rows of one scene contiguous and scenes in order (set by collate / strided)
+        self._counts = None
         self._map = cmap
         self._nbr = {}        # (kernel_size, id(out CoordSet)) -> nbr table
         self._children = {}   # new_stride -> CoordSet
         self._offsets = {}
+
+    def batch_counts(self):
+        """rows per scene (host ints; one device->host read per coordinate set, cached)"""
+        if self._counts is None:
+            if self.n_batch <= 1:
+                self._counts = [self.n]
+            else:
+                self._counts = torch.bincount(self.C[:, 0].long(), minlength=self.n_batch).tolist()
+        return self._counts
 
     @property
     def cmap(self):
@@ -94,7 +105,9 @@ class CoordSet:
             call("cnrma_sparse_stride_coords", ptr(self.C), self.n, None, ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
                  ptr(n_out), ptr(ws), stream())
             n = int(n_out.item())
-            self._children[ns] = CoordSet(out[:n], ns, m, self.n_batch)
+            child = CoordSet(out[:n], ns, m, self.n_batch)
+            child.scene_major = self.scene_major          # first-occurrence order keeps the scenes apart and in order
+            self._children[ns] = child
         return self._children[ns]
 
     def neighbours(self, out_set, kernel_size, offset_stride, method="auto"):
@@ -227,7 +240,10 @@ def sparse_collate(list_of_coords_feats, voxel_size):
         return parts[0][0]
     C = torch.cat([p[0].C for p in parts])
     F = torch.cat([p[0].F for p in parts])
-    return SparseTensor(F, CoordSet(C, 1, None, len(parts)))
+    cs = CoordSet(C, 1, None, len(parts))
+    cs.scene_major = True
+    cs._counts = [len(p[0]) for p in parts]
+    return SparseTensor(F, cs)
 
 
 def fold_bn(bn, bias=None):
@@ -420,8 +436,19 @@ def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
     ws = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=x.device)
     w = weight.contiguous().view(-1).float() if weight is not None else None
     b = bias.contiguous().view(-1).float() if bias is not None else None
-    call("cnrma_sparse_instnorm_f32", ptr(x.F.contiguous()), n, None, C, ptr(w), ptr(b), float(eps), int(relu), ptr(out),
-         ptr(ws), stream())
+    src = x.F.contiguous()
+    if x.cs.n_batch <= 1:
+        if n:
+            call("cnrma_sparse_instnorm_f32", ptr(src), n, None, C, ptr(w), ptr(b), float(eps), int(relu), ptr(out), ptr(ws),
+                 stream())
+    else:                                   # statistics per scene (MinkowskiInstanceNorm): one pass per row segment
+        assert x.cs.scene_major, "instance norm of a multi-scene tensor needs scene-major rows"
+        r0 = 0
+        for nb in x.cs.batch_counts():
+            if nb:
+                call("cnrma_sparse_instnorm_f32", ptr(src[r0:r0 + nb]), nb, None, C, ptr(w), ptr(b), float(eps), int(relu),
+                     ptr(out[r0:r0 + nb]), ptr(ws), stream())
+            r0 += nb
     return SparseTensor(out, x.cs)
 
 

@@ -94,7 +94,9 @@ class FCAF3DHead(nn.Module):
         return super().train(mode)
 
     # ---- forward (reference :107-139, :275-298) ---------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, fused=False):
+        """fused=True (eval only): several scenes stay in ONE row set per level -- every output list has a single entry
+        and a fifth list holds the rows' scene ids; decode with get_bboxes_fused()."""
         outs = []
         inputs = x
         x = inputs[-1]
@@ -105,9 +107,9 @@ class FCAF3DHead(nn.Module):
                 x = inputs[i] + x                       # coordinate union, features added (:114)
                 x = self._prune(x, scores)
             out = getattr(self, f"out_block_{i}")(x)
-            out = self.forward_single(out, self.scales[i])
+            out = self.forward_single(out, self.scales[i], fused)
             scores = out[-1]
-            outs.append(out[:-1])
+            outs.append(out[:-1] + ([out[-1].C[:, 0]],) if fused else out[:-1])
         return zip(*outs[::-1])
 
     def _prune(self, x, scores):
@@ -115,19 +117,22 @@ class FCAF3DHead(nn.Module):
         if self.pts_threshold < 0:
             return x
         with torch.no_grad():
-            perms = x.decomposition_permutations
-            if all(len(p) <= self.pts_threshold for p in perms):
+            counts = x.cs.batch_counts()
+            if all(c <= self.pts_threshold for c in counts):
                 return x                                # the top-k keeps every row: pruning is the identity
             interpolated = scores.features_at_coordinates(x.C.float())
-            if len(perms) == 1:
-                # single scene: radix-select keep-mask instead of torch.topk's sort (same row set; ties by index)
+            # radix-select keep-mask instead of torch.topk's sort (same row set; ties by index)
+            if len(counts) == 1:
                 mask = S.topk_mask(interpolated, self.pts_threshold)
-            else:
-                mask = torch.zeros(len(interpolated), dtype=torch.bool, device=x.device)
-                for p in perms:
-                    k = min(len(p), self.pts_threshold)
-                    ids = torch.topk(interpolated[p].squeeze(1), k, sorted=False).indices
-                    mask[p[ids]] = True
+            else:                                       # per scene: the other scenes' rows are masked to -inf
+                flat, scene = interpolated.view(-1), x.C[:, 0]
+                low = torch.full_like(flat, float("-inf"))
+                mask = None
+                for b, nb in enumerate(counts):
+                    mine = scene == b
+                    m = mine.to(torch.uint8) if nb <= self.pts_threshold else \
+                        S.topk_mask(torch.where(mine, flat, low), self.pts_threshold)
+                    mask = m if mask is None else mask | m
         return self.pruning(x, mask)
 
     def _head_weights(self):
@@ -143,8 +148,8 @@ class FCAF3DHead(nn.Module):
             self._fused_head = (w, b.contiguous())
         return self._fused_head
 
-    def forward_single(self, x, scale):
-        if self.training or x.cs.n_batch > 1:
+    def forward_single(self, x, scale, fused=False):
+        if self.training or (x.cs.n_batch > 1 and not fused):
             if self.training:
                 centerness = self.centerness_conv(x).F
                 cls_score = self.cls_conv(x).F
@@ -201,6 +206,35 @@ class FCAF3DHead(nn.Module):
                                                [x[i] for x in cls_scores], [x[i] for x in points],
                                                scene_ids[i] if scene_ids is not None else None, save_path))
         return out
+
+    def get_bboxes_fused(self, centernesses, bbox_preds, cls_scores, points, scenes, n_scenes):
+        """decode of forward(..., fused=True): per level ONE row set for all scenes + the rows' scene ids.  Per scene the
+        nms_pre best rows by max class score x centerness are picked with the other scenes masked out (reference
+        _get_bboxes_single :247-256 per scene).  Returns [(bboxes, scores)] per scene."""
+        nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
+        per_scene = [([], []) for _ in range(n_scenes)]
+        for cen, box, cls, pts, sc in zip(centernesses, bbox_preds, cls_scores, points, scenes):
+            cen, box, cls, pts, sc = cen[0], box[0], cls[0], pts[0], sc[0]
+            if n_scenes == 1:
+                ids = None
+                if len(cls) > nms_pre > 0:
+                    ids = S.max_scores(cls, cen).topk(nms_pre)[1]
+                groups = [ids]
+            else:
+                # ONE stable sort per level on the key (scene, descending score): every scene's rows become a contiguous
+                # run in rank order, of which the first nms_pre are taken (scores are >= 0: their bit patterns order them)
+                counts = torch.bincount(sc.long(), minlength=n_scenes).tolist()
+                bits = S.max_scores(cls, cen).view(torch.int32).long()
+                order = torch.sort((sc.long() << 32) | (0xFFFFFFFF - bits), stable=True)[1]
+                groups, r0 = [], 0
+                for nb in counts:
+                    groups.append(order[r0:r0 + (min(nb, nms_pre) if nms_pre > 0 else nb)])
+                    r0 += nb
+            for b, ids in enumerate(groups):
+                bx, scr = S.select_decode(ids, cls, cen, box, pts, self.yaw_parametrization)
+                per_scene[b][0].append(bx)
+                per_scene[b][1].append(scr)
+        return [(torch.cat(bx), torch.cat(scr)) for bx, scr in per_scene]
 
     def loss(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
         if self.loss_cls is None:

@@ -145,3 +145,40 @@ def test_concurrent_scenes_on_separate_streams_match_sequential(scene, device):
         assert len(outs[w]) == per_thread
         for b, sc in outs[w]:
             assert torch.equal(b, ref["bboxes"]) and torch.equal(sc, ref["scores"])
+
+
+def test_batched_scenes_equal_single_scenes(device):
+    """pipeline.forward_scenes (several scenes through one sparse network pass: collated voxels, per-scene instance norm,
+    per-scene pruning and decode) gives each scene the detections of its own forward_scene pass"""
+    import bench
+    from cnrma_amd import pipeline, synth
+    shape = "St"
+    V, C, H, W, dims, stride = synth.SHAPES[shape]
+    torch.manual_seed(0)
+    backbone, head = bench.build_model(C, device)
+    head.pts_threshold = 3000                     # make the per-scene pruning bite on the finest level
+    cfg = pipeline.SceneConfig(dims, stride=stride, max_points=None)      # no random point selection: deterministic
+    scenes = []
+    for seed in (0, 1, 2):
+        sc = synth.make_scene(shape, seed=seed)
+        scenes.append(dict(features=sc["features"][:, 0].to(device), projection=sc["projection"][:, 0],
+                           tsdf=sc["tsdf"][0, 0].to(device), offset=(0.1 * seed, 0.0, -0.05 * seed)))
+    singles = [pipeline.forward_scene(cfg, backbone, head, s_["features"], s_["projection"], s_["tsdf"], offset=s_["offset"])
+               for s_ in scenes]
+    for s_, a in zip(scenes, singles):             # a batch of one is the single-scene path
+        b = pipeline.forward_scenes(cfg, backbone, head, [s_])[0]
+        assert torch.equal(a["bboxes"], b["bboxes"]) and torch.equal(a["scores"], b["scores"])
+    batched = pipeline.forward_scenes(cfg, backbone, head, scenes)
+    assert len(batched) == 3
+    for a, b in zip(singles, batched):
+        assert a["M"] == b["M"] and a["M_unique"] == b["M_unique"]
+        assert a["bboxes"].shape == b["bboxes"].shape and a["bboxes"].shape[0] > 100
+        ka = a["scores"].max(dim=1)[0].argsort(descending=True, stable=True)
+        kb = b["scores"].max(dim=1)[0].argsort(descending=True, stable=True)
+        # the same rows were selected and they rank the same, up to swaps between near-equal scores (the split over
+        # kernel offsets of a layer depends on its row count, so sums are rounded in a different order)
+        ra, rb = a["scores"][ka].cpu().numpy(), b["scores"][kb].cpu().numpy()
+        sa, sb = a["bboxes"][ka].cpu().numpy(), b["bboxes"][kb].cpu().numpy()
+        same = np.isclose(ra, rb, rtol=2e-4, atol=2e-6).all(axis=1) & np.isclose(sa, sb, rtol=1e-3, atol=1e-4).all(axis=1)
+        assert same.mean() > 0.995, same.mean()
+        np.testing.assert_allclose(np.sort(ra.max(axis=1)), np.sort(rb.max(axis=1)), rtol=2e-4, atol=2e-6)
