@@ -9,10 +9,14 @@ sc = synth.make_scene("S", seed=0)
 feat, proj, tsdf = sc["features"][:, 0].to(dev), sc["projection"][:, 0], sc["tsdf"][0, 0].to(dev)
 backbone, head = bench.build_model(C, dev)
 cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
+B = int(os.environ.get("CNRMA_B", "1"))
+scene = dict(features=feat, projection=proj, tsdf=tsdf)
+run = (lambda: pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)) if B == 1 else \
+      (lambda: pipeline.forward_scenes(cfg, backbone, head, [scene] * B))
 for _ in range(2):
-    pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+    run()
 prof = bench.KernelProfile(); prof.install()
-pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+run()
 prof.uninstall(); torch.cuda.synchronize()
 tot = 0
 for name, a, e0, e1 in prof.records:
