@@ -617,12 +617,17 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
 // fp32.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each):
 // 2.67x fewer matrix-pipe cycles at the accuracy of an fp32 fma chain.  Weights are pre-split / pre-transposed once
 // (cnrma_sparse_conv_prepare_weights); features are split while they are staged into LDS.
-// LDS images: [plane][row][k] bf16 with a row stride of 40 elements (80 B): the ds_read_b128 fragment reads of
-// 16 consecutive rows then fall on 16 distinct 16-byte bank slots.
+// LDS images: [plane][row][k] bf16, see lds_slot() below.
 // ================================================================================================================
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-constexpr int LDK = 40;
+// LDS images: [plane][row][32 k] 16-bit, unpadded 64-byte rows; the four 16-byte slots of a row are XORed with bits
+// 2..3 of the row.  Fragment reads (ds_read_b128: 16-lane groups of rows {0-3,12-15,20-27} / {4-11,16-19,28-31}, same
+// k-slot) then fall on 16 distinct 16-byte bank positions, and the staging stores (ds_write_b64 / _b128: consecutive
+// lanes fill whole rows) stay a permutation of contiguous 128 bytes -- both conflict-free.  (The former padded 80-byte
+// rows were conflict-free for the reads only: SQ_LDS_BANK_CONFLICT was 33 % of SQ_LDS_IDX_ACTIVE, profiles/.)
+constexpr int LDK = 32;
+__device__ __forceinline__ int lds_slot(int row, int slot) { return row * LDK + ((slot ^ ((row >> 2) & 3)) << 3); }
 
 __device__ __forceinline__ void split3(const float4& v, uint2& h, uint2& m, uint2& l) {
   uint16_t hh[4], mm[4], ll[4];
@@ -805,15 +810,17 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
       if constexpr (MODE == 0) {
         uint2 h, m, l;
         split3(v, h, m, l);
-        *reinterpret_cast<uint2*>(a0 + row * LDK + kc * 4) = h;
-        *reinterpret_cast<uint2*>(a1 + row * LDK + kc * 4) = m;
-        *reinterpret_cast<uint2*>(a2 + row * LDK + kc * 4) = l;
+        const int o = lds_slot(row, kc >> 1) + (kc & 1) * 4;
+        *reinterpret_cast<uint2*>(a0 + o) = h;
+        *reinterpret_cast<uint2*>(a1 + o) = m;
+        *reinterpret_cast<uint2*>(a2 + o) = l;
       } else {
         v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
         uint2 h, m;
         split2(v, h, m);
-        *reinterpret_cast<uint2*>(a0 + row * LDK + kc * 4) = h;
-        *reinterpret_cast<uint2*>(a1 + row * LDK + kc * 4) = m;
+        const int o = lds_slot(row, kc >> 1) + (kc & 1) * 4;
+        *reinterpret_cast<uint2*>(a0 + o) = h;
+        *reinterpret_cast<uint2*>(a1 + o) = m;
       }
     }
   }
@@ -840,9 +847,9 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
     for (int i = 0; i < N; ++i) {
       const int idx = tid + i * 256;
       const int row = idx >> 2, g = idx & 3;
-      *reinterpret_cast<u32x4_t*>(a0 + row * LDK + g * 8) = h[i];
-      *reinterpret_cast<u32x4_t*>(a1 + row * LDK + g * 8) = m[i];
-      *reinterpret_cast<u32x4_t*>(a2 + row * LDK + g * 8) = l[i];
+      *reinterpret_cast<u32x4_t*>(a0 + lds_slot(row, g)) = h[i];
+      *reinterpret_cast<u32x4_t*>(a1 + lds_slot(row, g)) = m[i];
+      *reinterpret_cast<u32x4_t*>(a2 + lds_slot(row, g)) = l[i];
     }
   }
 };
@@ -952,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
         uint4 v = rb[i];
         const bool ok = (b_ok >> i) & 1u;
         v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-        *reinterpret_cast<uint4*>(&Bs[pl][row * LDK + chunk * 8]) = v;
+        *reinterpret_cast<uint4*>(&Bs[pl][lds_slot(row, chunk)]) = v;
       }
     }
   };
@@ -975,8 +982,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
       if (nk >= 0) load_src(next_active(nk), src_nxt);
     }
     if (nk >= 0) load_stage(nk, ncin, src_cur);
-    const int a_off = (wr * (32 * TM) + (lane & 31)) * LDK + (lane >> 5) * 8;
-    const int b_off = (wc * (32 * TN) + (lane & 31)) * LDK + (lane >> 5) * 8;
+    const int a_row = wr * (32 * TM) + (lane & 31), b_row = wc * (32 * TN) + (lane & 31), fhalf = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
       if constexpr (MODE == 0) {
@@ -984,11 +990,11 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) af[a][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][a_off + a * 32 * LDK + ks]);
+          for (int pl = 0; pl < 3; ++pl) af[a][pl] = *reinterpret_cast<const bf16x8_t*>(&As[pl][lds_slot(a_row + a * 32, (ks >> 3) + fhalf)]);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bf[b][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][b_off + b * 32 * LDK + ks]);
+          for (int pl = 0; pl < 3; ++pl) bf[b][pl] = *reinterpret_cast<const bf16x8_t*>(&Bs[pl][lds_slot(b_row + b * 32, (ks >> 3) + fhalf)]);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1007,11 +1013,11 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) af[a][pl] = *reinterpret_cast<const f16x8_t*>(&As[pl][a_off + a * 32 * LDK + ks]);
+          for (int pl = 0; pl < 2; ++pl) af[a][pl] = *reinterpret_cast<const f16x8_t*>(&As[pl][lds_slot(a_row + a * 32, (ks >> 3) + fhalf)]);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) bf[b][pl] = *reinterpret_cast<const f16x8_t*>(&Bs[pl][b_off + b * 32 * LDK + ks]);
+          for (int pl = 0; pl < 2; ++pl) bf[b][pl] = *reinterpret_cast<const f16x8_t*>(&Bs[pl][lds_slot(b_row + b * 32, (ks >> 3) + fhalf)]);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
