@@ -44,6 +44,7 @@ SIGNATURES = {
     "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, P]),
     "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
     "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
+    "cnrma_sparse_conv_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights": (c_int, [P, I, I, I, P, P]),
     "cnrma_sparse_split_features": (c_int, [P, L, P, I, P, P]),
     "cnrma_sparse_conv_bf16x6": (c_int, [P, P, L, I, P, I, P, I, P, P, P, I, P, P, L, P, P, c_size_t, P]),

@@ -663,14 +663,18 @@ __device__ __forceinline__ void split2_f16(float x, uint16_t& h, uint16_t& m) {
   m = __builtin_bit_cast(uint16_t, mm);
 }
 
-__device__ __forceinline__ void split2(const float4& v, uint2& h, uint2& m) {
-  uint16_t hh[4], mm[4];
-  split2_f16(v.x, hh[0], mm[0]);
-  split2_f16(v.y, hh[1], mm[1]);
-  split2_f16(v.z, hh[2], mm[2]);
-  split2_f16(v.w, hh[3], mm[3]);
-  h = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
-  m = make_uint2((uint32_t)mm[0] | ((uint32_t)mm[1] << 16), (uint32_t)mm[2] | ((uint32_t)mm[3] << 16));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+// (v * scale) -> fp16 pairs h, m in packed arithmetic: v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32 (3 VALU per value)
+__device__ __forceinline__ void split2(const float4& v, float scale, uint2& h, uint2& m) {
+  f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  a *= scale; b *= scale;
+  const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
+  const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);   // exact
+  const f16x2_t ma = __builtin_convertvector(ra, f16x2_t), mb = __builtin_convertvector(rb, f16x2_t);
+  h = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  m = make_uint2(__builtin_bit_cast(uint32_t, ma), __builtin_bit_cast(uint32_t, mb));
 }
 
 // A tensor's magnitude bound lives in AMAX_SLOTS words, one per 64-byte line: a block publishes ONE candidate (wave
@@ -719,20 +723,25 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ i
   block_amax_publish(out, mx, sh4);
 }
 
-// W fp32 [K][Cin][Cout] -> Wt fp16 [2 planes][K][Cout][Cin] scaled by f16_scale_for(*amax), + trailer float = *amax
+// prepared weight images pad Cout to a multiple of 128 with zero rows (the largest column tile): B-tile loads need no
+// bounds check and no select
+__host__ __device__ inline int conv_cout_padded(int Cout) { return (Cout + 127) & ~127; }
+
+// W fp32 [K][Cin][Cout] -> Wt fp16 [2 planes][K][Cout_p][Cin] scaled by f16_scale_for(*amax), + trailer float = *amax
 __global__ __launch_bounds__(256) void prep_weights_f16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int K,
                                                                int Cin, int Cout, const float* __restrict__ amax) {
-  const int64_t total = (int64_t)K * Cin * Cout;
+  const int Cp = conv_cout_padded(Cout);
+  const int64_t total = (int64_t)K * Cin * Cp;
   const float am = read_amax(amax);
   const float sc = f16_scale_for(am);
   if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(wt + 2 * total) = am;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int cin = (int)(t % Cin);
     const int64_t q = t / Cin;
-    const int co = (int)(q % Cout);
-    const int k = (int)(q / Cout);
+    const int co = (int)(q % Cp);
+    const int k = (int)(q / Cp);
     uint16_t hh, mm;
-    split2_f16(w[((int64_t)k * Cin + cin) * Cout + co] * sc, hh, mm);
+    split2_f16(co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] * sc : 0.0f, hh, mm);
     wt[t] = hh;
     wt[total + t] = mm;
   }
@@ -764,13 +773,14 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float* __rest
 // W fp32 [K][Cin][Cout] -> Wt bf16 [3 planes][K][Cout][Cin]
 __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
                                                            int Cin, int Cout) {
-  const int64_t total = (int64_t)K * Cin * Cout;
+  const int Cp = conv_cout_padded(Cout);
+  const int64_t total = (int64_t)K * Cin * Cp;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int cin = (int)(t % Cin);
     const int64_t q = t / Cin;
-    const int co = (int)(q % Cout);
-    const int k = (int)(q / Cout);
-    const float a = w[((int64_t)k * Cin + cin) * Cout + co];
+    const int co = (int)(q % Cp);
+    const int k = (int)(q / Cp);
+    const float a = co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] : 0.0f;
     uint16_t hh, mm, ll;
     split3_trunc(a, hh, mm, ll);
     uint16_t* o = reinterpret_cast<uint16_t*>(wt);
@@ -806,8 +816,8 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
       const int row = idx >> 3, kc = idx & 7;
       float4 v = r[i];
       const bool k = (ok >> i) & 1u;
-      v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
       if constexpr (MODE == 0) {
+        v.x = k ? v.x : 0.f; v.y = k ? v.y : 0.f; v.z = k ? v.z : 0.f; v.w = k ? v.w : 0.f;
         uint2 h, m, l;
         split3(v, h, m, l);
         const int o = lds_slot(row, kc >> 1) + (kc & 1) * 4;
@@ -815,9 +825,9 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
         *reinterpret_cast<uint2*>(a1 + o) = m;
         *reinterpret_cast<uint2*>(a2 + o) = l;
       } else {
-        v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
+        // a missing neighbour was loaded from row 0 (clamped address): its scale is 0 instead of a select per value
         uint2 h, m;
-        split2(v, h, m);
+        split2(v, k ? a_scale : 0.0f, h, m);
         const int o = lds_slot(row, kc >> 1) + (kc & 1) * 4;
         *reinterpret_cast<uint2*>(a0 + o) = h;
         *reinterpret_cast<uint2*>(a1 + o) = m;
@@ -876,8 +886,9 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   const int cout0 = blockIdx.y * BN;
   const int zs = blockIdx.z;
   const int Cin = p.Cin, Cout = p.Cout, K = p.K;
-  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * K * Cin * Cout;
-  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout : 0);
+  const int Cout_p = conv_cout_padded(Cout);     // prepared images pad Cout with zero rows: no bounds check on B
+  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * K * Cin * Cout_p;
+  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout_p : 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid / WAVES_N, wc = wid % WAVES_N;
   float a_scale = 1.0f, out_scale = 1.0f;
@@ -927,26 +938,20 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
   AStageRegs<IN_SPLIT, A_ITERS> areg;
-  uint4 rb[B_ITERS];
-  unsigned b_ok = 0;
+  u32x4_t rb[B_ITERS];                            // first-class vectors (HIP's uint4 struct arrays end up in scratch)
   const int G8 = Cin >> 3;
   const float* in_f32 = p.in;
   const uint16_t* in_sp = p.in_split;
   const int64_t in_zero = p.in_zero_row;
   auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
-    b_ok = 0;
     areg.load(in_f32, in_sp, in_zero, tid, srcs, cin0, G8, Cin);
-    const __bf16* Wk = Wz + (int64_t)k * Cout * Cin;
+    const __bf16* Wk = Wz + (int64_t)k * Cout_p * Cin + cin0;
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
-      int idx = tid + i * 256;                         // over [plane][row][chunk]
-      const bool in_tile = idx < B_CHUNKS;
-      idx = in_tile ? idx : 0;
+      int idx = tid + i * 256;                         // over [plane][row][chunk]; the lane part is loop invariant
+      idx = idx < B_CHUNKS ? idx : 0;
       const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
-      const int co = cout0 + row;
-      const bool ok = in_tile && co < Cout;
-      rb[i] = *reinterpret_cast<const uint4*>(Wk + pl * plane_elems + (int64_t)(ok ? co : 0) * Cin + cin0 + chunk * 8);
-      b_ok |= (ok ? 1u : 0u) << i;
+      rb[i] = *reinterpret_cast<const u32x4_t*>(Wk + pl * plane_elems + (int64_t)(cout0 + row) * Cin + chunk * 8);
     }
   };
   auto store_stage = [&]() {
@@ -956,10 +961,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
       const int idx = tid + i * 256;
       if (idx < B_CHUNKS) {
         const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
-        uint4 v = rb[i];
-        const bool ok = (b_ok >> i) & 1u;
-        v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
-        *reinterpret_cast<uint4*>(&Bs[pl][lds_slot(row, chunk)]) = v;
+        *reinterpret_cast<u32x4_t*>(&Bs[pl][lds_slot(row, chunk)]) = rb[i];
       }
     }
   };
@@ -1165,7 +1167,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   if (mode == 1) {
     if (weight_split == nullptr || in_amax == nullptr || in_split != nullptr || out_split != nullptr) return CNRMA_EINVAL;
     p.w_amax = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(weight_split) +
-                                              2 * (int64_t)(slices > 1 ? slices : 1) * K * Cin * Cout);
+                                              2 * (int64_t)(slices > 1 ? slices : 1) * K * Cin * conv_cout_padded(Cout));
   }
   int bm, bn;
   // tile choice, measured per layer class and precision on MI355X at the ScanNet shape: f16x3 tiles
@@ -1601,7 +1603,7 @@ extern "C" int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32
 extern "C" int cnrma_sparse_conv_prepare_weights(const float* weight, int K, int Cin, int Cout, void* weight_split,
                                                  void* stream) {
   if (K <= 0 || Cin <= 0 || Cout <= 0) return CNRMA_EINVAL;
-  int64_t total = (int64_t)K * Cin * Cout;
+  int64_t total = (int64_t)K * Cin * conv_cout_padded(Cout);
   int64_t blocks = ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
@@ -1634,24 +1636,29 @@ extern "C" int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n
   return 0;
 }
 
+extern "C" size_t cnrma_sparse_conv_weight_bytes(int K, int Cin, int Cout) {
+  return (size_t)3 * K * Cin * conv_cout_padded(Cout) * sizeof(uint16_t);
+}
+
 extern "C" size_t cnrma_amax_bytes(void) { return sizeof(float) * AMAX_SLOTS * AMAX_STRIDE; }
 
 extern "C" size_t cnrma_sparse_conv_f16_weight_bytes(int K, int Cin, int Cout) {
-  return (size_t)2 * K * Cin * Cout * sizeof(uint16_t) + 64 + sizeof(float) * AMAX_SLOTS * AMAX_STRIDE;
+  return (size_t)2 * K * Cin * conv_cout_padded(Cout) * sizeof(uint16_t) + 64 + sizeof(float) * AMAX_SLOTS * AMAX_STRIDE;
 }
 
 extern "C" int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K, int Cin, int Cout, void* weight_split,
                                                      void* stream) {
   if (K <= 0 || Cin <= 0 || Cout <= 0 || weight_split == nullptr) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  const int64_t total = (int64_t)K * Cin * Cout;
+  const int64_t total_src = (int64_t)K * Cin * Cout;
+  const int64_t total = (int64_t)K * Cin * conv_cout_padded(Cout);
   uint16_t* wt = reinterpret_cast<uint16_t*>(weight_split);
   float* amax = reinterpret_cast<float*>(wt + 2 * total) + 16;       // slot scratch behind the 64-byte trailer
   hipError_t e = hipMemsetAsync(amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
   if (e != hipSuccess) return -(int)e;
-  int64_t blocks = ceil_div(total / 4 + 1, 256);
+  int64_t blocks = ceil_div(total_src / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, total, nullptr, 1, amax);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, total_src, nullptr, 1, amax);
   blocks = ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(prep_weights_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, wt, K, Cin, Cout, amax);

@@ -319,7 +319,7 @@ def split_weights_f16(weight):
 
 
 def split_weights(weight):
-    """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [3,K,Cout,Cin] (hi / mid / lo pieces).  The result is cached ON
+    """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [3,K,Cout_p,Cin] (hi / mid / lo pieces, Cout padded to 128).  The result is cached ON
     the weight tensor object (so it dies with it) and rebuilt when the tensor is modified in place or moved."""
     tag = (weight._version, weight.data_ptr(), weight.device)
     hit = getattr(weight, "_cnrma_split", None)
@@ -329,7 +329,7 @@ def split_weights(weight):
     if w.dim() == 2:
         w = w.unsqueeze(0)
     K, Cin, Cout = w.shape
-    ws = torch.empty((3, K, Cout, Cin), dtype=torch.bfloat16, device=w.device)
+    ws = torch.empty(_lib.load().cnrma_sparse_conv_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights", ptr(w), K, Cin, Cout, ptr(ws), stream())
     try:
         weight._cnrma_split = (tag, ws)

@@ -230,8 +230,10 @@ int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, in
 /* fp32-grade convolution on the bf16 matrix cores ("bf16x6": each fp32 operand split exactly into 3 bf16 pieces, the 6
  * significant partial products accumulated in fp32; relative error ~2^-23 per product, i.e. that of an fp32 fma chain;
  * 2.67x fewer matrix-pipe cycles than the fp32 MFMA path).  Needs Cin % 32 == 0.
- * cnrma_sparse_conv_prepare_weights: weight fp32 [K][Cin][Cout] -> weight_split bf16 [3][K][Cout][Cin]
- * (6*K*Cin*Cout bytes), done once per layer.  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
+ * cnrma_sparse_conv_prepare_weights: weight fp32 [K][Cin][Cout] -> weight_split bf16 [3][K][Cout_p][Cin], Cout_p = Cout
+ * rounded up to 128 with zero rows (cnrma_sparse_conv_weight_bytes bytes), done once per layer.  Same arguments /
+ * epilogue as cnrma_sparse_conv_f32 otherwise. */
+size_t cnrma_sparse_conv_weight_bytes(int K, int Cin, int Cout);
 int cnrma_sparse_conv_prepare_weights(const float* weight, int K, int Cin, int Cout, void* weight_split, void* stream);
 /* Pre-split feature companions: a feature matrix [N][C] (C % 8 == 0) can carry its bf16 split
  * [N+1][C/8][3 planes][8] (48 bytes per 8 channels; row N is all zeros and stands in for missing neighbours).
@@ -260,7 +262,7 @@ int cnrma_sparse_convtr_gen_bf16x6(const int32_t* in_coords, const float* in_fea
  * 64-byte line, whose maximum is the bound (blocks publish into the slot their index hashes to: same-address atomics
  * would serialise).  in_amax: bound >= max|in_feats| (cnrma_absmax_f32, or the out_amax of the producing convolution);
  * out_amax (may be NULL): zeroed by the caller, receives max|out_feats|.
- * cnrma_sparse_conv_prepare_weights_f16: weight fp32 [K][Cin][Cout] -> fp16 [2][K][Cout][Cin] of weight * 2^s + a trailer
+ * cnrma_sparse_conv_prepare_weights_f16: weight fp32 [K][Cin][Cout] -> fp16 [2][K][Cout_p][Cin] of weight * 2^s + a trailer
  * holding max|weight| (cnrma_sparse_conv_f16_weight_bytes bytes in all), done once per layer. */
 size_t cnrma_amax_bytes(void);
 int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out_amax, void* stream);
