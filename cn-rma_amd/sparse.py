@@ -62,6 +62,11 @@ def _offsets_tensor(kernel_size, stride, device):
     return _OFFSETS[key]
 
 
+def scene_counts(scene_col, n_scenes):
+    """rows per scene id as host ints with ONE device->host read (torch.bincount reads the maximum back first)"""
+    return torch.stack([(scene_col == b).sum() for b in range(n_scenes)]).tolist()
+
+
 class CoordSet:
     def __init__(self, coords, stride, cmap=None, n_batch=1):
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
@@ -83,7 +88,7 @@ class CoordSet:
             if self.n_batch <= 1:
                 self._counts = [self.n]
             else:
-                self._counts = torch.bincount(self.C[:, 0].long(), minlength=self.n_batch).tolist()
+                self._counts = scene_counts(self.C[:, 0], self.n_batch)
         return self._counts
 
     @property

@@ -223,7 +223,7 @@ class FCAF3DHead(nn.Module):
             else:
                 # ONE stable sort per level on the key (scene, descending score): every scene's rows become a contiguous
                 # run in rank order, of which the first nms_pre are taken (scores are >= 0: their bit patterns order them)
-                counts = torch.bincount(sc.long(), minlength=n_scenes).tolist()
+                counts = S.scene_counts(sc, n_scenes)
                 bits = S.max_scores(cls, cen).view(torch.int32).long()
                 order = torch.sort((sc.long() << 32) | (0xFFFFFFFF - bits), stable=True)[1]
                 groups, r0 = [], 0

@@ -1,25 +1,33 @@
-"""host-side enqueue time per stage (no device sync inside) vs end-to-end time: are we host-bound?"""
+"""host-side (Python) time per scene of the batched pipeline: cProfile top entries + wall time with the GPU idle-waits
+separated (time spent inside .item()/.tolist() is waiting for the device, the rest is CPU work under the GIL)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
-from cnrma_amd import pipeline, rma, synth
-from cnrma_amd import sparse as S
+from cnrma_amd import pipeline, synth
 dev = torch.device("cuda:0")
 V, C, H, W, dims, stride = synth.SHAPES["S"]
 sc = synth.make_scene("S", seed=0)
-feat, proj, tsdf = sc["features"][:, 0].to(dev), sc["projection"][:, 0], sc["tsdf"][0, 0].to(dev)
+scene = dict(features=sc["features"][:, 0].to(dev), projection=sc["projection"][:, 0], tsdf=sc["tsdf"][0, 0].to(dev))
 backbone, head = bench.build_model(C, dev)
 cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
-for _ in range(5):
-    pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+for _ in range(4):
+    pipeline.forward_scenes(cfg, backbone, head, [scene] * B)
 torch.cuda.synchronize()
-import cProfile, pstats
-N = 20
+N = 10
 t0 = time.perf_counter()
+for _ in range(N):
+    pipeline.forward_scenes(cfg, backbone, head, [scene] * B)
+torch.cuda.synchronize()
+print("wall ms/scene (no profiler)", (time.perf_counter() - t0) / (N * B) * 1e3)
+import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(N):
-    pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
+    pipeline.forward_scenes(cfg, backbone, head, [scene] * B)
 pr.disable()
 torch.cuda.synchronize()
-print("ms/scene", (time.perf_counter() - t0) / N * 1e3)
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr)
+tot = sum(v[2] for v in st.stats.values())
+wait = sum(v[2] for k, v in st.stats.items() if k[2] in ("<method 'item' of 'torch._C.TensorBase' objects>", "<method 'tolist' of 'torch._C.TensorBase' objects>"))
+print("profiled total ms/scene", tot / (N * B) * 1e3, "of which waiting in item/tolist", wait / (N * B) * 1e3)
+st.sort_stats("tottime").print_stats(32)
