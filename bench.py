@@ -243,10 +243,13 @@ def main():
     torch.cuda.synchronize()
     out = run_steps(max(args.warmup, args.streams * max(1, args.batch)))
     barrier()
+    c0 = os.times()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    c1 = os.times()
+    host_cpu = ((c1.user - c0.user) + (c1.system - c0.system)) / dt      # cores kept busy by this rank's threads
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -263,6 +266,7 @@ def main():
                                f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000, "
                                f"FCAF3D MinkResNet34 + head (18 classes), 1 scene per GPU per step "
                                f"({max(1, args.batch)} scenes share one sparse-network pass, {args.streams} passes in flight)",
+                   "host_cpu_cores_busy": round(host_cpu, 2), "host_cores": os.cpu_count(),
                    "scenes_in_flight": args.streams * max(1, args.batch), "scenes_per_network_pass": max(1, args.batch),
                    "M_rows": out["M"], "M_selected": out["M_selected"], "M_unique": out["M_unique"],
                    "level_rows": out["level_rows"], "head_rows": out["head_rows"]},
