@@ -115,6 +115,37 @@ class CoordSet:
             self._children[ns] = child
         return self._children[ns]
 
+    def prefetch_strided(self, levels, factor=2):
+        """the chain self -> strided -> strided ... (`levels` deep) enqueued back to back -- level k+1 reads level k's
+        row count on the device -- with ONE device->host read of all row counts at the end instead of one per level.
+        The sets are cached, so the strided() calls of the layers that follow cost nothing."""
+        todo, cs, ns = [], self, self.stride
+        while len(todo) < levels and (ns * factor) in cs._children:        # already known prefix
+            ns *= factor
+            cs = cs._children[ns]
+            levels -= 1
+        src_C, src_ndev, cap = cs.C, None, cs.n
+        if levels <= 0 or cap == 0:
+            return
+        ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(cap), dtype=torch.uint8, device=self.device)
+        for _ in range(levels):
+            ns *= factor
+            m = CoordMap(cap, self.device)
+            out = torch.empty((cap, 4), dtype=torch.int32, device=self.device)
+            n_out = torch.empty(1, dtype=torch.int32, device=self.device)
+            call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
+                 ptr(n_out), ptr(ws), stream())
+            todo.append((ns, out, n_out, m))
+            src_C, src_ndev = out, n_out
+        counts = torch.cat([t[2] for t in todo]).tolist()
+        for (ns_k, out, _, m), n in zip(todo, counts):
+            if m.cap > 8 * _next_pow2(max(2 * n, 16)):
+                m = None                      # a far over-sized table scatters the probes: rebuild compactly on first use
+            child = CoordSet(out[:n], ns_k, m, self.n_batch)
+            child.scene_major = cs.scene_major
+            cs._children[ns_k] = child
+            cs = child
+
     def neighbours(self, out_set, kernel_size, offset_stride, method="auto"):
         """nbr[No][K]: row of `self` at out_coord + offset_k (or -1).  method: "generic" probes every (output, offset)
         pair; "auto" uses the symmetric builder for stride-1 odd kernels on one set and the input-driven builder for

@@ -59,6 +59,9 @@ class FCAF3DBackbone(nn.Module):
 
     def forward(self, x):
         outs = []
+        # the coordinate sets of all stride-2 steps (stem conv, max pool, one per layer) depend on the input sites only:
+        # build the whole chain now with a single device->host read of the row counts
+        x.cs.prefetch_strided(2 + self.n_outs)
         x = self.conv1(x)
         for i in range(self.n_outs):
             x = getattr(self, f"layer{i + 1}")(x)

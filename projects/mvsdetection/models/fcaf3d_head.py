@@ -96,7 +96,8 @@ class FCAF3DHead(nn.Module):
     # ---- forward (reference :107-139, :275-298) ---------------------------------------------------------------
     def forward(self, x, fused=False):
         """fused=True (eval only): several scenes stay in ONE row set per level -- every output list has a single entry
-        and a fifth list holds the rows' scene ids; decode with get_bboxes_fused()."""
+        and a fifth list holds the level's coordinate set (scene ids, cached rows per scene); decode with
+        get_bboxes_fused()."""
         outs = []
         inputs = x
         x = inputs[-1]
@@ -109,7 +110,7 @@ class FCAF3DHead(nn.Module):
             out = getattr(self, f"out_block_{i}")(x)
             out = self.forward_single(out, self.scales[i], fused)
             scores = out[-1]
-            outs.append(out[:-1] + ([out[-1].C[:, 0]],) if fused else out[:-1])
+            outs.append(out[:-1] + ([out[-1].cs],) if fused else out[:-1])
         return zip(*outs[::-1])
 
     def _prune(self, x, scores):
@@ -213,8 +214,9 @@ class FCAF3DHead(nn.Module):
         _get_bboxes_single :247-256 per scene).  Returns [(bboxes, scores)] per scene."""
         nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
         per_scene = [([], []) for _ in range(n_scenes)]
-        for cen, box, cls, pts, sc in zip(centernesses, bbox_preds, cls_scores, points, scenes):
-            cen, box, cls, pts, sc = cen[0], box[0], cls[0], pts[0], sc[0]
+        for cen, box, cls, pts, cs in zip(centernesses, bbox_preds, cls_scores, points, scenes):
+            cen, box, cls, pts, cs = cen[0], box[0], cls[0], pts[0], cs[0]
+            sc = cs.C[:, 0]
             if n_scenes == 1:
                 ids = None
                 if len(cls) > nms_pre > 0:
@@ -223,7 +225,7 @@ class FCAF3DHead(nn.Module):
             else:
                 # ONE stable sort per level on the key (scene, descending score): every scene's rows become a contiguous
                 # run in rank order, of which the first nms_pre are taken (scores are >= 0: their bit patterns order them)
-                counts = S.scene_counts(sc, n_scenes)
+                counts = cs.batch_counts()                  # usually cached by the pruning step of the same level
                 bits = S.max_scores(cls, cen).view(torch.int32).long()
                 order = torch.sort((sc.long() << 32) | (0xFFFFFFFF - bits), stable=True)[1]
                 groups, r0 = [], 0
