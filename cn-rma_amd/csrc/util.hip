@@ -161,6 +161,11 @@ struct SampleWs {          // sampler workspace (int32 words)
   int32_t need[4];         // need[d] = rows still to take inside the prefix after pass d-1 (need[0] = n_keep)
   int32_t tie_count, pad;
   int32_t tie_idx[256];
+  // more than 256 rows share the threshold key (e.g. thousands of exactly equal scores): a second select over the ROW
+  // INDEX of the tie rows finds the need[3]-th smallest one exactly (passes 3..5 reuse the find kernel)
+  int32_t hist2[3][2048];
+  int32_t prefix2[3];
+  int32_t need2[4];
 };
 
 __device__ __forceinline__ int key_digit(uint32_t k, int pass) {
@@ -212,6 +217,36 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restr
   }
 }
 
+// second-level select, only active when the tie list overflowed: digit histogram of the row index over the tie rows
+__global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
+                                                              uint32_t seed, int pass, SampleWs* __restrict__ ws) {
+  if (ws->tie_count <= 256) return;
+  __shared__ int h[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+  __syncthreads();
+  const int64_t M = m_dev[0];
+  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    if (select_key(scores, seed, (uint32_t)i) != key) continue;
+    const uint32_t k2 = (uint32_t)i;                         // smaller index = kept first
+    if (key_matches(k2, pass, ws->prefix2)) atomicAdd(&h[key_digit(k2, pass)], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (h[i]) atomicAdd(&ws->hist2[pass][i], h[i]);
+}
+
+__global__ __launch_bounds__(1024) void sample_tie_find_kernel(SampleWs* __restrict__ ws, int pass) {
+  if (ws->tie_count <= 256) return;
+  __shared__ int smem[1024 / 64 + 1];
+  const int need = pass == 0 ? ws->need[3] : ws->need2[pass];
+  const int a = ws->hist2[pass][2 * threadIdx.x], b = ws->hist2[pass][2 * threadIdx.x + 1];
+  int total;
+  const int ex = block_excl_scan<1024>(a + b, smem, &total);
+  if (ex < need && ex + a >= need) { ws->prefix2[pass] = 2 * threadIdx.x; ws->need2[pass + 1] = need - ex; }
+  else if (ex + a < need && ex + a + b >= need) { ws->prefix2[pass] = 2 * threadIdx.x + 1; ws->need2[pass + 1] = need - ex - a; }
+}
+
 __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
                                                           uint32_t seed, const SampleWs* __restrict__ ws, int n_keep,
                                                           uint8_t* __restrict__ mask) {
@@ -221,10 +256,14 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
     // the need smallest indices among the (normally 1, at most 256) rows that carry the threshold key
     const int cnt = min(ws->tie_count, 256), need = ws->need[3];
     int32_t bound = -1;
-    for (int r = 0; r < need; ++r) {
-      int32_t best = 0x7FFFFFFF;
-      for (int q = 0; q < cnt; ++q) { const int32_t v = ws->tie_idx[q]; if (v > bound && v < best) best = v; }
-      bound = best;
+    if (ws->tie_count > 256) {       // exact: the need-th smallest tie index from the second-level select
+      bound = (int32_t)(((uint32_t)ws->prefix2[0] << 21) | ((uint32_t)ws->prefix2[1] << 10) | (uint32_t)ws->prefix2[2]);
+    } else {
+      for (int r = 0; r < need; ++r) {
+        int32_t best = 0x7FFFFFFF;
+        for (int q = 0; q < cnt; ++q) { const int32_t v = ws->tie_idx[q]; if (v > bound && v < best) best = v; }
+        bound = best;
+      }
     }
     tie_bound = bound;
   }
@@ -254,6 +293,10 @@ static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, 
     hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws, pass, n_keep);
   }
   hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws);
+  for (int pass = 0; pass < 3; ++pass) {      // no-ops unless more than 256 rows carry the threshold key
+    hipLaunchKernelGGL(sample_tie_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, ws);
+    hipLaunchKernelGGL(sample_tie_find_kernel, dim3(1), dim3(1024), 0, st, ws, pass);
+  }
   hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws, n_keep, mask);
   CNRMA_LAUNCH_CHECK();
   return 0;

@@ -246,12 +246,7 @@ class SparseTensor:
 
 
 # --------------------------------------------------------------------------------------------------------------
-def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
-    """ME.utils.batch_sparse_collate + ME.SparseTensor (ray_marching.py:328-330): floor(coord / voxel_size),
-    first occurrence wins.  row_order "first" = rows in first-occurrence order, "morton" = rows sorted by the
-    Morton code of the voxel (ME's own order is implementation-defined).  Returns (SparseTensor @ stride 1,
-    src_index int32 = source row of every output row)."""
-    _lib.require_gpu()
+def _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order):
     coords = coords.contiguous().float()
     feats = feats.contiguous().float()
     M, C = feats.shape
@@ -265,20 +260,32 @@ def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
     call("cnrma_voxelize_f32", ptr(coords), ptr(feats), M, C, float(voxel_size), int(batch_id),
          {"first": 0, "morton": 1}[row_order], ptr(m.keys), ptr(m.vals),
          m.cap, ptr(out_c), ptr(out_f), ptr(src), ptr(n_out), ptr(ws), stream())
+    return out_c, out_f, src, n_out, m
+
+
+def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
+    """ME.utils.batch_sparse_collate + ME.SparseTensor (ray_marching.py:328-330): floor(coord / voxel_size),
+    first occurrence wins.  row_order "first" = rows in first-occurrence order, "morton" = rows sorted by the
+    Morton code of the voxel (ME's own order is implementation-defined).  Returns (SparseTensor @ stride 1,
+    src_index int32 = source row of every output row)."""
+    _lib.require_gpu()
+    out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order)
     n = int(n_out.item())
     return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
 
 
 def sparse_collate(list_of_coords_feats, voxel_size):
     """Multi-scene variant: one SparseTensor holding all scenes (batch id = list index)."""
-    parts = [voxelize(c, f, voxel_size, b) for b, (c, f) in enumerate(list_of_coords_feats)]
-    if len(parts) == 1:
-        return parts[0][0]
-    C = torch.cat([p[0].C for p in parts])
-    F = torch.cat([p[0].F for p in parts])
+    if len(list_of_coords_feats) == 1:
+        return voxelize(*list_of_coords_feats[0], voxel_size, 0)[0]
+    _lib.require_gpu()
+    parts = [_voxelize_enqueue(c, f, voxel_size, b, "morton") for b, (c, f) in enumerate(list_of_coords_feats)]
+    counts = torch.cat([p[3] for p in parts]).tolist()              # ONE device->host read for all scenes
+    C = torch.cat([p[0][:n] for p, n in zip(parts, counts)])
+    F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
     cs = CoordSet(C, 1, None, len(parts))
     cs.scene_major = True
-    cs._counts = [len(p[0]) for p in parts]
+    cs._counts = counts
     return SparseTensor(F, cs)
 
 
@@ -504,8 +511,17 @@ def union_add(a, b):
     ws = torch.empty(_lib.load().cnrma_union_workspace_bytes(nb), dtype=torch.uint8, device=dev)
     call("cnrma_sparse_union_add_f32", ptr(a.C), ptr(a.F.contiguous()), na, None, ptr(b.C), ptr(b.F.contiguous()), nb,
          None, C, ptr(m.keys), ptr(m.vals), m.cap, ptr(out_c), ptr(out_f), ptr(n_out), ptr(ws), stream())
-    n = int(n_out.item())
-    return SparseTensor(out_f[:n], CoordSet(out_c[:n], a.cs.stride, m, max(a.cs.n_batch, b.cs.n_batch)))
+    nbatch = max(a.cs.n_batch, b.cs.n_batch)
+    if nbatch > 1:          # row count and rows per scene with ONE device->host read
+        live = torch.arange(na + nb, device=dev) < n_out
+        scene = out_c[:, 0]
+        got = torch.cat([n_out] + [((scene == s_) & live).sum().view(1).to(torch.int32) for s_ in range(nbatch)]).tolist()
+        n, counts = got[0], got[1:]
+    else:
+        n, counts = int(n_out.item()), None
+    cs = CoordSet(out_c[:n], a.cs.stride, m, nbatch)
+    cs._counts = counts
+    return SparseTensor(out_f[:n], cs)
 
 
 def interpolate(score, query_coords):
@@ -521,20 +537,23 @@ def interpolate(score, query_coords):
     return out
 
 
-def prune(x, keep_mask):
-    """MinkowskiPruning: rows where keep_mask, order preserved."""
+def prune(x, keep_mask, n_keep=None, counts=None):
+    """MinkowskiPruning: rows where keep_mask, order preserved.  n_keep: number of ones in the mask when the caller
+    knows it (saves the device->host read); counts: rows per scene of the result when known."""
     _lib.require_gpu()
     from .rma import mask_to_index
     n, C = x.F.shape
     mask = keep_mask.to(torch.uint8).contiguous()
     sel, n_sel = mask_to_index(mask)
-    k = int(n_sel.item())
+    k = int(n_sel.item()) if n_keep is None else int(n_keep)
     out_c = torch.empty((k, 4), dtype=torch.int32, device=x.device)
     out_f = torch.empty((k, C), dtype=torch.float32, device=x.device)
     if n:
         call("cnrma_sparse_prune_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, C, ptr(sel), ptr(out_c), ptr(out_f),
              stream())
-    return SparseTensor(out_f, CoordSet(out_c, x.cs.stride, None, x.cs.n_batch), None, x.amax)
+    cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch)
+    cs._counts = counts
+    return SparseTensor(out_f, cs, None, x.amax)
 
 
 def head_post(y, coords, n_reg, n_cls, scale, voxel_size):

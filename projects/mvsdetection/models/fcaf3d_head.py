@@ -123,6 +123,7 @@ class FCAF3DHead(nn.Module):
                 return x                                # the top-k keeps every row: pruning is the identity
             interpolated = scores.features_at_coordinates(x.C.float())
             # radix-select keep-mask instead of torch.topk's sort (same row set; ties by index)
+            kept = [min(c, self.pts_threshold) for c in counts]
             if len(counts) == 1:
                 mask = S.topk_mask(interpolated, self.pts_threshold)
             else:                                       # per scene: the other scenes' rows are masked to -inf
@@ -134,7 +135,7 @@ class FCAF3DHead(nn.Module):
                     m = mine.to(torch.uint8) if nb <= self.pts_threshold else \
                         S.topk_mask(torch.where(mine, flat, low), self.pts_threshold)
                     mask = m if mask is None else mask | m
-        return self.pruning(x, mask)
+        return S.prune(x, mask, n_keep=sum(kept), counts=kept)      # the mask holds exactly min(n, threshold) rows per scene
 
     def _head_weights(self):
         """the three 1x1 head convolutions as ONE [128, 1+R+n_cls] GEMM (+ bias row for the class logits)"""

@@ -436,3 +436,20 @@ def test_f16x3_all_zero_and_empty_inputs(device):
     shift = torch.full((64,), 0.5, device=device)
     y = S.conv(to_st(c, np.zeros_like(f), 1, device), W, 3, 1, shift=shift, precision="f16x3")
     assert float((y.F - 0.5).abs().max()) == 0.0 and _amax(y) == 0.5
+
+
+def test_topk_mask_is_exact_under_heavy_ties(device):
+    """thousands of exactly equal scores at the threshold: exactly k rows, the tied ones by smallest index
+    (the row set of a stable descending sort)"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(4)
+    for n, k, n_zero in ((50000, 20000, 40000), (300000, 200000, 150000), (5000, 4999, 5000), (70000, 300, 0)):
+        s = rng.rand(n).astype(np.float32)
+        s[rng.permutation(n)[:n_zero]] = 0.0                     # a big block of ties (interpolated scores are often 0)
+        if n_zero == 0:
+            s[rng.permutation(n)[:3000]] = 0.75                  # ties inside the kept range, cut through the middle
+            k = int((s > 0.75).sum()) + 1500
+        m = S.topk_mask(torch.from_numpy(s).to(device), k).cpu().numpy().astype(bool)
+        order = np.argsort(-s, kind="stable")[:k]
+        exp = np.zeros(n, dtype=bool); exp[order] = True
+        assert m.sum() == k and (m == exp).all()
