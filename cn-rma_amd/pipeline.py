@@ -61,17 +61,21 @@ def forward_scenes(cfg, backbone, head, scenes):
     runs per scene; the scenes' voxels are then collated into one multi-scene sparse tensor (batch id = list index,
     ray_marching.py:328-330 builds exactly that for B samples) for the backbone + neck/head, whose ~300 small launches
     and split-K tails are thereby shared; decode is per scene.  Returns one dict per scene like forward_scene()."""
-    parts, infos = [], []
-    for sc_ in scenes:
+    parts, infos, states = [], [], []
+    for sc_ in scenes:                                   # phase 1: everything up to the row-count read-back, all scenes
         feats = rma.to_nhwc(sc_["features"])
         volume, count = rma.backproject_accum(feats, sc_["projection"], cfg.dims, cfg.voxel_size, cfg.origin, cfg.stride)
         proj_inv = rma.projection_inverse(sc_["projection"], cfg.stride).to(feats.device, non_blocking=True)
-        coords, pfeats, info = rma.aggregate_points(
-            feats, proj_inv, sc_["tsdf"], cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
-            cfg.ray_marching_type, cfg.depth_points, offset=sc_.get("offset", (0.0, 0.0, 0.0)), max_points=cfg.max_points,
-            sampler=cfg.sampler, mask=sc_.get("mask"))
+        states.append(rma.aggregate_begin(feats, proj_inv, sc_["tsdf"], cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps,
+                                          cfg.thr, cfg.ray_marching_type, cfg.depth_points))
+        infos.append(dict(volume=volume, count=count))
+    reads = torch.cat([st["readback"] for st in states]).tolist()       # ONE device->host read for all scenes
+    w = len(reads) // len(scenes)
+    for b, (sc_, st) in enumerate(zip(scenes, states)):    # phase 2: selection + emission
+        coords, pfeats, info = rma.aggregate_finish(st, reads[b * w:(b + 1) * w], sc_.get("offset", (0.0, 0.0, 0.0)),
+                                                    cfg.max_points, cfg.sampler, sc_.get("mask"))
         parts.append((coords, pfeats))
-        infos.append(dict(info, volume=volume, count=count))
+        infos[b].update(info)
     x = S.sparse_collate(parts, cfg.voxel_size_fcaf3d)
     levels = backbone(x)
     cen, box, cls, pts, scn = map(list, head(levels, fused=True))

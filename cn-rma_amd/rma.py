@@ -256,9 +256,21 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
                          distribution, different RNG stream; no host RNG on the critical path).
     mask:    optional explicit keep-mask (numpy bool / torch uint8 of length M); overrides `sampler`.
     """
+    st = aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids,
+                         reference_quirks)
+    # the one read-back the reference also has (nonzero(), :781): total row count (+ the record-overflow guard)
+    return aggregate_finish(st, st["readback"].tolist(), offset, max_points, sampler, mask)
+
+
+def aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
+                    select_grids=0, reference_quirks=True):
+    """first half of aggregate_points: march, row offsets, mean weight -- everything up to the read-back of the row
+    count.  st["readback"] (int32 [1 or 2] on the device) must be read by the caller (several scenes can share one
+    device->host read: torch.cat of their read-backs) and handed to aggregate_finish()."""
     _lib.require_gpu()
     m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids)
     single_march = m.kept_cap() > 0
+    kept = overflow = None
     if single_march:
         cnt, wsum, kept, overflow = m.march()
     else:
@@ -272,13 +284,18 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
     call("cnrma_sum_f64", ptr(wsum), ptr(wtot), m.R, ptr(ws), stream())
     m_total = off[m.R:]
     call("cnrma_rma_mean_weight", ptr(wtot), m_total.data_ptr(), ptr(mean_w), stream())
-    # the one read-back the reference also has (nonzero(), :781): total row count (+ the record-overflow guard)
-    if single_march:
-        M, ovf = torch.cat((m_total, overflow)).tolist()
-        if ovf:
-            raise _lib.CnrmaError("kept-sample record overflow: a ray kept more than 1/thr samples")
-    else:
-        M = int(m_total.item())
+    readback = torch.cat((m_total, overflow)) if single_march else m_total
+    return dict(m=m, single_march=single_march, cnt=cnt, off=off, kept=kept, mean_w=mean_w, m_total=m_total,
+                readback=readback)
+
+
+def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, sampler="numpy", mask=None):
+    """second half of aggregate_points; readback = st["readback"] as host ints"""
+    m, single_march, off, kept, mean_w, m_total, cnt = (st[k] for k in ("m", "single_march", "off", "kept", "mean_w",
+                                                                         "m_total", "cnt"))
+    M = int(readback[0])
+    if single_march and readback[1]:
+        raise _lib.CnrmaError("kept-sample record overflow: a ray kept more than 1/thr samples")
     if M == 0:
         raise TypeError("no valid points in any view (ray_marching.py:300)")
     sel = None
