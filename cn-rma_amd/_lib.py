@@ -3,6 +3,7 @@
 The product path has NO fallback: if the library is missing or a symbol is absent this module raises.
 """
 import ctypes
+import threading
 import os
 from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
@@ -121,6 +122,26 @@ def call(name, *args):
     if rc != 0:
         raise CnrmaError(f"{name} failed with code {rc}" + (" (invalid argument)" if rc == -22 else " (-hipError_t)"))
     return rc
+
+
+_tls = threading.local()
+
+
+def read_ints(t):
+    """device int tensor -> list of host ints, as an asynchronous copy into this thread's pinned buffer followed by a
+    wait on the CURRENT stream only.  (Tensor.item()/.tolist() issue a blocking hipMemcpy into pageable memory, during
+    which other host threads' launches stall: with several scenes in flight that drained the whole GPU at every
+    read-back.)"""
+    import torch
+    t = t.reshape(-1)
+    n = t.numel()
+    buf = getattr(_tls, "pinned", None)
+    if buf is None or buf.numel() < n or buf.dtype != t.dtype:
+        buf = torch.empty(max(64, n), dtype=t.dtype, pin_memory=True)
+        _tls.pinned = buf
+    buf[:n].copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return buf[:n].tolist()
 
 
 _gpu_ok = False

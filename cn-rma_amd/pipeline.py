@@ -10,7 +10,7 @@ backbone and the Atlas reconstruction network replaced by their outputs (feature
 """
 import torch
 
-from . import rma
+from . import _lib, rma
 from . import sparse as S
 
 
@@ -69,7 +69,7 @@ def forward_scenes(cfg, backbone, head, scenes):
         states.append(rma.aggregate_begin(feats, proj_inv, sc_["tsdf"], cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps,
                                           cfg.thr, cfg.ray_marching_type, cfg.depth_points))
         infos.append(dict(volume=volume, count=count))
-    reads = torch.cat([st["readback"] for st in states]).tolist()       # ONE device->host read for all scenes
+    reads = _lib.read_ints(torch.cat([st["readback"] for st in states]))       # ONE device->host read for all scenes
     w = len(reads) // len(scenes)
     for b, (sc_, st) in enumerate(zip(scenes, states)):    # phase 2: selection + emission
         coords, pfeats, info = rma.aggregate_finish(st, reads[b * w:(b + 1) * w], sc_.get("offset", (0.0, 0.0, 0.0)),

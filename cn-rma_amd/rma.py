@@ -259,7 +259,7 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
     st = aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids,
                          reference_quirks)
     # the one read-back the reference also has (nonzero(), :781): total row count (+ the record-overflow guard)
-    return aggregate_finish(st, st["readback"].tolist(), offset, max_points, sampler, mask)
+    return aggregate_finish(st, _lib.read_ints(st["readback"]), offset, max_points, sampler, mask)
 
 
 def aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",

@@ -64,7 +64,7 @@ def _offsets_tensor(kernel_size, stride, device):
 
 def scene_counts(scene_col, n_scenes):
     """rows per scene id as host ints with ONE device->host read (torch.bincount reads the maximum back first)"""
-    return torch.stack([(scene_col == b).sum() for b in range(n_scenes)]).tolist()
+    return _lib.read_ints(torch.stack([(scene_col == b).sum() for b in range(n_scenes)]))
 
 
 class CoordSet:
@@ -109,7 +109,7 @@ class CoordSet:
             ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(self.n), dtype=torch.uint8, device=self.device)
             call("cnrma_sparse_stride_coords", ptr(self.C), self.n, None, ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
                  ptr(n_out), ptr(ws), stream())
-            n = int(n_out.item())
+            n = _lib.read_ints(n_out)[0]
             child = CoordSet(out[:n], ns, m, self.n_batch)
             child.scene_major = self.scene_major          # first-occurrence order keeps the scenes apart and in order
             self._children[ns] = child
@@ -137,7 +137,7 @@ class CoordSet:
                  ptr(n_out), ptr(ws), stream())
             todo.append((ns, out, n_out, m))
             src_C, src_ndev = out, n_out
-        counts = torch.cat([t[2] for t in todo]).tolist()
+        counts = _lib.read_ints(torch.cat([t[2] for t in todo]))
         for (ns_k, out, _, m), n in zip(todo, counts):
             if m.cap > 8 * _next_pow2(max(2 * n, 16)):
                 m = None                      # a far over-sized table scatters the probes: rebuild compactly on first use
@@ -270,7 +270,7 @@ def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
     src_index int32 = source row of every output row)."""
     _lib.require_gpu()
     out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order)
-    n = int(n_out.item())
+    n = _lib.read_ints(n_out)[0]
     return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
 
 
@@ -280,7 +280,7 @@ def sparse_collate(list_of_coords_feats, voxel_size):
         return voxelize(*list_of_coords_feats[0], voxel_size, 0)[0]
     _lib.require_gpu()
     parts = [_voxelize_enqueue(c, f, voxel_size, b, "morton") for b, (c, f) in enumerate(list_of_coords_feats)]
-    counts = torch.cat([p[3] for p in parts]).tolist()              # ONE device->host read for all scenes
+    counts = _lib.read_ints(torch.cat([p[3] for p in parts]))       # ONE device->host read for all scenes
     C = torch.cat([p[0][:n] for p, n in zip(parts, counts)])
     F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
     cs = CoordSet(C, 1, None, len(parts))
@@ -515,10 +515,11 @@ def union_add(a, b):
     if nbatch > 1:          # row count and rows per scene with ONE device->host read
         live = torch.arange(na + nb, device=dev) < n_out
         scene = out_c[:, 0]
-        got = torch.cat([n_out] + [((scene == s_) & live).sum().view(1).to(torch.int32) for s_ in range(nbatch)]).tolist()
+        got = _lib.read_ints(torch.cat([n_out] + [((scene == s_) & live).sum().view(1).to(torch.int32)
+                                                   for s_ in range(nbatch)]))
         n, counts = got[0], got[1:]
     else:
-        n, counts = int(n_out.item()), None
+        n, counts = _lib.read_ints(n_out)[0], None
     cs = CoordSet(out_c[:n], a.cs.stride, m, nbatch)
     cs._counts = counts
     return SparseTensor(out_f[:n], cs)
@@ -545,7 +546,7 @@ def prune(x, keep_mask, n_keep=None, counts=None):
     n, C = x.F.shape
     mask = keep_mask.to(torch.uint8).contiguous()
     sel, n_sel = mask_to_index(mask)
-    k = int(n_sel.item()) if n_keep is None else int(n_keep)
+    k = _lib.read_ints(n_sel)[0] if n_keep is None else int(n_keep)
     out_c = torch.empty((k, 4), dtype=torch.int32, device=x.device)
     out_f = torch.empty((k, C), dtype=torch.float32, device=x.device)
     if n:
