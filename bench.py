@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--workload", default="S", help="S = ScanNet config (40 views, 32ch 120x160 -> 192x192x80); St; tiny")
     ap.add_argument("--streams", type=int, default=3,
                     help="scenes in flight per GPU (each on its own HIP stream + host thread); 1 = strictly sequential")
-    ap.add_argument("--batch", type=int, default=2,
+    ap.add_argument("--batch", type=int, default=4,
                     help="scenes per sparse-network pass (their voxels are collated into one multi-scene tensor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
