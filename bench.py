@@ -37,8 +37,8 @@ PMC_CONV_TRAFFIC_S_BF16X6 = dict(bytes_per_launch=(2 * 4805.0e6 * 1.024 + 1140.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--workload", default="S", help="S = ScanNet config (40 views, 32ch 120x160 -> 192x192x80); St; tiny")
     ap.add_argument("--streams", type=int, default=3,
                     help="scenes in flight per GPU (each on its own HIP stream + host thread); 1 = strictly sequential")
@@ -210,11 +210,23 @@ def main():
         B = max(1, args.batch)
         groups = [list(range(g, min(n, g + B))) for g in range(0, n, B)]       # scene ids per network pass
 
+        nxt = [0]
+        lock = threading.Lock()
+
+        def take():                          # dynamic hand-out: no worker is left with an extra pass at the end
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            return groups[i] if i < len(groups) else None
+
         def worker(w):
             try:
                 torch.cuda.set_device(local_rank)
                 with torch.cuda.stream(streams[w]):
-                    for g in groups[w::args.streams]:
+                    while True:
+                        g = take()
+                        if g is None:
+                            break
                         if B == 1:
                             outs = [pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)]
                         else:
