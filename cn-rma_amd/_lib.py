@@ -22,6 +22,7 @@ SIGNATURES = {
     "cnrma_rma_neus_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P]),
     "cnrma_rma_neus_emit_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, F, F, F,
                                         P, I, P, I, P, I, P, P]),
+    "cnrma_rma_neus_rows_backward_f32": (c_int, [P, I, I, I, I, I, P, P, I, P, P, P, P]),
     "cnrma_rma_neus_march_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
     "cnrma_rma_neus_emit_rows_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, I, P, P, P, F, F, F, P, I, P, I, P, I, P, P]),
     "cnrma_sample_workspace_bytes": (c_size_t, []),

@@ -477,6 +477,62 @@ extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* 
   return 0;
 }
 
+// Backward of the emission w.r.t. the feature maps (the only differentiable input: the weights are computed under
+// torch.no_grad() in the reference, ray_marching.py:705): out[j][c] = feat[pixel(r)][c] * (w_j / w_div), so
+// grad_feat[pixel(r)][c] = sum over the SELECTED rows j of ray r of grad_out[j][c] * (w_j / w_div).  The rows of a ray
+// are known from its kept-sample records: one lane group per ray walks them in step order -- no atomics, deterministic.
+template <int LPR>
+__global__ __launch_bounds__(256) void neus_rows_backward_kernel(int64_t R, int C, const int32_t* __restrict__ row_offset,
+                                                                const int2* __restrict__ kept, int cap,
+                                                                const int32_t* __restrict__ sel,
+                                                                const float* __restrict__ w_div,
+                                                                const float* __restrict__ grad_out, int grad_stride,
+                                                                float* __restrict__ grad_feat) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = t / LPR;
+  const int sub = (int)(t % LPR);
+  if (r >= R) return;
+  const int64_t m0 = row_offset[r];
+  const int cnt = (int)(row_offset[r + 1] - m0);
+  const float wd = w_div ? w_div[0] : 1.0f;
+  for (int c = sub; c < C; c += LPR) {
+    float acc = 0.0f;
+    for (int i = 0; i < cnt; ++i) {
+      const int64_t j = sel ? (int64_t)sel[m0 + i] : m0 + i;
+      if (j < 0) continue;
+      const float w = __int_as_float(kept[r * cap + i].x);
+      const float scale = w_div ? w / wd : 1.0f;           // the forward's factor, same operations
+      acc += grad_out[j * grad_stride + c] * scale;
+    }
+    grad_feat[r * C + c] = acc;
+  }
+}
+
+extern "C" int cnrma_rma_neus_rows_backward_f32(const float* grad_out_feat, int grad_stride, int V, int C, int H, int W,
+                                                const int32_t* row_offset, const void* kept, int cap,
+                                                const int32_t* sel_index, const float* w_div, float* grad_feat_nhwc,
+                                                void* stream) {
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || kept == nullptr || cap <= 0 || grad_out_feat == nullptr ||
+      grad_feat_nhwc == nullptr)
+    return CNRMA_EINVAL;
+  const int64_t R = (int64_t)V * H * W;
+  const int lpr = C >= 32 ? 32 : (C >= 8 ? 8 : 1);
+  const unsigned blocks = (unsigned)ceil_div(R * lpr, 256);
+  hipStream_t st = as_stream(stream);
+  const int2* k2 = reinterpret_cast<const int2*>(kept);
+  if (lpr == 32)
+    hipLaunchKernelGGL((neus_rows_backward_kernel<32>), dim3(blocks), dim3(256), 0, st, R, C, row_offset, k2, cap, sel_index,
+                       w_div, grad_out_feat, grad_stride, grad_feat_nhwc);
+  else if (lpr == 8)
+    hipLaunchKernelGGL((neus_rows_backward_kernel<8>), dim3(blocks), dim3(256), 0, st, R, C, row_offset, k2, cap, sel_index,
+                       w_div, grad_out_feat, grad_stride, grad_feat_nhwc);
+  else
+    hipLaunchKernelGGL((neus_rows_backward_kernel<1>), dim3(blocks), dim3(256), 0, st, R, C, row_offset, k2, cap, sel_index,
+                       w_div, grad_out_feat, grad_stride, grad_feat_nhwc);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const float* feat_nhwc, int V, int C,
                                        int H, int W, int X, int Y, int Z, float voxel_size, float ox, float oy,
                                        float oz, int n_steps, float t_one, float thr, const int32_t* row_offset,

@@ -326,8 +326,41 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
         m.emit_rows(off, Ms, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
     else:
         m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
-    info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, count=cnt)
+    info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m)
     return coords, feats, info
+
+
+def aggregate_points_backward(info, grad_feats):
+    """gradient of aggregate_points()'s `feats` output w.r.t. the NHWC feature maps [V,H,W,C] (the weights and places
+    carry no gradient, ray_marching.py:705): needs the forward's `info` (single-march path)."""
+    m, kept = info["march"], info["kept"]
+    if kept is None:
+        raise NotImplementedError("the backward needs the kept-sample records of the single-march forward (NeuS, thr > 1/62)")
+    g = grad_feats.contiguous().float()
+    out = torch.empty((m.V, m.H, m.W, m.C), dtype=torch.float32, device=m.dev)
+    call("cnrma_rma_neus_rows_backward_f32", ptr(g), g.shape[1], m.V, m.C, m.H, m.W, ptr(info["row_offset"]), ptr(kept),
+         kept.shape[1], ptr(info["sel"]), ptr(info["mean_w"]), ptr(out), stream())
+    return out
+
+
+class AggregatePoints(torch.autograd.Function):
+    """differentiable aggregate_points(): (features NCHW [V,C,H,W], ...) -> (coords [Ms,3], feats [Ms,C]); the gradient
+    flows from `feats` to the feature maps (and on into the 2D backbone), like the reference's indexing
+    features[b, :, v, u] (ray_marching.py:793-797)."""
+
+    @staticmethod
+    def forward(ctx, features_nchw, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, offset, max_points, sampler, mask):
+        nhwc = to_nhwc(features_nchw.detach())
+        coords, feats, info = aggregate_points(nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0,
+                                               offset, max_points, sampler, mask)
+        ctx.info = info
+        ctx.mark_non_differentiable(coords)
+        return coords, feats
+
+    @staticmethod
+    def backward(ctx, _grad_coords, grad_feats):
+        g = aggregate_points_backward(ctx.info, grad_feats)                 # [V,H,W,C]
+        return (g.permute(0, 3, 1, 2).contiguous(),) + (None,) * 11
 
 
 def aggregate_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",

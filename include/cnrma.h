@@ -103,6 +103,14 @@ int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const floa
 int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y, int Z,
                              float voxel_size, float ox, float oy, float oz, int n_steps, float t_one, float thr,
                              int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow, void* stream);
+
+/* Backward of cnrma_rma_neus_emit_rows_f32 w.r.t. the feature maps (training; the weights carry no
+ * gradient: the reference computes them under torch.no_grad(), ray_marching.py:705).
+ * grad_feat_nhwc[ray][c] = sum over the selected rows j of the ray of grad_out_feat[j][c] * (w_j / w_div[0]); rows are
+ * walked in step order from the kept-sample records of the forward march (no atomics; rays without rows get zeros). */
+int cnrma_rma_neus_rows_backward_f32(const float* grad_out_feat, int grad_stride, int V, int C, int H, int W,
+                                     const int32_t* row_offset, const void* kept, int cap, const int32_t* sel_index,
+                                     const float* w_div, float* grad_feat_nhwc, void* stream);
 int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
                                  int n_steps, float t_one, const int32_t* row_offset, int64_t n_out, const void* kept,
                                  int cap, const int32_t* sel_index, void* records, const float* w_div, float addx,

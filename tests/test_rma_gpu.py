@@ -257,3 +257,32 @@ def test_scannet_test_grid_256_vs_oracle(device):
     assert rows.shape[0] == raw.shape[0]
     assert count_mismatch(rows[:, :3], raw[:, :3]) == 0 and count_mismatch(rows[:, 4:], raw[:, 4:]) == 0
     np.testing.assert_allclose(rows[:, 3].cpu().numpy(), raw[:, 3].numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("max_points", [None, 700])
+def test_aggregation_backward_vs_oracle_autograd(device, max_points):
+    """gradient of the aggregated point features w.r.t. the 2D feature maps (first piece): the HIP
+    backward (one lane group per ray over its kept-sample records) == torch autograd through the oracle"""
+    from cnrma_amd import rma, synth
+    from oracle import rma_oracle as O
+    sc = synth.make_scene("tiny", seed=3)
+    proj, tsdf = sc["projection"][:, 0], sc["tsdf"][0, 0]
+    f_cpu = sc["features"][:, 0].clone().requires_grad_(True)
+    pts = O.aggregate_rma(proj, f_cpu, tsdf, sc["dims"], 0.04, sc["origin"], sc["stride"])
+    mask = None
+    if max_points is not None:
+        np.random.seed(5)
+        mask = O.sample_mask_numpy(pts.shape[0], max_points)
+    sel = pts[:, 3:] if mask is None else pts[torch.from_numpy(mask)][:, 3:]
+    g = torch.randn(sel.shape, generator=torch.Generator().manual_seed(1))
+    (sel * g).sum().backward()
+
+    f_gpu = sc["features"][:, 0].clone().to(device).requires_grad_(True)
+    pinv = rma.projection_inverse(proj, sc["stride"]).to(device)
+    coords, feats = rma.AggregatePoints.apply(f_gpu, pinv, tsdf.to(device), sc["dims"], 0.04, sc["origin"], 300, 0.05,
+                                              (0.0, 0.0, 0.0), max_points, "numpy", mask)
+    assert not coords.requires_grad and feats.requires_grad and feats.shape == sel.shape
+    np.testing.assert_allclose(feats.detach().cpu().numpy(), sel.detach().numpy(), rtol=1e-5, atol=1e-6)
+    (feats * g.to(device)).sum().backward()
+    np.testing.assert_allclose(f_gpu.grad.cpu().numpy(), f_cpu.grad.numpy(), rtol=1e-5, atol=1e-6)
+    assert float(f_gpu.grad.abs().sum()) > 0
