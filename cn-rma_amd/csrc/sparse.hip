@@ -1506,6 +1506,102 @@ inline unsigned grid_for(int64_t work, int block = 256, int64_t max_blocks = 655
 // ================================================================================================================
 // C-ABI
 // ================================================================================================================
+// ================================================================================================================
+// Backward of the sparse convolution (training).
+//   dgrad: grad_in[i] = sum_k grad_out[nbrT[i][k]] @ W[k]^T -- the forward kernel on the TRANSPOSED neighbour table
+//          (nbrT[i][k] = the output row o with nbr[o][k] == i; for a fixed offset the map o -> i is injective);
+//   wgrad: gradW[k] = sum_o in[nbr[o][k]]^T (x) grad_out[o] -- a [Cin x rows] x [rows x Cout] product per offset on the
+//          fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulation), rows split into chunks whose
+//          partial sums go to slabs that the caller adds up (deterministic, no atomics).
+// ================================================================================================================
+__global__ __launch_bounds__(256) void kernel_map_transpose_kernel(const int32_t* __restrict__ nbr, int64_t no_cap,
+                                                                   const int32_t* __restrict__ no_dev, int K,
+                                                                   int64_t n_in, int32_t* __restrict__ nbr_t) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= live_rows(no_cap, no_dev) * K) return;
+  const int32_t i = nbr[t];
+  if (i >= 0 && i < n_in) nbr_t[(int64_t)i * K + (t % K)] = (int32_t)(t / K);
+}
+
+// one wave per block: a 64 x 64 (Cin x Cout) tile of gradW[k] over one chunk of output rows
+__global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr,
+                                                        int K, const float* __restrict__ gout, int Cout, int64_t no_cap,
+                                                        const int32_t* __restrict__ no_dev, int rows_per_chunk,
+                                                        float* __restrict__ slab) {
+  const int64_t n_live = live_rows(no_cap, no_dev);
+  const int chunk = blockIdx.x, k = blockIdx.y;
+  const int tiles_co = (Cout + 63) / 64;
+  const int ci0 = (blockIdx.z / tiles_co) * 64, co0 = (blockIdx.z % tiles_co) * 64;
+  const int lane = threadIdx.x, m = lane & 31, kk = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  const int64_t r1 = min(n_live, r0 + rows_per_chunk);
+  for (int64_t o0 = r0; o0 < r1; o0 += 2) {
+    const int64_t o = o0 + kk;
+    const bool live = o < r1;
+    int32_t src = -1;
+    if (live) src = nbr ? nbr[o * K + k] : (int32_t)o;
+    float a[2], b[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ci = ci0 + t * 32 + m, co = co0 + t * 32 + m;
+      a[t] = (src >= 0 && ci < Cin) ? in[(int64_t)src * Cin + ci] : 0.0f;
+      b[t] = (live && co < Cout) ? gout[o * Cout + co] : 0.0f;
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+  }
+  float* dst = slab + ((int64_t)chunk * K + k) * Cin * Cout;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int co = co0 + y * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[x][y][i];
+      }
+    }
+}
+
+extern "C" int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K,
+                                                 int64_t n_in, int32_t* nbr_t, void* stream) {
+  if (no_cap <= 0 || K <= 0 || n_in <= 0 || nbr == nullptr || nbr_t == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * K * sizeof(int32_t), st);
+  if (e != hipSuccess) return -(int)e;
+  hipLaunchKernelGGL(kernel_map_transpose_kernel, dim3((unsigned)ceil_div(no_cap * K, 256)), dim3(256), 0, st, nbr, no_cap,
+                     no_dev, K, n_in, nbr_t);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_wgrad_chunks(int64_t no_cap, int rows_per_chunk) {
+  return rows_per_chunk > 0 ? (int)ceil_div(no_cap, rows_per_chunk) : 0;
+}
+
+extern "C" int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out,
+                                           int Cout, int64_t no_cap, const int32_t* no_dev, int rows_per_chunk,
+                                           float* slabs, void* stream) {
+  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0 || rows_per_chunk <= 0 || (rows_per_chunk & 1) || slabs == nullptr)
+    return CNRMA_EINVAL;
+  const unsigned chunks = (unsigned)ceil_div(no_cap, rows_per_chunk);
+  const unsigned tiles = (unsigned)(ceil_div(Cin, 64) * ceil_div(Cout, 64));
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(chunks, (unsigned)K, tiles), dim3(64), 0, as_stream(stream), in_feats, Cin, nbr,
+                     K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t cnrma_voxelize_workspace_bytes(int64_t M) {
   int64_t n4 = (M + 3) / 4 * 4;
   return (size_t)(n4 * 33) + sort_temp_bytes(M) + cnrma_scan_workspace_bytes(M) + 1024;

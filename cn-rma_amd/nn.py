@@ -32,6 +32,15 @@ class MinkowskiConvolution(nn.Module):
             self.kernel.uniform_(-stdv, stdv)
 
     def forward(self, x, scale=None, shift=None, residual=None, act=None):
+        if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad) and scale is None and \
+                residual is None and act is None:
+            # training: differentiable convolution (dgrad / wgrad kernels), bias added by torch
+            y = S.conv_autograd(x, self.kernel, self.kernel_size, self.stride)
+            if shift is None and self.bias is not None:
+                y = S.SparseTensor(y.F + self.bias.view(1, -1), y.cs)
+            elif shift is not None:
+                y = S.SparseTensor(y.F + shift.view(1, -1), y.cs)
+            return y
         if shift is None and self.bias is not None:
             shift = self.bias.view(-1).contiguous()
         return S.conv(x, self.kernel, self.kernel_size, self.stride, scale, shift, residual, act)

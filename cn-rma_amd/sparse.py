@@ -426,6 +426,83 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
     return SparseTensor(out, out_cs, out_split)
 
 
+def _conv_on_table(feats, n_out, nbr, weight, precision=None):
+    """out [n_out, Cout] = sum_k feats[nbr[:, k]] @ weight[k] for an explicit neighbour table (None = identity, K == 1)"""
+    w = weight.contiguous().float()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, Cin, Cout = w.shape
+    out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
+    if n_out == 0:
+        return out
+    ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(n_out, Cout, K)
+    ws = _workspace(ws_bytes, feats.device) if ws_bytes else None
+    feats = feats.contiguous().float()
+    prec = precision or CONV_PRECISION
+    if prec == "f16x3" and Cin % 32 == 0:
+        amax = torch.zeros(_AMAX_WORDS, dtype=torch.float32, device=feats.device)
+        call("cnrma_absmax_f32", ptr(feats), feats.shape[0], None, Cin, ptr(amax), stream())
+        call("cnrma_sparse_conv_f16x3", ptr(feats), ptr(amax), Cin, ptr(nbr), K, ptr(split_weights_f16(w)), Cout, None, None,
+             None, 0, ptr(out), None, n_out, None, ptr(ws), ws_bytes, stream())
+    else:
+        call("cnrma_sparse_conv_f32", ptr(feats), Cin, ptr(nbr), K, ptr(w), Cout, None, None, None, 0, ptr(out), n_out, None,
+             ptr(ws), ws_bytes, stream())
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    """sum_k F[nbr[:, k]] @ W[k] with gradients: dgrad = the same convolution of grad_out over the transposed table with
+    W[k]^T, wgrad = cnrma_sparse_conv_wgrad_f32."""
+
+    @staticmethod
+    def forward(ctx, F, weight, nbr, n_out, precision):
+        ctx.save_for_backward(F, weight)
+        ctx.nbr, ctx.n_out, ctx.precision = nbr, n_out, precision
+        return _conv_on_table(F.detach(), n_out, nbr, weight.detach(), precision)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        F, weight = ctx.saved_tensors
+        nbr, n_out = ctx.nbr, ctx.n_out
+        w = weight.detach().float()
+        w3 = w.unsqueeze(0) if w.dim() == 2 else w
+        K, Cin, Cout = w3.shape
+        g = grad_out.contiguous().float()
+        n_in = F.shape[0]
+        grad_F = grad_W = None
+        if ctx.needs_input_grad[0]:
+            if nbr is None:
+                grad_F = _conv_on_table(g, n_in, None, w3.transpose(1, 2).contiguous(), ctx.precision)
+            else:
+                nbr_t = torch.empty((n_in, K), dtype=torch.int32, device=g.device)
+                if n_in and n_out:
+                    call("cnrma_sparse_kernel_map_transpose", ptr(nbr), n_out, None, K, n_in, ptr(nbr_t), stream())
+                else:
+                    nbr_t.fill_(-1)
+                grad_F = _conv_on_table(g, n_in, nbr_t, w3.transpose(1, 2).contiguous(), ctx.precision)
+        if ctx.needs_input_grad[1]:
+            rows = 2048
+            chunks = _lib.load().cnrma_sparse_conv_wgrad_chunks(max(n_out, 1), rows)
+            slabs = torch.zeros((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
+            if n_out:
+                call("cnrma_sparse_conv_wgrad_f32", ptr(F.detach().contiguous().float()), Cin, ptr(nbr), K, ptr(g), Cout,
+                     n_out, None, rows, ptr(slabs), stream())
+            grad_W = slabs.sum(dim=0).view(weight.shape)
+        return grad_F, grad_W, None, None, None
+
+
+def conv_autograd(x, weight, kernel_size=3, stride=1, precision=None):
+    """differentiable MinkowskiConvolution (no fused epilogue): gradients flow to x.F and to the weight"""
+    _lib.require_gpu()
+    K = kernel_size ** 3
+    in_cs = x.cs
+    out_cs = in_cs if stride == 1 else in_cs.strided(stride)
+    nbr = None if (kernel_size == 1 and stride == 1) else in_cs.neighbours(out_cs, kernel_size, in_cs.stride)
+    assert (weight.shape[0] if weight.dim() == 3 else 1) == K
+    out = _ConvFn.apply(x.F, weight, nbr, out_cs.n, precision)
+    return SparseTensor(out, out_cs)
+
+
 def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, precision=None):
     """MinkowskiGenerativeConvolutionTranspose(k=2, s=2): 8 children per parent at half the tensor stride;
     out row k*N + i = in[i] @ W[k] (k decodes with x fastest)."""

@@ -286,6 +286,18 @@ int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feat
                                   const float* scale, const float* shift, int act, int32_t* out_coords,
                                   float* out_feats, float* out_amax, void* stream);
 
+/* Backward of the sparse convolution (training).
+ * cnrma_sparse_kernel_map_transpose: nbr_t[n_in][K] with nbr_t[i][k] = o where nbr[o][k] == i (else -1); the data
+ *   gradient is then the forward convolution of grad_out over nbr_t with the per-offset transposed weights.
+ * cnrma_sparse_conv_wgrad_f32: slabs[chunk][K][Cin][Cout] = sum over the chunk's output rows o of
+ *   in_feats[nbr[o][k]]^T (x) grad_out[o] (fp32 MFMA); the weight gradient is the sum of the
+ *   cnrma_sparse_conv_wgrad_chunks(no_cap, rows_per_chunk) slabs.  nbr == NULL: identity map (K == 1). */
+int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K, int64_t n_in,
+                                      int32_t* nbr_t, void* stream);
+int cnrma_sparse_conv_wgrad_chunks(int64_t no_cap, int rows_per_chunk);
+int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out, int Cout,
+                                int64_t no_cap, const int32_t* no_dev, int rows_per_chunk, float* slabs, void* stream);
+
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */
 int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats, int64_t n_cap, const int32_t* n_dev,

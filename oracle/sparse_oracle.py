@@ -81,6 +81,29 @@ def conv(coords, feats, weight, kernel_size, stride, tensor_stride, out_coords=N
     return out_coords, out
 
 
+def conv_backward(coords, feats, weight, grad_out, kernel_size, stride, tensor_stride, out_coords=None):
+    """gradients of conv() w.r.t. feats and weight (fp64): grad_in[i] += G[o] @ W[k]^T, gradW[k] += F[i]^T @ G[o] for
+    every pair (i, o) of offset k"""
+    coords = np.asarray(coords, dtype=np.int64)
+    W = np.asarray(weight, dtype=np.float64)
+    W3 = W[None] if W.ndim == 2 else W
+    if out_coords is None:
+        out_coords = coords if stride == 1 else stride_coords(coords, tensor_stride * stride)
+    look = Lookup(coords)
+    F = np.asarray(feats, dtype=np.float64)
+    G = np.asarray(grad_out, dtype=np.float64)
+    gF, gW = np.zeros_like(F), np.zeros_like(W3)
+    for k, off in enumerate(kernel_offsets(kernel_size, tensor_stride)):
+        q = out_coords.copy()
+        q[:, 1:] += off
+        idx = look(q)
+        m = idx >= 0
+        if m.any():
+            np.add.at(gF, idx[m], G[m] @ W3[k].T)
+            gW[k] += F[idx[m]].T @ G[m]
+    return gF, gW.reshape(W.shape)
+
+
 def conv_transpose_generative(coords, feats, weight, tensor_stride):
     """k=2 s=2 generative transpose: out[p + off_k*(s/2)] = in[p] @ W[k]; rows ordered k-major (k*N + i)."""
     coords = np.asarray(coords, dtype=np.int64)

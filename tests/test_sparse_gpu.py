@@ -453,3 +453,28 @@ def test_topk_mask_is_exact_under_heavy_ties(device):
         order = np.argsort(-s, kind="stable")[:k]
         exp = np.zeros(n, dtype=bool); exp[order] = True
         assert m.sum() == k and (m == exp).all()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,ts", [(32, 64, 3, 1, 1), (64, 32, 3, 2, 2), (64, 128, 1, 1, 1), (64, 64, 1, 2, 1),
+                                                   (5, 7, 3, 1, 1)])
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_conv_backward_vs_oracle(device, cin, cout, k, stride, ts, precision):
+    """dgrad (forward kernel on the transposed neighbour table) and wgrad (fp32 MFMA over row chunks) of the sparse
+    convolution against the fp64 restatement"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + cout + k + stride)
+    c, f = rand_sparse(rng, n=5000, span=12, C=cin, ts=ts, batch=2)
+    W = (rng.randn(*((k ** 3, cin, cout) if k > 1 else (cin, cout))) / np.sqrt(cin * k ** 3)).astype(np.float32)
+    x = to_st(c, f, ts, device)
+    x.F.requires_grad_(True)
+    Wt = torch.from_numpy(W).to(device).requires_grad_(True)
+    y = S.conv_autograd(x, Wt, k, stride, precision=precision)
+    oc, of = SO.conv(c, f, W, k, stride, ts)
+    G = rng.randn(*of.shape).astype(np.float32)
+    assert (y.cs.C.cpu().numpy() == oc).all()                 # same rows in the same (first-occurrence) order
+    np.testing.assert_allclose(y.F.detach().cpu().numpy(), of, rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(of).max())))
+    (y.F * torch.from_numpy(G).to(device)).sum().backward()
+    gF, gW = SO.conv_backward(c, f, W, G, k, stride, ts)
+    tol = 2e-6
+    assert np.abs(x.F.grad.cpu().numpy() - gF).max() / np.abs(gF).max() < tol
+    assert np.abs(Wt.grad.cpu().numpy() - gW).max() / np.abs(gW).max() < tol
