@@ -503,10 +503,31 @@ def conv_autograd(x, weight, kernel_size=3, stride=1, precision=None):
     return SparseTensor(out, out_cs)
 
 
+def _train(*tensors):
+    """training path wanted: autograd is on and one of the operands carries a gradient"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _act_torch(f, act):
+    return torch.relu(f) if act == "relu" else (torch.nn.functional.elu(f) if act == "elu" else f)
+
+
 def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, precision=None):
     """MinkowskiGenerativeConvolutionTranspose(k=2, s=2): 8 children per parent at half the tensor stride;
     out row k*N + i = in[i] @ W[k] (k decodes with x fastest)."""
     _lib.require_gpu()
+    if _train(x.F, weight):
+        # training: 8 dense GEMMs (no neighbour structure: every parent has all 8 children) through torch / rocBLAS
+        n, half = x.cs.n, x.cs.stride // 2
+        k = torch.arange(8, device=x.device)
+        off = torch.stack((torch.zeros_like(k), k & 1, (k >> 1) & 1, (k >> 2) & 1), dim=1).to(torch.int32) * half
+        out_c = (x.C.unsqueeze(0) + off.unsqueeze(1)).reshape(8 * n, 4).contiguous()
+        out_f = torch.einsum("nc,kcd->knd", x.F, weight.float()).reshape(8 * n, weight.shape[2])
+        if scale is not None:
+            out_f = out_f * scale
+        if shift is not None:
+            out_f = out_f + shift
+        return SparseTensor(_act_torch(out_f, act), CoordSet(out_c, half, None, x.cs.n_batch))
     w = weight.contiguous().float()
     K, Cin, Cout = w.shape
     assert K == 8 and x.cs.stride % 2 == 0
@@ -541,6 +562,10 @@ def max_pool(x, kernel_size=2, stride=2):
     out_cs = x.cs.strided(stride)
     nbr = x.cs.neighbours(out_cs, kernel_size, x.cs.stride)
     C = x.F.shape[1]
+    if _train(x.F):      # training: gather + amax in torch (the gradient goes to the arg-max child)
+        pad = torch.cat((x.F, x.F.new_full((1, C), float("-inf"))))
+        idx = torch.where(nbr < 0, torch.full_like(nbr, x.cs.n), nbr).long()
+        return SparseTensor(pad[idx].amax(dim=1), out_cs)
     out = torch.empty((out_cs.n, C), dtype=torch.float32, device=x.device)
     if out_cs.n:
         call("cnrma_sparse_maxpool_f32", ptr(x.F.contiguous()), C, ptr(nbr), nbr.shape[1], ptr(out), out_cs.n, None,
@@ -556,6 +581,20 @@ def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
     ws = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=x.device)
     w = weight.contiguous().view(-1).float() if weight is not None else None
     b = bias.contiguous().view(-1).float() if bias is not None else None
+    if _train(x.F, weight, bias):    # training: per-scene statistics in torch
+        outs, r0 = [], 0
+        for nb in x.cs.batch_counts():
+            f = x.F[r0:r0 + nb]
+            mu = f.mean(dim=0, keepdim=True)
+            var = ((f - mu) ** 2).mean(dim=0, keepdim=True)
+            y = (f - mu) / torch.sqrt(var + eps)
+            if weight is not None:
+                y = y * weight.view(1, -1)
+            if bias is not None:
+                y = y + bias.view(1, -1)
+            outs.append(torch.relu(y) if relu else y)
+            r0 += nb
+        return SparseTensor(torch.cat(outs), x.cs)
     src = x.F.contiguous()
     if x.cs.n_batch <= 1:
         if n:
@@ -599,6 +638,11 @@ def union_add(a, b):
         n, counts = _lib.read_ints(n_out)[0], None
     cs = CoordSet(out_c[:n], a.cs.stride, m, nbatch)
     cs._counts = counts
+    if _train(a.F, b.F):            # training: the kernel placed the rows (a's first, then b's new ones); sum through torch
+        b_row = cs.neighbours(b.cs, 1, a.cs.stride, method="generic").view(-1).long()
+        f = torch.zeros((n, C), dtype=torch.float32, device=dev)
+        f = torch.cat((a.F, f[na:]))
+        return SparseTensor(f.index_add(0, b_row, b.F), cs)
     return SparseTensor(out_f[:n], cs)
 
 
@@ -631,6 +675,8 @@ def prune(x, keep_mask, n_keep=None, counts=None):
              stream())
     cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch)
     cs._counts = counts
+    if _train(x.F):
+        return SparseTensor(x.F[torch.nonzero(mask).view(-1)], cs)
     return SparseTensor(out_f, cs, None, x.amax)
 
 

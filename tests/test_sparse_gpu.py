@@ -478,3 +478,74 @@ def test_conv_backward_vs_oracle(device, cin, cout, k, stride, ts, precision):
     tol = 2e-6
     assert np.abs(x.F.grad.cpu().numpy() - gF).max() / np.abs(gF).max() < tol
     assert np.abs(Wt.grad.cpu().numpy() - gW).max() / np.abs(gW).max() < tol
+
+
+def test_training_paths_equal_the_inference_kernels(device):
+    """the differentiable (torch-composed) paths of the non-conv sparse ops give the inference kernels' results"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(31)
+    c, f = rand_sparse(rng, n=4000, span=10, C=32, ts=2, batch=2)
+    order = np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))          # scene-major rows (instance norm segments)
+    c, f = c[order], f[order]
+
+    def both(fn):
+        x0 = to_st(c, f, 2, device); x0.cs.n_batch = 2; x0.cs.scene_major = True
+        x1 = to_st(c, f, 2, device); x1.cs.n_batch = 2; x1.cs.scene_major = True
+        x1.F.requires_grad_(True)
+        with torch.no_grad():
+            y0 = fn(x0)
+        y1 = fn(x1)
+        assert y1.F.requires_grad and (y0.C.cpu() == y1.C.cpu()).all()
+        np.testing.assert_allclose(y1.F.detach().cpu().numpy(), y0.F.cpu().numpy(), rtol=2e-5, atol=2e-5)
+        y1.F.sum().backward()
+        assert torch.isfinite(x1.F.grad).all()
+        return y0
+
+    w = torch.from_numpy(rng.randn(32).astype(np.float32)).to(device)
+    b = torch.from_numpy(rng.randn(32).astype(np.float32)).to(device)
+    Wt = torch.from_numpy((rng.randn(8, 32, 16) / 6).astype(np.float32)).to(device)
+    both(lambda x: S.max_pool(x, 2, 2))
+    both(lambda x: S.instance_norm(x, w, b, 1e-8, relu=True))
+    both(lambda x: S.conv_transpose_generative(x, Wt, act="elu"))
+    both(lambda x: S.prune(x, torch.arange(x.cs.n, device=device) % 3 != 1))
+    c2, f2 = rand_sparse(rng, n=3000, span=10, C=32, ts=2, batch=2)
+    other = to_st(c2, f2, 2, device); other.cs.n_batch = 2
+    both(lambda x: S.union_add(x, other))
+
+
+def test_fcaf3d_trains_one_step(device):
+    """backbone + head in training mode: forward through the differentiable sparse ops (dgrad / wgrad kernels for the
+    convolutions), backward, every parameter receives a finite gradient and SGD lowers the loss on the same batch"""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(7)
+    torch.manual_seed(0)
+    pts = torch.from_numpy((rng.rand(6000, 3) * np.array([2.0, 1.6, 1.0])).astype(np.float32)).to(device)
+    feats = torch.from_numpy(rng.randn(6000, 32).astype(np.float32)).to(device)
+    backbone = FCAF3DBackbone(in_channels=32, depth=14).to(device)
+    head = FCAF3DHead(n_classes=4, in_channels=(64, 128, 256, 512), out_channels=128, n_reg_outs=6, voxel_size=0.01,
+                      pts_threshold=100000, assigner=None).to(device)
+    backbone.init_weights(); head.init_weights()
+    backbone.train(); head.train()
+    params = [p for p in list(backbone.parameters()) + list(head.parameters())]
+    opt = torch.optim.SGD(params, lr=1e-3)
+
+    def loss_fn():
+        x, _ = S.voxelize(pts, feats, 0.01)
+        x.F.requires_grad_(True)
+        cen, box, cls, _ = map(list, head(backbone(x)))
+        t = sum((c_[0] ** 2).mean() for c_ in cen) + sum((b_[0][:, :6].log() ** 2).mean() for b_ in box) \
+            + sum((k_[0] ** 2).mean() for k_ in cls)
+        return t, x
+    l0, x = loss_fn()
+    opt.zero_grad()
+    l0.backward()
+    assert torch.isfinite(x.F.grad).all() and float(x.F.grad.abs().sum()) > 0
+    missing = [n for n, p in list(backbone.named_parameters()) + list(head.named_parameters()) if p.grad is None]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in params)
+    opt.step()
+    l1, _ = loss_fn()
+    assert float(l1.detach()) < float(l0.detach()), (float(l0.detach()), float(l1.detach()))
