@@ -271,6 +271,8 @@ def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
     _lib.require_gpu()
     out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order)
     n = _lib.read_ints(n_out)[0]
+    if _train(feats):                     # training: the surviving rows through torch indexing (keeps the graph)
+        return SparseTensor(feats[src[:n].long()], CoordSet(out_c[:n], 1, m)), src[:n]
     return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
 
 
@@ -282,7 +284,10 @@ def sparse_collate(list_of_coords_feats, voxel_size):
     parts = [_voxelize_enqueue(c, f, voxel_size, b, "morton") for b, (c, f) in enumerate(list_of_coords_feats)]
     counts = _lib.read_ints(torch.cat([p[3] for p in parts]))       # ONE device->host read for all scenes
     C = torch.cat([p[0][:n] for p, n in zip(parts, counts)])
-    F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
+    if _train(*[f for _, f in list_of_coords_feats]):
+        F = torch.cat([f.float()[p[2][:n].long()] for (_, f), p, n in zip(list_of_coords_feats, parts, counts)])
+    else:
+        F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
     cs = CoordSet(C, 1, None, len(parts))
     cs.scene_major = True
     cs._counts = counts

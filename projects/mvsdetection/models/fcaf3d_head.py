@@ -32,6 +32,88 @@ class _TestCfg(dict):
     __getattr__ = dict.get
 
 
+def _without_type(cfg):
+    return {k: v for k, v in dict(cfg).items() if k not in ("type", "use_sigmoid")}
+
+
+class _SigmoidFocalLoss(nn.Module):
+    """mmdet FocalLoss(use_sigmoid=True): sum over rows and classes of alpha_t (1 - p_t)^gamma BCE / avg_factor;
+    label < 0 (or >= n_classes) = background row (all-zero target)."""
+
+    def __init__(self, gamma=2.0, alpha=0.25, loss_weight=1.0, **_):
+        super().__init__()
+        self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
+
+    def forward(self, pred, labels, avg_factor=None):
+        t = torch.zeros_like(pred)
+        pos = (labels >= 0) & (labels < pred.shape[1])
+        t[pos.nonzero().view(-1), labels[pos].long()] = 1.0
+        p = pred.sigmoid()
+        pt = (1 - p) * t + p * (1 - t)
+        w = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)
+        loss = nn.functional.binary_cross_entropy_with_logits(pred, t, reduction="none") * w
+        return self.loss_weight * loss.sum() / (avg_factor if avg_factor is not None else max(loss.numel(), 1))
+
+
+class _SigmoidBCELoss(nn.Module):
+    """mmdet CrossEntropyLoss(use_sigmoid=True): BCE with logits, summed / avg_factor"""
+
+    def __init__(self, loss_weight=1.0, **_):
+        super().__init__()
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, avg_factor=None):
+        loss = nn.functional.binary_cross_entropy_with_logits(pred, target.float(), reduction="none")
+        return self.loss_weight * loss.sum() / (avg_factor if avg_factor is not None else max(loss.numel(), 1))
+
+
+class _AxisAlignedIoU3DLoss(nn.Module):
+    """IoU3DLoss(with_yaw=False) of the FCAF3D code base: (1 - IoU3D) of (cx,cy,cz,w,l,h) boxes, weighted, / avg_factor.
+    The rotated variant (with_yaw=True, ARKit) needs a differentiable rotated IoU and is not provided."""
+
+    def __init__(self, loss_weight=1.0, with_yaw=False, **_):
+        super().__init__()
+        if with_yaw:
+            raise NotImplementedError("rotated IoU3D loss (with_yaw=True) is not available without mmdet3d")
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        p_lo, p_hi = pred[:, :3] - pred[:, 3:6] / 2, pred[:, :3] + pred[:, 3:6] / 2
+        t_lo, t_hi = target[:, :3] - target[:, 3:6] / 2, target[:, :3] + target[:, 3:6] / 2
+        inter = (torch.min(p_hi, t_hi) - torch.max(p_lo, t_lo)).clamp(min=0).prod(dim=1)
+        union = pred[:, 3:6].prod(dim=1) + target[:, 3:6].prod(dim=1) - inter
+        loss = 1 - inter / union.clamp(min=1e-8)
+        if weight is not None:
+            loss = loss * weight
+        return self.loss_weight * loss.sum() / (avg_factor if avg_factor is not None else max(loss.numel(), 1))
+
+
+class GTBoxes:
+    """the three attributes of mmdet3d's DepthInstance3DBoxes the assigner and the loss touch, for use without mmdet3d:
+    tensor [m,7] = (x, y, z_bottom, dx, dy, dz, yaw), gravity_center [m,3], volume [m]"""
+
+    def __init__(self, tensor):
+        self.tensor = tensor.float()
+        if self.tensor.shape[1] == 6:
+            self.tensor = torch.cat((self.tensor, self.tensor.new_zeros(len(self.tensor), 1)), dim=1)
+
+    @property
+    def gravity_center(self):
+        c = self.tensor[:, :3].clone()
+        c[:, 2] += self.tensor[:, 5] / 2
+        return c
+
+    @property
+    def volume(self):
+        return self.tensor[:, 3] * self.tensor[:, 4] * self.tensor[:, 5]
+
+    def __len__(self):
+        return len(self.tensor)
+
+    def to(self, device):
+        return GTBoxes(self.tensor.to(device))
+
+
 @HEADS.register_module()
 class FCAF3DHead(nn.Module):
     def __init__(self, n_classes, in_channels, out_channels, n_reg_outs, voxel_size, pts_threshold, assigner,
@@ -48,8 +130,10 @@ class FCAF3DHead(nn.Module):
         if HAVE_MMDET:
             from mmdet.models.builder import build_loss
             self.loss_centerness, self.loss_bbox, self.loss_cls = map(build_loss, (loss_centerness, loss_bbox, loss_cls))
-        else:
-            self.loss_centerness = self.loss_bbox = self.loss_cls = None
+        else:   # the three losses the configs name, restated in torch (mmdet / mmdet3d are third-party: unpinned)
+            self.loss_centerness = _SigmoidBCELoss(**_without_type(loss_centerness))
+            self.loss_bbox = _AxisAlignedIoU3DLoss(**_without_type(loss_bbox))
+            self.loss_cls = _SigmoidFocalLoss(**_without_type(loss_cls))
         self.train_cfg = train_cfg
         self.test_cfg = _TestCfg(test_cfg) if isinstance(test_cfg, dict) else test_cfg
         self.pts_threshold = pts_threshold
@@ -180,6 +264,22 @@ class FCAF3DHead(nn.Module):
     def _bbox_pred_to_bbox(self, points, bbox_pred):
         if bbox_pred.shape[0] == 0:
             return bbox_pred
+        if torch.is_grad_enabled() and bbox_pred.requires_grad:       # training: the same formulas in torch (:300-349)
+            b, p = bbox_pred, points
+            ctr = torch.stack((p[:, 0] + (b[:, 1] - b[:, 0]) / 2, p[:, 1] + (b[:, 3] - b[:, 2]) / 2,
+                               p[:, 2] + (b[:, 5] - b[:, 4]) / 2), dim=-1)
+            if b.shape[1] == 6:
+                return torch.cat((ctr, torch.stack((b[:, 0] + b[:, 1], b[:, 2] + b[:, 3], b[:, 4] + b[:, 5]), -1)), dim=-1)
+            if self.yaw_parametrization == "naive":
+                return torch.cat((ctr, torch.stack((b[:, 0] + b[:, 1], b[:, 2] + b[:, 3], b[:, 4] + b[:, 5]), -1), b[:, 6:7]), -1)
+            if self.yaw_parametrization == "sin-cos":
+                norm = torch.sqrt(b[:, 6:7] ** 2 + b[:, 7:8] ** 2)
+                size = torch.stack((b[:, 0] + b[:, 1], b[:, 2] + b[:, 3], b[:, 4] + b[:, 5]), -1)
+                return torch.cat((ctr, size, torch.atan2(b[:, 6:7] / norm, b[:, 7:8] / norm)), -1)
+            scale = b[:, 0] + b[:, 1] + b[:, 2] + b[:, 3]
+            q = torch.exp(torch.sqrt(b[:, 6] ** 2 + b[:, 7] ** 2))
+            return torch.cat((ctr, torch.stack((scale / (1 + q), scale / (1 + q) * q, b[:, 5] + b[:, 4],
+                                                0.5 * torch.atan2(b[:, 6], b[:, 7])), -1)), dim=-1)
         return S.decode_boxes(points.float(), bbox_pred, self.yaw_parametrization)
 
     def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, scene_id=None, save_path=None):
@@ -240,9 +340,46 @@ class FCAF3DHead(nn.Module):
         return [(torch.cat(bx), torch.cat(scr)) for bx, scr in per_scene]
 
     def loss(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
-        if self.loss_cls is None:
-            raise NotImplementedError("training losses need mmdet's loss registry (SURVEY.md 8(f) row 3)")
-        raise NotImplementedError("loss path is a later-round item")
+        """per-scene assignment + centerness / IoU / focal losses, averaged over the scenes (reference :142-167)"""
+        assert len(centernesses[0]) == len(bbox_preds[0]) == len(cls_scores[0]) == len(points[0]) == len(gt_bboxes) \
+            == len(gt_labels)
+        per = [self._loss_single([x[i] for x in centernesses], [x[i] for x in bbox_preds], [x[i] for x in cls_scores],
+                                 [x[i] for x in points], gt_bboxes[i], gt_labels[i]) for i in range(len(gt_bboxes))]
+        return dict(loss_centerness=torch.mean(torch.stack([p[0] for p in per])),
+                    loss_bbox=torch.mean(torch.stack([p[1] for p in per])),
+                    loss_cls=torch.mean(torch.stack([p[2] for p in per])))
+
+    def _loss_single(self, centernesses, bbox_preds, cls_scores, points, gt_bboxes, gt_labels):
+        """reference :170-214 (single process: reduce_mean is the identity; under DDP mmdet's reduce_mean averages the
+        normalisers over the ranks)"""
+        if self.assigner is None:
+            raise ValueError("FCAF3DHead.loss needs an assigner (config key `assigner`)")
+        if not hasattr(gt_bboxes, "gravity_center"):
+            gt_bboxes = GTBoxes(torch.as_tensor(gt_bboxes))
+        with torch.no_grad():
+            centerness_targets, bbox_targets, labels = self.assigner.assign(points, gt_bboxes, gt_labels)
+        centerness, bbox_pred, cls_score, pts = map(torch.cat, (centernesses, bbox_preds, cls_scores, points))
+        pos = torch.nonzero(labels >= 0).squeeze(1)
+        n_pos = max(_reduce_mean(torch.tensor(float(len(pos)), device=centerness.device)), 1.0)
+        loss_cls = self.loss_cls(cls_score, labels, avg_factor=n_pos)
+        pos_ctr, pos_box = centerness[pos], bbox_pred[pos]
+        pos_ctr_t = centerness_targets[pos].unsqueeze(1)
+        denorm = max(_reduce_mean(pos_ctr_t.sum().detach()), 1e-6)
+        if len(pos) > 0:
+            loss_centerness = self.loss_centerness(pos_ctr, pos_ctr_t, avg_factor=n_pos)
+            loss_bbox = self.loss_bbox(self._bbox_pred_to_bbox(pts[pos], pos_box), bbox_targets[pos],
+                                       weight=pos_ctr_t.squeeze(1), avg_factor=denorm)
+        else:
+            loss_centerness, loss_bbox = pos_ctr.sum(), pos_box.sum()
+        return loss_centerness, loss_bbox, loss_cls
+
+
+def _reduce_mean(t):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = t.clone()
+        dist.all_reduce(t.div_(dist.get_world_size()))
+    return float(t)
 
 
 def compute_centerness(bbox_targets):

@@ -161,8 +161,15 @@ class RayMarching(nn.Module):
         assert B == 1, "the reference is structurally batch-1 per GPU (ray_marching.py:707)"
         self.points_detection = []
         for b in range(B):
+            pinv = rma.projection_inverse(projections[:, b].cpu(), self.backbone2d_stride).to(features.device)
+            if torch.is_grad_enabled() and features.requires_grad and self.ray_marching_type == "neus":
+                # training: the gradient of the aggregated features flows back into the 2D feature maps (:793-797)
+                coords, feats = rma.AggregatePoints.apply(features[:, b], pinv, tsdf[b, 0].detach(), self.voxel_dim,
+                                                          self.voxel_size, self.origin.view(-1).tolist(), 300,
+                                                          self.neus_threshold, (0.0, 0.0, 0.0), None, "numpy", None)
+                self.points_detection.append(torch.cat((coords, feats), dim=1))
+                continue
             nhwc = rma.to_nhwc(features[:, b])
-            pinv = rma.projection_inverse(projections[:, b].cpu(), self.backbone2d_stride).to(nhwc.device)
             pts, _ = rma.aggregate_rows(nhwc, pinv, tsdf[b, 0], self.voxel_dim, self.voxel_size,
                                         self.origin.view(-1).tolist(), 300, self.neus_threshold,
                                         self.ray_marching_type, self.depth_points)
@@ -176,7 +183,11 @@ class RayMarching(nn.Module):
             if self.max_points is not None:
                 mask = sample_points(points[b], max_points=self.max_points)        # numpy global RNG, like the reference
             off = offsets[b].view(-1).tolist()
-            c, f = rma.select_rows(points[b], off, mask)
+            if torch.is_grad_enabled() and points[b].requires_grad:      # training: keep the autograd graph of the features
+                keep = points[b] if mask is None else points[b][torch.as_tensor(mask, device=points[b].device).bool()]
+                c, f = keep[:, :3].detach() + points[b].new_tensor(off), keep[:, 3:]
+            else:
+                c, f = rma.select_rows(points[b], off, mask)
             gt = gt_bboxes[b] if gt_bboxes is not None else None
             if self.feature_transform is not None and not test:
                 c, gt = self.feature_transform(c, gt)

@@ -117,3 +117,44 @@ def test_raymarching_with_atlas3d_predicts_its_own_tsdf(device, tmp_path):
     got = model.points_detection[0].cpu()
     assert got.shape == pts.shape and count_mismatch(got[:, :3], pts[:, :3]) == 0
     assert os.path.exists(tmp_path / "r" / "s" / "s_bbox_raw.npz")
+
+
+def test_raymarching_train_step(device, tmp_path):
+    """SURVEY.md 8f rank 3 end to end: train_step of the registered detector on a synthetic scene with ground-truth boxes --
+    differentiable aggregation (gradient reaches the 2D feature maps), sparse network on the dgrad / wgrad kernels, FCAF3D
+    assignment + centerness / IoU / focal losses; a few SGD steps on the same scene lower the loss"""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model
+    from cnrma_amd import synth
+    sc = synth.make_scene("tiny", seed=6)
+    C = sc["features"].shape[2]
+    cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+    m = dict(cfg["model"])
+    m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
+             use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14))
+    torch.manual_seed(2)
+    model = build_model(m)
+    model.detection_backbone.init_weights()
+    model.detection_head.init_weights()
+    model = model.to(device).train()
+    dims = np.array(sc["dims"], dtype=np.float32) * 0.04
+    boxes = torch.tensor([[0.35 * dims[0], 0.4 * dims[1], 0.1 * dims[2], 0.5, 0.4, 0.5, 0.0],
+                          [0.65 * dims[0], 0.6 * dims[1], 0.2 * dims[2], 0.4, 0.6, 0.4, 0.0]], device=device)
+    feats = sc["features"][:, 0].to(device).requires_grad_(True)
+    data = dict(features=[feats], projection=[sc["projection"][:, 0].to(device)], tsdf=sc["tsdf"].to(device),
+                offset=[torch.zeros(3, device=device)], gt_bboxes_3d=[boxes], gt_labels_3d=[torch.tensor([1, 3], device=device)])
+    opt = torch.optim.SGD(model.parameters(), lr=2e-3)
+    losses = []
+    for it in range(4):
+        out = model.train_step(dict(data), None)
+        assert set(out["log_vars"]) >= {"loss_centerness", "loss_bbox", "loss_cls", "total_loss"}
+        opt.zero_grad()
+        if feats.grad is not None:
+            feats.grad = None
+        out["loss"].backward()
+        if it == 0:
+            assert feats.grad is not None and torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
+            assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(float(out["loss"].detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
