@@ -73,11 +73,11 @@ class _AxisAlignedIoU3DLoss(nn.Module):
 
     def __init__(self, loss_weight=1.0, with_yaw=False, **_):
         super().__init__()
-        if with_yaw:
-            raise NotImplementedError("rotated IoU3D loss (with_yaw=True) is not available without mmdet3d")
-        self.loss_weight = loss_weight
+        self.loss_weight, self.with_yaw = loss_weight, with_yaw      # building the ARKit config for inference must not fail
 
     def forward(self, pred, target, weight=None, avg_factor=None):
+        if self.with_yaw:
+            raise NotImplementedError("rotated IoU3D loss (with_yaw=True) is not available without mmdet3d")
         p_lo, p_hi = pred[:, :3] - pred[:, 3:6] / 2, pred[:, :3] + pred[:, 3:6] / 2
         t_lo, t_hi = target[:, :3] - target[:, 3:6] / 2, target[:, :3] + target[:, 3:6] / 2
         inter = (torch.min(p_hi, t_hi) - torch.max(p_lo, t_lo)).clamp(min=0).prod(dim=1)
