@@ -17,6 +17,7 @@ SIGNATURES = {
     "cnrma_abi_version": (c_int, []),
     "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
     "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P]),
+    "cnrma_backproject_backward_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, P, P]),
     "cnrma_backproject_index_f32": (c_int, [P, I, I, I, I, I, F, F, F, F, P, P, P, P]),
     "cnrma_ray_params_f32": (c_int, [P, I, I, I, P, P, P]),
     "cnrma_rma_neus_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P]),

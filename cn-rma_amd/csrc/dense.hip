@@ -204,6 +204,63 @@ extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* 
   return launch_accum<1>(p, feat_nhwc, proj, volume, count, st);
 }
 
+// Backward of the accumulate + mean w.r.t. the feature maps (training): volume[c][g] = sum_v feat[v][pix_v(g)][c] / count[g],
+// so every valid (voxel, view) pair adds grad_volume[c][g] / count[g] to grad_feat[v][pix][c].  ~58 voxels share a pixel:
+// float atomics (sum order not fixed: training only).  One lane per (voxel, 4 channels): a wave adds 128-byte channel
+// vectors, the shape the memory-side atomic units run at full rate for.
+template <int LPV>
+__global__ __launch_bounds__(256) void backproject_backward_kernel(DenseParams p, const float* __restrict__ grad_volume,
+                                                                   const int32_t* __restrict__ count,
+                                                                   const float* __restrict__ proj,
+                                                                   float* __restrict__ grad_feat) {
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t g = t / LPV;
+  const int sub = (int)(t % LPV);
+  if (g >= G) return;
+  const int cnt = count[g];
+  if (cnt <= 0) return;
+  float wx, wy, wz;
+  voxel_world(p, g, &wx, &wy, &wz);
+  const float denom = (float)cnt;
+  const int64_t plane = (int64_t)p.H * p.W * p.C;
+  for (int c = 4 * sub; c < p.C; c += 4 * LPV) {
+    float gq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gq[j] = (c + j < p.C) ? grad_volume[(int64_t)(c + j) * G + g] / denom : 0.0f;
+    for (int v = 0; v < p.V; ++v) {
+      float rx, ry;
+      if (!project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry)) continue;
+      float* q = grad_feat + v * plane + ((int64_t)(int)ry * p.W + (int)rx) * p.C + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < p.C) atomicAdd(q + j, gq[j]);
+    }
+  }
+}
+
+extern "C" int cnrma_backproject_backward_f32(const float* grad_volume, const int32_t* count, const float* proj, int V,
+                                              int C, int H, int W, int X, int Y, int Z, float voxel_size, float ox,
+                                              float oy, float oz, float* grad_feat_nhwc, void* stream) {
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0 || grad_volume == nullptr || count == nullptr ||
+      grad_feat_nhwc == nullptr)
+    return CNRMA_EINVAL;
+  DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(grad_feat_nhwc, 0, (size_t)V * H * W * C * sizeof(float), st);
+  if (e != hipSuccess) return -(int)e;
+  const int64_t G = (int64_t)X * Y * Z;
+  if (C >= 32) {
+    hipLaunchKernelGGL((backproject_backward_kernel<8>), dim3((unsigned)ceil_div(G * 8, 256)), dim3(256), 0, st, p,
+                       grad_volume, count, proj, grad_feat_nhwc);
+  } else {
+    hipLaunchKernelGGL((backproject_backward_kernel<1>), dim3((unsigned)ceil_div(G, 256)), dim3(256), 0, st, p, grad_volume,
+                       count, proj, grad_feat_nhwc);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_backproject_index_f32(const float* proj_view, int H, int W, int X, int Y, int Z, float voxel_size,
                                            float ox, float oy, float oz, int32_t* px, int32_t* py, uint8_t* valid,
                                            void* stream) {

@@ -65,6 +65,30 @@ def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stri
     return volume, count
 
 
+class BackprojectAccum(torch.autograd.Function):
+    """differentiable backproject_accum(): features NCHW [V,C,H,W] -> (volume [C,X,Y,Z], count [X,Y,Z]); the gradient of the
+    volume flows to the feature maps (training of the Atlas 3D network together with the 2D backbone)."""
+
+    @staticmethod
+    def forward(ctx, features_nchw, projections, dims, voxel_size, origin, stride):
+        nhwc = to_nhwc(features_nchw.detach())
+        volume, count = backproject_accum(nhwc, projections, dims, voxel_size, origin, stride)
+        ctx.args = (projections, tuple(dims), float(voxel_size), tuple(float(o) for o in origin), stride, nhwc.shape)
+        ctx.count = count
+        ctx.mark_non_differentiable(count)
+        return volume, count
+
+    @staticmethod
+    def backward(ctx, grad_volume, _grad_count):
+        projections, dims, vs, origin, stride, (V, H, W, C) = ctx.args
+        dev = grad_volume.device
+        proj = _f32(scale_projection(projections.to(torch.float32), stride)).to(dev)
+        g = torch.empty((V, H, W, C), dtype=torch.float32, device=dev)
+        call("cnrma_backproject_backward_f32", ptr(grad_volume.contiguous().float()), ptr(ctx.count), ptr(proj), V, C, H, W,
+             dims[0], dims[1], dims[2], vs, origin[0], origin[1], origin[2], ptr(g), stream())
+        return g.permute(0, 3, 1, 2).contiguous(), None, None, None, None, None
+
+
 def backproject_index(projection_scaled, hw, dims, voxel_size, origin, device):
     """Debug/parity: rounded pixel (px, py) and validity of every voxel for ONE view (ray_marching.py:51-58)."""
     _lib.require_gpu()

@@ -49,6 +49,13 @@ int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V
                                 int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
                                 float* volume, int32_t* count, void* stream);
 
+/* Backward of cnrma_backproject_accum_f32 w.r.t. the feature maps (training):
+ * grad_feat_nhwc[v][pix_v(g)][c] += grad_volume[c][g] / count[g] for every valid (voxel g, view v) pair; the output is
+ * zeroed first; float atomics (~58 voxels share a pixel), so the sum order is not fixed. */
+int cnrma_backproject_backward_f32(const float* grad_volume, const int32_t* count, const float* proj, int V, int C, int H,
+                                   int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                   float* grad_feat_nhwc, void* stream);
+
 /* single view, debug/parity: px,py int32 [G] (rounded pixel, INT32_MIN when not finite), valid uint8 [G] */
 int cnrma_backproject_index_f32(const float* proj_view, int H, int W, int X, int Y, int Z, float voxel_size,
                                 float ox, float oy, float oz, int32_t* px, int32_t* py, uint8_t* valid,

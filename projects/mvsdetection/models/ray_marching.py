@@ -128,9 +128,13 @@ class RayMarching(nn.Module):
         vols, valids = [], []
         org = self.origin.view(-1).tolist()
         for b in range(B):
-            nhwc = rma.to_nhwc(feats[:, b])
-            vol, cnt = rma.backproject_accum(nhwc, projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
-                                             self.backbone2d_stride)
+            if torch.is_grad_enabled() and feats.requires_grad:      # training: gradient of the volume -> feature maps
+                vol, cnt = rma.BackprojectAccum.apply(feats[:, b], projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                                                      self.backbone2d_stride)
+            else:
+                nhwc = rma.to_nhwc(feats[:, b])
+                vol, cnt = rma.backproject_accum(nhwc, projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                                                 self.backbone2d_stride)
             vols.append(vol)
             valids.append((cnt > 0).unsqueeze(0))
         self.volume = torch.stack(vols)

@@ -158,3 +158,39 @@ def test_raymarching_train_step(device, tmp_path):
         opt.step()
         losses.append(float(out["loss"].detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_raymarching_train_step_with_atlas3d(device, tmp_path):
+    """joint training step with the Atlas 3D network in the loop: TSDF losses (their gradient reaches the 2D feature maps
+    through the dense unprojection's backward) + detection losses (through the aggregation's backward)"""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model
+    from cnrma_amd import synth
+    sc = synth.make_scene("tiny", seed=9)
+    C = sc["features"].shape[2]
+    X, Y, Z = sc["dims"]
+    cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+    m = dict(cfg["model"])
+    m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
+             use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14),
+             backbone_3d=dict(type="AtlasBackbone3D", channels=[C, 16, 32], layers_down=[1, 1, 1], layers_up=[1, 1], drop=0.0,
+                              zero_init_residual=False, cond_proj=False, norm="BN"),
+             tsdf_head=dict(type="AtlasTSDFHead", input_channels=[C, 16], n_scales=2, voxel_size=0.04, label_smoothing=1.05,
+                            sparse_threshold=[0.99]))
+    torch.manual_seed(4)
+    model = build_model(m)
+    model.detection_backbone.init_weights(); model.detection_head.init_weights()
+    model = model.to(device).train()
+    dims = np.array(sc["dims"], dtype=np.float32) * 0.04
+    boxes = torch.tensor([[0.5 * dims[0], 0.5 * dims[1], 0.1 * dims[2], 0.6, 0.5, 0.5, 0.0]], device=device)
+    feats = sc["features"][:, 0].to(device).requires_grad_(True)
+    gt = sc["tsdf"].to(device).clamp(-1, 1)
+    tsdf_list = {"tsdf_gt_004": gt, "tsdf_gt_008": torch.nn.functional.avg_pool3d(gt, 2)}
+    data = dict(features=[feats], projection=[sc["projection"][:, 0].to(device)], offset=[torch.zeros(3, device=device)],
+                gt_bboxes_3d=[boxes], gt_labels_3d=[torch.tensor([2], device=device)], tsdf_list=tsdf_list)
+    out = model.train_step(dict(data), None)
+    assert {"tsdf_loss_004", "tsdf_loss_008", "loss_cls", "loss_bbox", "loss_centerness"} <= set(out["log_vars"])
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]) and torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
+    g3d = [p.grad for p in model.backbone3d.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in g3d)

@@ -286,3 +286,22 @@ def test_aggregation_backward_vs_oracle_autograd(device, max_points):
     (feats * g.to(device)).sum().backward()
     np.testing.assert_allclose(f_gpu.grad.cpu().numpy(), f_cpu.grad.numpy(), rtol=1e-5, atol=1e-6)
     assert float(f_gpu.grad.abs().sum()) > 0
+
+
+def test_dense_unprojection_backward_vs_oracle_autograd(device):
+    """gradient of the mean feature volume w.r.t. the 2D feature maps: float-atomic scatter == torch autograd through the
+    oracle's gather / mean (sum order differs: tolerance, not bits)"""
+    from cnrma_amd import rma, synth
+    from oracle import rma_oracle as O
+    sc = synth.make_scene("tiny", seed=8)
+    proj = sc["projection"][:, 0]
+    f_cpu = sc["features"][:, 0].clone().requires_grad_(True)
+    vol, cnt = O.backproject_accum(sc["dims"], 0.04, sc["origin"], proj, f_cpu, sc["stride"])
+    g = torch.randn(vol.shape, generator=torch.Generator().manual_seed(3))
+    (vol * g).sum().backward()
+    f_gpu = sc["features"][:, 0].clone().to(device).requires_grad_(True)
+    v2, c2 = rma.BackprojectAccum.apply(f_gpu, proj, sc["dims"], 0.04, sc["origin"], sc["stride"])
+    assert count_mismatch(v2.detach(), vol.detach()) == 0 and torch.equal(c2.cpu(), cnt.to(torch.int32))
+    (v2 * g.to(device)).sum().backward()
+    ref = f_cpu.grad.numpy()
+    np.testing.assert_allclose(f_gpu.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
