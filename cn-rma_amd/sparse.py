@@ -272,7 +272,7 @@ def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
     out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order)
     n = _lib.read_ints(n_out)[0]
     if _train(feats):                     # training: the surviving rows through torch indexing (keeps the graph)
-        return SparseTensor(feats[src[:n].long()], CoordSet(out_c[:n], 1, m)), src[:n]
+        return SparseTensor(feats.index_select(0, src[:n].long()), CoordSet(out_c[:n], 1, m)), src[:n]
     return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
 
 
@@ -285,7 +285,7 @@ def sparse_collate(list_of_coords_feats, voxel_size):
     counts = _lib.read_ints(torch.cat([p[3] for p in parts]))       # ONE device->host read for all scenes
     C = torch.cat([p[0][:n] for p, n in zip(parts, counts)])
     if _train(*[f for _, f in list_of_coords_feats]):
-        F = torch.cat([f.float()[p[2][:n].long()] for (_, f), p, n in zip(list_of_coords_feats, parts, counts)])
+        F = torch.cat([f.float().index_select(0, p[2][:n].long()) for (_, f), p, n in zip(list_of_coords_feats, parts, counts)])
     else:
         F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
     cs = CoordSet(C, 1, None, len(parts))
@@ -562,15 +562,42 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
     return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch), out_split, out_amax)
 
 
+class _MaxPoolFn(torch.autograd.Function):
+    """max over the window through the pooling kernel; backward: every input row has exactly ONE parent (k = stride), so
+    grad_in[i] = grad_out[parent(i)] where F[i] attains the parent's maximum -- plain gathers, no scatter"""
+
+    @staticmethod
+    def forward(ctx, F, nbr, n_out):
+        Fd = F.detach().contiguous()
+        C = Fd.shape[1]
+        out = torch.empty((n_out, C), dtype=torch.float32, device=Fd.device)
+        if n_out:
+            call("cnrma_sparse_maxpool_f32", ptr(Fd), C, ptr(nbr), nbr.shape[1], ptr(out), n_out, None, stream())
+        ctx.save_for_backward(Fd, out)
+        ctx.nbr = nbr
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        Fd, out = ctx.saved_tensors
+        nbr = ctx.nbr
+        n_in, K = Fd.shape[0], nbr.shape[1]
+        nbr_t = torch.empty((n_in, K), dtype=torch.int32, device=Fd.device)
+        call("cnrma_sparse_kernel_map_transpose", ptr(nbr), out.shape[0], None, K, n_in, ptr(nbr_t), stream())
+        parent = nbr_t.max(dim=1).values.long()
+        has = parent >= 0
+        parent = parent.clamp(min=0)
+        hit = (Fd == out.index_select(0, parent)) & has.unsqueeze(1)
+        return grad_out.contiguous().index_select(0, parent) * hit.to(grad_out.dtype), None, None
+
+
 def max_pool(x, kernel_size=2, stride=2):
     _lib.require_gpu()
     out_cs = x.cs.strided(stride)
     nbr = x.cs.neighbours(out_cs, kernel_size, x.cs.stride)
     C = x.F.shape[1]
-    if _train(x.F):      # training: gather + amax in torch (the gradient goes to the arg-max child)
-        pad = torch.cat((x.F, x.F.new_full((1, C), float("-inf"))))
-        idx = torch.where(nbr < 0, torch.full_like(nbr, x.cs.n), nbr).long()
-        return SparseTensor(pad[idx].amax(dim=1), out_cs)
+    if _train(x.F):      # training: the kernel's maximum; the gradient goes to the child that attains it
+        return SparseTensor(_MaxPoolFn.apply(x.F, nbr, out_cs.n), out_cs)
     out = torch.empty((out_cs.n, C), dtype=torch.float32, device=x.device)
     if out_cs.n:
         call("cnrma_sparse_maxpool_f32", ptr(x.F.contiguous()), C, ptr(nbr), nbr.shape[1], ptr(out), out_cs.n, None,
@@ -681,7 +708,7 @@ def prune(x, keep_mask, n_keep=None, counts=None):
     cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch)
     cs._counts = counts
     if _train(x.F):
-        return SparseTensor(x.F[torch.nonzero(mask).view(-1)], cs)
+        return SparseTensor(x.F.index_select(0, torch.nonzero(mask).view(-1)), cs)
     return SparseTensor(out_f, cs, None, x.amax)
 
 

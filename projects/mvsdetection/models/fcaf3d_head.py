@@ -249,9 +249,10 @@ class FCAF3DHead(nn.Module):
             reg_distance = torch.exp(scale(reg_final[:, :6]))                                  # :284
             bbox_pred = torch.cat((reg_distance, reg_final[:, 6:]), dim=1)                     # :285-286
             perms = x.decomposition_permutations
-            centernesses = [centerness[p] for p in perms]
-            bbox_preds = [bbox_pred[p] for p in perms]
-            cls_scores = [cls_score[p] for p in perms]
+            # index_select: its backward is an index_add (advanced indexing's sorts, far slower on large row sets)
+            centernesses = [centerness.index_select(0, p) for p in perms]
+            bbox_preds = [bbox_pred.index_select(0, p) for p in perms]
+            cls_scores = [cls_score.index_select(0, p) for p in perms]
             points = [c * self.voxel_size for c in x.decomposed_coordinates]                   # :294-296
             return centernesses, bbox_preds, cls_scores, points, prune_scores
         # single scene, eval: the three 1x1 convolutions are ONE GEMM and the whole tail is one kernel

@@ -188,7 +188,8 @@ class RayMarching(nn.Module):
                 mask = sample_points(points[b], max_points=self.max_points)        # numpy global RNG, like the reference
             off = offsets[b].view(-1).tolist()
             if torch.is_grad_enabled() and points[b].requires_grad:      # training: keep the autograd graph of the features
-                keep = points[b] if mask is None else points[b][torch.as_tensor(mask, device=points[b].device).bool()]
+                keep = points[b] if mask is None else points[b].index_select(
+                    0, torch.nonzero(torch.as_tensor(mask, device=points[b].device)).view(-1))
                 c, f = keep[:, :3].detach() + points[b].new_tensor(off), keep[:, 3:]
             else:
                 c, f = rma.select_rows(points[b], off, mask)

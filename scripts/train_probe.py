@@ -1,0 +1,41 @@
+"""time of one training step of the detector at the ScanNet shape (features and TSDF given; detection losses only)"""
+import os, sys, time, runpy
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import projects.mvsdetection  # noqa: F401
+from projects.mvsdetection.registry import build_model
+from cnrma_amd import synth
+dev = torch.device("cuda:0")
+shape = sys.argv[1] if len(sys.argv) > 1 else "S"
+sc = synth.make_scene(shape, seed=0)
+C = sc["features"].shape[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cfg = runpy.run_path(os.path.join(root, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+m = dict(cfg["model"])
+m.update(save_path="/tmp/cnrma_train_probe", voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]),
+         use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34))
+torch.manual_seed(0)
+model = build_model(m)
+model.detection_backbone.init_weights(); model.detection_head.init_weights()
+model = model.to(dev).train()
+dims = np.array(sc["dims"], dtype=np.float32) * 0.04
+rng = np.random.RandomState(0)
+boxes = torch.tensor([[rng.uniform(.2, .8) * dims[0], rng.uniform(.2, .8) * dims[1], rng.uniform(0, .3) * dims[2], .8, .6, .7, 0.]
+                      for _ in range(12)], dtype=torch.float32, device=dev)
+labels = torch.from_numpy(rng.randint(0, 18, size=12)).to(dev)
+feats = sc["features"][:, 0].to(dev).requires_grad_(True)
+data = dict(features=[feats], projection=[sc["projection"][:, 0].to(dev)], tsdf=sc["tsdf"].to(dev),
+            offset=[torch.zeros(3, device=dev)], gt_bboxes_3d=[boxes], gt_labels_3d=[labels])
+opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+def step():
+    out = model.train_step(dict(data), None)
+    opt.zero_grad(); feats.grad = None
+    out["loss"].backward()
+    opt.step()
+    return float(out["loss"].detach())
+for _ in range(2): l = step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 5
+for _ in range(n): l = step()
+torch.cuda.synchronize()
+print(f"{shape}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms per training step, loss {l:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
