@@ -1180,7 +1180,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   };
   if (Cout <= 32) pick(T128x32);
   else if (six && mode == 1) {
-    if (Cout >= 128) pick(no_cap >= 16384 && no_cap < 50000 ? T128x128 : (no_cap < 1000 && Cout < 256 ? T64x64 : T64x128));
+    if (Cout >= 128) pick(no_cap >= 16384 && no_cap < 40000 ? T128x128 : (no_cap < 1000 && Cout < 256 ? T64x64 : T64x128));
     else pick(no_cap >= 200000 && Cin > 32 ? T128x64 : T64x64);
   }
   else if (six && no_cap < 1000 && Cout >= 256) pick(T64x128);
