@@ -486,7 +486,11 @@ class _ConvFn(torch.autograd.Function):
                     nbr_t.fill_(-1)
                 grad_F = _conv_on_table(g, n_in, nbr_t, w3.transpose(1, 2).contiguous(), ctx.precision)
         if ctx.needs_input_grad[1]:
-            rows = 2048
+            # one wave per (row chunk, offset, 64x64 weight tile): size the chunks for ~8 waves per SIMD (latency hiding)
+            tiles = ((Cin + 63) // 64) * ((Cout + 63) // 64)
+            want = max(1, 8192 // (K * tiles))
+            rows = max(64, -(-max(n_out, 1) // want))
+            rows += rows & 1
             chunks = _lib.load().cnrma_sparse_conv_wgrad_chunks(max(n_out, 1), rows)
             slabs = torch.zeros((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
             if n_out:
