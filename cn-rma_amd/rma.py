@@ -231,10 +231,7 @@ def sample_mask_device(m_dev, M, n_keep, seed=None):
 def _drop_single_sample_views(cnt, wsum, V):
     """Reference quirk: a view that keeps exactly ONE sample is dropped entirely -- torch.squeeze() makes the
     index 0-dim, len() raises and the bare except skips the view (ray_marching.py:781-782, :282-287)."""
-    per_view = cnt.view(V, -1).sum(dim=1)
-    keep = (per_view != 1).to(cnt.dtype).view(V, 1)
-    cnt.view(V, -1).mul_(keep)
-    wsum.view(V, -1).mul_(keep.to(wsum.dtype))
+    call("cnrma_rma_drop_single_sample_views", ptr(cnt), ptr(wsum), int(V), cnt.numel() // int(V), stream())
 
 
 def rma_view_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",

@@ -151,6 +151,10 @@ int cnrma_rma_depth_emit_f32(const float* proj_inv, const float* tsdf, const flo
                              float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
                              int feat_stride, void* stream);
 
+/* Reference quirk: a view whose rays keep exactly ONE sample in total is dropped (ray_marching.py:781-782: squeeze()
+ * makes the index 0-dim, len() raises, the bare except skips the view): zeroes that view's counts and weight sums. */
+int cnrma_rma_drop_single_sample_views(int32_t* count, double* wsum, int V, int64_t rays_per_view, void* stream);
+
 /* mean_w[0] = (float)(wsum_total[0] / m_total[0])   -- torch.mean(weights), ray_marching.py:303 */
 int cnrma_rma_mean_weight(const double* wsum_total, const int32_t* m_total, float* mean_w, void* stream);
 
