@@ -177,38 +177,71 @@ __device__ __forceinline__ bool key_matches(uint32_t k, int pass, const int32_t*
   return true;
 }
 
+// Every block resolves the digits of the finished passes itself from the complete global histograms (a 2048-bin scan by
+// 256 threads) instead of a separate one-block "find" launch per pass: first bin whose cumulative count reaches `need`.
+// All threads of the block call it; returns through *digit / *need_next (same values in every thread).
+__device__ __forceinline__ void resolve_digit(const int32_t* __restrict__ hist, int need, int* digit, int* need_next,
+                                              int* smem /* 256/64 + 1 + 2 ints */) {
+  int bins[8], local = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bins[j] = hist[8 * threadIdx.x + j]; local += bins[j]; }
+  int* out = smem + 256 / 64 + 1;
+  if (threadIdx.x == 0) { out[0] = 0; out[1] = 0; }       // need > total (n_keep >= M): the mask kernel keeps every row
+  int total;
+  int ex = block_excl_scan<256>(local, smem, &total);
+  if (ex < need && ex + local >= need) {          // exactly one thread: the crossing lies in its 8 bins
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ex < need && ex + bins[j] >= need) { out[0] = 8 * threadIdx.x + j; out[1] = need - ex; }
+      ex += bins[j];
+    }
+  }
+  __syncthreads();
+  *digit = out[0];
+  *need_next = out[1];
+  __syncthreads();
+}
+
 // block-private LDS histogram of one digit, flushed with (contiguous) global atomics
 __global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
-                                                          uint32_t seed, int pass, SampleWs* __restrict__ ws) {
+                                                          uint32_t seed, int pass, int n_keep, SampleWs* __restrict__ ws) {
   __shared__ int h[2048];
+  __shared__ int rs[256 / 64 + 1 + 2];
+  int32_t prefix[3] = {0, 0, 0};
+  int need = n_keep;
+  for (int q = 0; q < pass; ++q) {
+    int nn;
+    resolve_digit(ws->hist[q], need, &prefix[q], &nn, rs);
+    need = nn;
+  }
   for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
   __syncthreads();
   const int64_t M = m_dev[0];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t k = select_key(scores, seed, (uint32_t)i);
-    if (key_matches(k, pass, ws->prefix)) atomicAdd(&h[key_digit(k, pass)], 1);
+    if (key_matches(k, pass, prefix)) atomicAdd(&h[key_digit(k, pass)], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2048; i += 256)
     if (h[i]) atomicAdd(&ws->hist[pass][i], h[i]);
 }
 
-// one block of 1024 threads, 2 bins each: first digit whose cumulative count reaches need[pass]
-__global__ __launch_bounds__(1024) void sample_find_kernel(SampleWs* __restrict__ ws, int pass, int n_keep) {
-  __shared__ int smem[1024 / 64 + 1];
-  const int need = pass == 0 ? n_keep : ws->need[pass];
-  const int a = ws->hist[pass][2 * threadIdx.x], b = ws->hist[pass][2 * threadIdx.x + 1];
-  int total;
-  const int ex = block_excl_scan<1024>(a + b, smem, &total);
-  if (ex < need && ex + a >= need) { ws->prefix[pass] = 2 * threadIdx.x; ws->need[pass + 1] = need - ex; }
-  else if (ex + a < need && ex + a + b >= need) { ws->prefix[pass] = 2 * threadIdx.x + 1; ws->need[pass + 1] = need - ex - a; }
-  if (threadIdx.x == 0 && pass == 0) ws->need[0] = n_keep;
-}
-
 __global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
-                                                          uint32_t seed, SampleWs* __restrict__ ws) {
+                                                          uint32_t seed, int n_keep, SampleWs* __restrict__ ws) {
+  __shared__ int rs[256 / 64 + 1 + 2];
+  int32_t prefix[3];
+  int need = n_keep;
+  for (int q = 0; q < 3; ++q) {
+    int nn;
+    resolve_digit(ws->hist[q], need, &prefix[q], &nn, rs);
+    need = nn;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {      // the later kernels read the threshold key and the tie quota from here
+    ws->prefix[0] = prefix[0]; ws->prefix[1] = prefix[1]; ws->prefix[2] = prefix[2];
+    ws->need[0] = n_keep; ws->need[3] = need;
+  }
   const int64_t M = m_dev[0];
-  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
+  const uint32_t key = ((uint32_t)prefix[0] << 21) | ((uint32_t)prefix[1] << 10) | (uint32_t)prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     if (select_key(scores, seed, (uint32_t)i) == key) {
       const int slot = atomicAdd(&ws->tie_count, 1);
@@ -222,6 +255,14 @@ __global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __r
                                                               uint32_t seed, int pass, SampleWs* __restrict__ ws) {
   if (ws->tie_count <= 256) return;
   __shared__ int h[2048];
+  __shared__ int rs[256 / 64 + 1 + 2];
+  int32_t prefix2[3] = {0, 0, 0};
+  int need = ws->need[3];
+  for (int q = 0; q < pass; ++q) {
+    int nn;
+    resolve_digit(ws->hist2[q], need, &prefix2[q], &nn, rs);
+    need = nn;
+  }
   for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
   __syncthreads();
   const int64_t M = m_dev[0];
@@ -229,22 +270,11 @@ __global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __r
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     if (select_key(scores, seed, (uint32_t)i) != key) continue;
     const uint32_t k2 = (uint32_t)i;                         // smaller index = kept first
-    if (key_matches(k2, pass, ws->prefix2)) atomicAdd(&h[key_digit(k2, pass)], 1);
+    if (key_matches(k2, pass, prefix2)) atomicAdd(&h[key_digit(k2, pass)], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2048; i += 256)
     if (h[i]) atomicAdd(&ws->hist2[pass][i], h[i]);
-}
-
-__global__ __launch_bounds__(1024) void sample_tie_find_kernel(SampleWs* __restrict__ ws, int pass) {
-  if (ws->tie_count <= 256) return;
-  __shared__ int smem[1024 / 64 + 1];
-  const int need = pass == 0 ? ws->need[3] : ws->need2[pass];
-  const int a = ws->hist2[pass][2 * threadIdx.x], b = ws->hist2[pass][2 * threadIdx.x + 1];
-  int total;
-  const int ex = block_excl_scan<1024>(a + b, smem, &total);
-  if (ex < need && ex + a >= need) { ws->prefix2[pass] = 2 * threadIdx.x; ws->need2[pass + 1] = need - ex; }
-  else if (ex + a < need && ex + a + b >= need) { ws->prefix2[pass] = 2 * threadIdx.x + 1; ws->need2[pass + 1] = need - ex - a; }
 }
 
 __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
@@ -252,12 +282,22 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
                                                           uint8_t* __restrict__ mask) {
   const int64_t M = m_dev[0];
   __shared__ int32_t tie_bound;     // rows with the threshold key are kept when their index <= tie_bound
+  __shared__ int rs[256 / 64 + 1 + 2];
+  int32_t prefix2[3] = {0, 0, 0};
+  if (ws->tie_count > 256) {         // exact: the need-th smallest tie index from the second-level histograms
+    int need2 = ws->need[3];
+    for (int q = 0; q < 3; ++q) {
+      int nn;
+      resolve_digit(ws->hist2[q], need2, &prefix2[q], &nn, rs);
+      need2 = nn;
+    }
+  }
   if (threadIdx.x == 0) {
     // the need smallest indices among the (normally 1, at most 256) rows that carry the threshold key
     const int cnt = min(ws->tie_count, 256), need = ws->need[3];
     int32_t bound = -1;
-    if (ws->tie_count > 256) {       // exact: the need-th smallest tie index from the second-level select
-      bound = (int32_t)(((uint32_t)ws->prefix2[0] << 21) | ((uint32_t)ws->prefix2[1] << 10) | (uint32_t)ws->prefix2[2]);
+    if (ws->tie_count > 256) {
+      bound = (int32_t)(((uint32_t)prefix2[0] << 21) | ((uint32_t)prefix2[1] << 10) | (uint32_t)prefix2[2]);
     } else {
       for (int r = 0; r < need; ++r) {
         int32_t best = 0x7FFFFFFF;
@@ -288,15 +328,11 @@ static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, 
   if (e != hipSuccess) return -(int)e;
   int blocks = (int)(m_cap / 2048 + 1);
   if (blocks > 1024) blocks = 1024;
-  for (int pass = 0; pass < 3; ++pass) {
-    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, ws);
-    hipLaunchKernelGGL(sample_find_kernel, dim3(1), dim3(1024), 0, st, ws, pass, n_keep);
-  }
-  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws);
-  for (int pass = 0; pass < 3; ++pass) {      // no-ops unless more than 256 rows carry the threshold key
+  for (int pass = 0; pass < 3; ++pass)
+    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, n_keep, ws);
+  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, n_keep, ws);
+  for (int pass = 0; pass < 3; ++pass)        // no-ops unless more than 256 rows carry the threshold key
     hipLaunchKernelGGL(sample_tie_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, ws);
-    hipLaunchKernelGGL(sample_tie_find_kernel, dim3(1), dim3(1024), 0, st, ws, pass);
-  }
   hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws, n_keep, mask);
   CNRMA_LAUNCH_CHECK();
   return 0;
