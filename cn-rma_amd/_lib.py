@@ -25,9 +25,9 @@ SIGNATURES = {
                                         P, I, P, I, P, I, P, P]),
     "cnrma_rma_neus_rows_backward_f32": (c_int, [P, I, I, I, I, I, P, P, I, P, P, P, P]),
     "cnrma_rma_neus_march_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
-    "cnrma_rma_neus_emit_rows_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, I, P, P, P, F, F, F, P, I, P, I, P, I, P, P]),
+    "cnrma_rma_neus_emit_rows_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, P, I, P, L, P, P, F, F, F, P, I, P, I, P, I, P, P]),
     "cnrma_sample_workspace_bytes": (c_size_t, []),
-    "cnrma_sample_mask": (c_int, [P, L, I, ctypes.c_uint32, P, P, P]),
+    "cnrma_sample_mask": (c_int, [P, L, I, ctypes.c_uint32, P, P, P, P]),
     "cnrma_topk_mask_f32": (c_int, [P, P, L, I, P, P, P]),
     "cnrma_rma_depth_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P]),
     "cnrma_rma_depth_emit_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P, F, F, F,
@@ -40,9 +40,9 @@ SIGNATURES = {
     "cnrma_mask_to_index": (c_int, [P, P, P, L, P, P]),
     "cnrma_select_rows_f32": (c_int, [P, L, I, P, F, F, F, P, P, P]),
     "cnrma_voxelize_workspace_bytes": (c_size_t, [L]),
-    "cnrma_voxelize_f32": (c_int, [P, P, L, I, F, I, I, P, P, L, P, P, P, P, P, P]),
+    "cnrma_voxelize_f32": (c_int, [P, P, L, P, I, F, I, I, P, P, L, P, P, P, L, P, P, P]),
     "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, P]),
-    "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, P, P, P]),
+    "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, L, P, P, P]),
     "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
     "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, P]),
     "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, P]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     "cnrma_instnorm_workspace_bytes": (c_size_t, [I]),
     "cnrma_sparse_instnorm_f32": (c_int, [P, L, P, I, P, P, F, I, P, P, P]),
     "cnrma_union_workspace_bytes": (c_size_t, [L]),
-    "cnrma_sparse_union_add_f32": (c_int, [P, P, L, P, P, P, L, P, I, P, P, L, P, P, P, P, P]),
+    "cnrma_sparse_union_add_f32": (c_int, [P, P, L, P, P, P, L, P, I, P, P, L, P, P, L, P, P, P]),
     "cnrma_sparse_interp_f32": (c_int, [P, L, P, P, P, P, L, I, P, P]),
     "cnrma_sparse_prune_f32": (c_int, [P, P, L, P, I, P, P, P, P]),
     "cnrma_rowmax_f32": (c_int, [P, L, P, I, P, P]),
@@ -81,6 +81,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2
 
 
 class CnrmaError(RuntimeError):
@@ -100,7 +101,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.cnrma_abi_version() != 1:
+    if lib.cnrma_abi_version() != ABI_VERSION:
         raise CnrmaError("ABI version mismatch")
     _lib = lib
     return lib

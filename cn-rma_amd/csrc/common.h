@@ -14,6 +14,29 @@
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Byte fill as a plain kernel (replaces hipMemsetAsync: inside a captured launch sequence its memset nodes did not
+// reliably re-execute on replay with this runtime -- stale hash tables on the second replay --, and a kernel node costs the
+// same).  p 4-byte aligned, n a multiple of 4 bytes.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void cnrma_fill_kernel(uint32_t* __restrict__ p, uint32_t word, size_t n_words) {
+  const size_t n4 = (((uintptr_t)p & 15) == 0) ? n_words / 4 : 0;
+  const uint4 w4 = make_uint4(word, word, word, word);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<uint4*>(p)[i] = w4;
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = word;
+}
+static inline hipError_t cnrma_fill_bytes(void* p, int byte, size_t n_bytes, hipStream_t st) {
+  if (n_bytes == 0) return hipSuccess;
+  if ((n_bytes & 3) != 0 || ((uintptr_t)p & 3) != 0) return hipMemsetAsync(p, byte, n_bytes, st);
+  const uint32_t b = (uint32_t)(byte & 0xFF), word = b | (b << 8) | (b << 16) | (b << 24);
+  size_t blocks = (n_bytes / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(cnrma_fill_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), word,
+                     n_bytes / 4);
+  return hipGetLastError();
+}
+
 // live row count of a device-counted tensor: min(capacity, *n_dev) (n_dev may be NULL)
 __device__ __forceinline__ int64_t live_rows(int64_t cap, const int32_t* n_dev) {
   if (n_dev == nullptr) return cap;

@@ -247,7 +247,7 @@ extern "C" int cnrma_backproject_backward_f32(const float* grad_volume, const in
     return CNRMA_EINVAL;
   DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(grad_feat_nhwc, 0, (size_t)V * H * W * C * sizeof(float), st);
+  hipError_t e = cnrma_fill_bytes(grad_feat_nhwc, 0, (size_t)V * H * W * C * sizeof(float), st);
   if (e != hipSuccess) return -(int)e;
   const int64_t G = (int64_t)X * Y * Z;
   if (C >= 32) {

@@ -123,7 +123,7 @@ extern "C" int cnrma_nms_mask_f32(const float* boxes_sorted, int n, float iou_th
   if (n <= 0) return n == 0 ? 0 : CNRMA_EINVAL;
   const int words = (n + 63) / 64;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(mask, 0, (size_t)n * words * sizeof(uint64_t), st);
+  hipError_t e = cnrma_fill_bytes(mask, 0, (size_t)n * words * sizeof(uint64_t), st);
   if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words), dim3(64), 0, st, boxes_sorted, n, iou_thr, rotated,
                      reinterpret_cast<unsigned long long*>(mask), words);

@@ -201,15 +201,16 @@ __global__ __launch_bounds__(256) void neus_count_kernel(MarchParams p, const fl
 //      channel vector (one full 128-B line read and written per row at C = 32).
 __global__ __launch_bounds__(256) void neus_scatter_records_kernel(int64_t R, const int32_t* __restrict__ row_offset,
                                                                    const int2* __restrict__ kept, int cap,
-                                                                   const int32_t* __restrict__ sel,
-                                                                   int4* __restrict__ rec) {
+                                                                   const int32_t* __restrict__ sel, int64_t sel_cap,
+                                                                   int64_t rec_cap, int4* __restrict__ rec) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int64_t m0 = row_offset[r];
   const int c = (int)(row_offset[r + 1] - m0);     // 0 for rays of dropped views as well
   for (int i = 0; i < c; ++i) {
+    if (sel && m0 + i >= sel_cap) break;            // rows past the capacity of the selection (flagged by the caller)
     const int64_t j = sel ? (int64_t)sel[m0 + i] : m0 + i;
-    if (j < 0) continue;
+    if (j < 0 || j >= rec_cap) continue;
     const int2 k = kept[r * cap + i];
     rec[j] = make_int4((int)r, k.y, k.x, 0);
   }
@@ -218,11 +219,12 @@ __global__ __launch_bounds__(256) void neus_scatter_records_kernel(int64_t R, co
 template <int LPR>
 __global__ __launch_bounds__(256) void neus_emit_rows_kernel(MarchParams p, int C, const float* __restrict__ proj_inv,
                                                             const float* __restrict__ feat, int64_t n_rows,
+                                                            const int32_t* __restrict__ n_rows_dev,
                                                             const int4* __restrict__ rec, EmitDst dst) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t j = t / LPR;
   const int sub = (int)(t % LPR);
-  if (j >= n_rows) return;
+  if (j >= live_rows(n_rows, n_rows_dev)) return;
   const int4 rc = rec[j];
   const int64_t r = rc.x;
   const int n = rc.y;
@@ -443,7 +445,7 @@ extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf
   if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr) return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
   int64_t R = (int64_t)V * H * W;
-  hipError_t e = hipMemsetAsync(overflow, 0, sizeof(int32_t), as_stream(stream));
+  hipError_t e = cnrma_fill_bytes(overflow, 0, sizeof(int32_t), as_stream(stream));
   if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
                      proj_inv, tsdf, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
@@ -453,7 +455,8 @@ extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf
 
 extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
                                             int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
-                                            const void* kept, int cap, const int32_t* sel_index, void* records,
+                                            const int32_t* n_out_dev, const void* kept, int cap,
+                                            const int32_t* sel_index, int64_t sel_cap, void* records,
                                             const float* w_div, float addx, float addy, float addz, float* out_xyz,
                                             int xyz_stride, float* out_w, int w_stride, float* out_feat,
                                             int feat_stride, int32_t* out_sample, void* stream) {
@@ -465,13 +468,16 @@ extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* 
   hipStream_t st = as_stream(stream);
   int4* rec = reinterpret_cast<int4*>(records);
   hipLaunchKernelGGL(neus_scatter_records_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, st, R, row_offset,
-                     reinterpret_cast<const int2*>(kept), cap, sel_index, rec);
-  if (C % 32 == 0) {
+                     reinterpret_cast<const int2*>(kept), cap, sel_index, sel_cap, n_out, rec);
+  if (C % 256 == 0) {      // one wave copies a row's 1-KiB channel vector per instruction
+    hipLaunchKernelGGL((neus_emit_rows_kernel<64>), dim3((unsigned)ceil_div(n_out * 64, 256)), dim3(256), 0, st, p, C,
+                       proj_inv, feat_nhwc, n_out, n_out_dev, rec, d);
+  } else if (C % 32 == 0) {
     hipLaunchKernelGGL((neus_emit_rows_kernel<8>), dim3((unsigned)ceil_div(n_out * 8, 256)), dim3(256), 0, st, p, C,
-                       proj_inv, feat_nhwc, n_out, rec, d);
+                       proj_inv, feat_nhwc, n_out, n_out_dev, rec, d);
   } else {
     hipLaunchKernelGGL((neus_emit_rows_kernel<2>), dim3((unsigned)ceil_div(n_out * 2, 256)), dim3(256), 0, st, p, C,
-                       proj_inv, feat_nhwc, n_out, rec, d);
+                       proj_inv, feat_nhwc, n_out, n_out_dev, rec, d);
   }
   CNRMA_LAUNCH_CHECK();
   return 0;

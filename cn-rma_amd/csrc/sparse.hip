@@ -126,11 +126,12 @@ __global__ __launch_bounds__(256) void uniq_write_kernel(const void* __restrict_
                                                          int batch_id, const int32_t* __restrict__ idx,
                                                          const int32_t* __restrict__ slot, int32_t* __restrict__ vals,
                                                          int32_t* __restrict__ out_coords,
-                                                         int32_t* __restrict__ out_src) {
+                                                         int32_t* __restrict__ out_src, int64_t out_cap) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= live_rows(n_cap, n_dev)) return;
   const int32_t j = idx[i];
   if (j < 0) return;
+  if (j >= out_cap) { vals[slot[i]] = -1; return; }   // beyond the planned capacity: dropped, and unmapped (see n_out)
   int b, x, y, z;
   quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
   reinterpret_cast<int4*>(out_coords)[j] = make_int4(b, x, y, z);
@@ -164,10 +165,11 @@ __global__ __launch_bounds__(256) void uniq_write_sorted_kernel(const void* __re
                                                                 const int32_t* __restrict__ slot,
                                                                 int32_t* __restrict__ vals,
                                                                 int32_t* __restrict__ out_coords,
-                                                                int32_t* __restrict__ out_src) {
+                                                                int32_t* __restrict__ out_src, int64_t out_cap) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= live_rows(n_cap, n_out)) return;
   const int64_t i = order[j];
+  if (j >= out_cap) { vals[slot[i]] = -1; return; }
   int b, x, y, z;
   quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
   reinterpret_cast<int4*>(out_coords)[j] = make_int4(b, x, y, z);
@@ -199,12 +201,13 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 template <int MODE>
 int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, int new_stride, int batch_id,
                uint64_t* keys, int32_t* vals, int64_t cap, int32_t* out_coords, int32_t* out_src, int32_t* n_out,
-               void* workspace, hipStream_t st, bool morton = false) {
+               void* workspace, hipStream_t st, bool morton = false, int64_t out_cap = 0) {
+  if (out_cap <= 0 || out_cap > n_cap) out_cap = n_cap;
   if (n_cap <= 0 || cap < 2 || (cap & (cap - 1)) != 0 || cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
   UniqueWs w = carve_unique_ws(workspace, n_cap);
-  hipError_t e = hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(uint64_t), st);
+  hipError_t e = cnrma_fill_bytes(keys, 0xFF, (size_t)cap * sizeof(uint64_t), st);
   if (e != hipSuccess) return -(int)e;
-  e = hipMemsetAsync(vals, 0x7F, (size_t)cap * sizeof(int32_t), st);
+  e = cnrma_fill_bytes(vals, 0x7F, (size_t)cap * sizeof(int32_t), st);
   if (e != hipSuccess) return -(int)e;
   const unsigned nb = (unsigned)ceil_div(n_cap, 256);
   hipLaunchKernelGGL((uniq_insert_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
@@ -214,7 +217,7 @@ int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, i
   if (rc) return rc;
   if (!morton) {
     hipLaunchKernelGGL((uniq_write_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
-                       batch_id, w.idx, w.slot, vals, out_coords, out_src);
+                       batch_id, w.idx, w.slot, vals, out_coords, out_src, out_cap);
   } else {
     // spatial (Morton) row order: a tile of consecutive rows is a compact block of voxels, so the gathers of the
     // convolutions hit L2 and whole kernel offsets can be skipped per tile on thin surfaces
@@ -227,7 +230,7 @@ int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, i
                                                        0, end_bit, st);
     if (e2 != hipSuccess) return -(int)e2;
     hipLaunchKernelGGL((uniq_write_sorted_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, vs, new_stride,
-                       batch_id, w.val_b, n_out, w.slot, vals, out_coords, out_src);
+                       batch_id, w.val_b, n_out, w.slot, vals, out_coords, out_src, out_cap);
   }
   CNRMA_LAUNCH_CHECK();
   return 0;
@@ -282,8 +285,10 @@ __global__ __launch_bounds__(256) void kernel_map_symmetric_kernel(const int32_t
   int64_t s = hash_find(keys, cap, coord_key(c.x, c.y + offsets[k * 3], c.z + offsets[k * 3 + 1], c.w + offsets[k * 3 + 2]));
   if (s >= 0) {
     const int32_t i = vals[s];
-    nbr[o * K + k] = i;
-    nbr[(int64_t)i * K + (K - 1 - k)] = (int32_t)o;
+    if (i >= 0) {                      // < 0: a row dropped by its producer (over the planned capacity)
+      nbr[o * K + k] = i;
+      nbr[(int64_t)i * K + (K - 1 - k)] = (int32_t)o;
+    }
   }
 }
 
@@ -305,13 +310,13 @@ __global__ __launch_bounds__(256) void kernel_map_strided_kernel(const int32_t* 
   const int ox = (c.y - px) / s, oy = (c.z - py) / s, oz = (c.w - pz) / s;   // 0 or 1: position inside the parent cell
   if (ksize == 2) {
     const int64_t slot = hash_find(out_keys, cap, coord_key(c.x, px, py, pz));
-    if (slot >= 0) nbr[(int64_t)out_vals[slot] * 8 + (ox + 2 * oy + 4 * oz)] = (int32_t)i;
+    if (slot >= 0 && out_vals[slot] >= 0) nbr[(int64_t)out_vals[slot] * 8 + (ox + 2 * oy + 4 * oz)] = (int32_t)i;
     return;
   }
   if (ksize == 1) {
     if (ox | oy | oz) return;
     const int64_t slot = hash_find(out_keys, cap, coord_key(c.x, px, py, pz));
-    if (slot >= 0) nbr[out_vals[slot]] = (int32_t)i;
+    if (slot >= 0 && out_vals[slot] >= 0) nbr[out_vals[slot]] = (int32_t)i;
     return;
   }
   // ksize == 3: per axis the offset (in units of s) from the output to this input is 0 when the input sits on the
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(256) void kernel_map_strided_kernel(const int32_t* 
         const int offx = ox ? (a == 0 ? 1 : -1) : 0, offy = oy ? (b == 0 ? 1 : -1) : 0, offz = oz ? (d == 0 ? 1 : -1) : 0;
         const int qx = c.y - offx * s, qy = c.z - offy * s, qz = c.w - offz * s;
         const int64_t slot = hash_find(out_keys, cap, coord_key(c.x, qx, qy, qz));
-        if (slot >= 0) nbr[(int64_t)out_vals[slot] * 27 + ((offx + 1) + 3 * (offy + 1) + 9 * (offz + 1))] = (int32_t)i;
+        if (slot >= 0 && out_vals[slot] >= 0)
+          nbr[(int64_t)out_vals[slot] * 27 + ((offx + 1) + 3 * (offy + 1) + 9 * (offz + 1))] = (int32_t)i;
       }
 }
 
@@ -1434,7 +1440,8 @@ __global__ __launch_bounds__(256) void union_merge_b_kernel(const int32_t* __res
                                                             uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
                                                             int64_t cap, int32_t* __restrict__ out_coords,
                                                             float* __restrict__ out_feats,
-                                                            const int32_t* __restrict__ n_new, int32_t* __restrict__ n_out) {
+                                                            const int32_t* __restrict__ n_new, int32_t* __restrict__ n_out,
+                                                            int64_t out_cap) {
   const int64_t nb = live_rows(nb_cap, nb_dev);
   const int64_t na = live_rows(na_cap, na_dev);
   if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = (int32_t)(na + n_new[0]);
@@ -1446,6 +1453,7 @@ __global__ __launch_bounds__(256) void union_merge_b_kernel(const int32_t* __res
       out_feats[(int64_t)m * C + c] += b_feats[t];          // unique coords in B: one writer per element
     } else {
       const int64_t row = na + idx[i];
+      if (row >= out_cap) continue;                           // over the planned capacity: dropped (n_out tells)
       out_feats[row * C + c] = b_feats[t];
       if (c == 0) {
         int4 cc = reinterpret_cast<const int4*>(b_coords)[i];
@@ -1475,7 +1483,7 @@ __global__ __launch_bounds__(256) void interp_kernel(const int32_t* __restrict__
                     (1.0f - fabsf((float)(q.w - cz)) / fs);
     if (w == 0.0f) continue;
     int64_t slot = hash_find(keys, cap, coord_key(q.x, cx, cy, cz));
-    if (slot >= 0) acc += w * score[vals[slot]];
+    if (slot >= 0 && vals[slot] >= 0) acc += w * score[vals[slot]];
   }
   out[i] = acc;
 }
@@ -1577,7 +1585,7 @@ extern "C" int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_
                                                  int64_t n_in, int32_t* nbr_t, void* stream) {
   if (no_cap <= 0 || K <= 0 || n_in <= 0 || nbr == nullptr || nbr_t == nullptr) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * K * sizeof(int32_t), st);
+  hipError_t e = cnrma_fill_bytes(nbr_t, 0xFF, (size_t)n_in * K * sizeof(int32_t), st);
   if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL(kernel_map_transpose_kernel, dim3((unsigned)ceil_div(no_cap * K, 256)), dim3(256), 0, st, nbr, no_cap,
                      no_dev, K, n_in, nbr_t);
@@ -1607,18 +1615,19 @@ extern "C" size_t cnrma_voxelize_workspace_bytes(int64_t M) {
   return (size_t)(n4 * 33) + sort_temp_bytes(M) + cnrma_scan_workspace_bytes(M) + 1024;
 }
 
-extern "C" int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, int C, float voxel_size,
-                                  int batch_id, int row_order, uint64_t* hash_keys, int32_t* hash_vals,
+extern "C" int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, const int32_t* m_dev, int C,
+                                  float voxel_size, int batch_id, int row_order, uint64_t* hash_keys, int32_t* hash_vals,
                                   int64_t hash_cap, int32_t* out_coords, float* out_feats, int32_t* out_src,
-                                  int32_t* n_out, void* workspace, void* stream) {
+                                  int64_t out_cap, int32_t* n_out, void* workspace, void* stream) {
+  if (out_cap <= 0 || out_cap > M) out_cap = M;
   if (C <= 0 || !(voxel_size > 0.0f) || out_src == nullptr || row_order < 0 || row_order > 1) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  int rc = run_unique<0>(coords, M, nullptr, voxel_size, 1, batch_id, hash_keys, hash_vals, hash_cap, out_coords,
-                         out_src, n_out, workspace, st, row_order == 1);
+  int rc = run_unique<0>(coords, M, m_dev, voxel_size, 1, batch_id, hash_keys, hash_vals, hash_cap, out_coords,
+                         out_src, n_out, workspace, st, row_order == 1, out_cap);
   if (rc) return rc;
   if (feats && out_feats) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(M * (int64_t)(C / 4 + 1))), dim3(256), 0, st, feats, out_src, M,
-                       n_out, C, out_feats);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(out_cap * (int64_t)(C / 4 + 1))), dim3(256), 0, st, feats, out_src,
+                       out_cap, n_out, C, out_feats);
     CNRMA_LAUNCH_CHECK();
   }
   return 0;
@@ -1628,7 +1637,7 @@ extern "C" int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, cons
                                       int32_t* hash_vals, int64_t hash_cap, void* stream) {
   if (n_cap <= 0 || hash_cap < 2 || (hash_cap & (hash_cap - 1)) != 0) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(hash_keys, 0xFF, (size_t)hash_cap * sizeof(uint64_t), st);
+  hipError_t e = cnrma_fill_bytes(hash_keys, 0xFF, (size_t)hash_cap * sizeof(uint64_t), st);
   if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL(build_map_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, st, coords, n_cap, n_dev,
                      hash_keys, hash_vals, hash_cap);
@@ -1638,10 +1647,11 @@ extern "C" int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, cons
 
 extern "C" int cnrma_sparse_stride_coords(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev,
                                           int new_stride, uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap,
-                                          int32_t* out_coords, int32_t* n_out, void* workspace, void* stream) {
+                                          int32_t* out_coords, int64_t out_cap, int32_t* n_out, void* workspace,
+                                          void* stream) {
   if (new_stride <= 0) return CNRMA_EINVAL;
   return run_unique<1>(in_coords, n_cap, n_dev, 1.0f, new_stride, 0, hash_keys, hash_vals, hash_cap, out_coords,
-                       nullptr, n_out, workspace, as_stream(stream));
+                       nullptr, n_out, workspace, as_stream(stream), false, out_cap);
 }
 
 extern "C" int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int32_t* no_dev,
@@ -1659,7 +1669,7 @@ extern "C" int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t 
                                                  const int32_t* offsets, int K, int32_t* nbr, void* stream) {
   if (n_cap <= 0 || K <= 0 || (K & 1) == 0) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(nbr, 0xFF, (size_t)n_cap * K * sizeof(int32_t), st);
+  hipError_t e = cnrma_fill_bytes(nbr, 0xFF, (size_t)n_cap * K * sizeof(int32_t), st);
   if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL(kernel_map_symmetric_kernel, dim3((unsigned)ceil_div(n_cap * (K / 2 + 1), 256)), dim3(256), 0, st,
                      coords, n_cap, n_dev, hash_keys, hash_vals, hash_cap, offsets, K, nbr);
@@ -1674,7 +1684,7 @@ extern "C" int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t
   if (n_cap <= 0 || no_cap <= 0 || in_stride <= 0 || kernel_size < 1 || kernel_size > 3) return CNRMA_EINVAL;
   const int K = kernel_size * kernel_size * kernel_size;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(nbr, 0xFF, (size_t)no_cap * K * sizeof(int32_t), st);
+  hipError_t e = cnrma_fill_bytes(nbr, 0xFF, (size_t)no_cap * K * sizeof(int32_t), st);
   if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL(kernel_map_strided_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, st, in_coords,
                      n_cap, n_dev, in_stride, kernel_size, out_hash_keys, out_hash_vals, hash_cap, nbr);
@@ -1723,7 +1733,7 @@ extern "C" int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n
                                 void* stream) {
   if (n_cap <= 0 || C <= 0 || out_amax == nullptr) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(out_amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
+  hipError_t e = cnrma_fill_bytes(out_amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
   if (e != hipSuccess) return -(int)e;
   int64_t blocks = ceil_div(n_cap * C / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
@@ -1750,7 +1760,7 @@ extern "C" int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K,
   const int64_t total = (int64_t)K * Cin * conv_cout_padded(Cout);
   uint16_t* wt = reinterpret_cast<uint16_t*>(weight_split);
   float* amax = reinterpret_cast<float*>(wt + 2 * total) + 16;       // slot scratch behind the 64-byte trailer
-  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
+  hipError_t e = cnrma_fill_bytes(amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
   if (e != hipSuccess) return -(int)e;
   int64_t blocks = ceil_div(total_src / 4 + 1, 256);
   if (blocks > 2048) blocks = 2048;
@@ -1852,8 +1862,9 @@ extern "C" int cnrma_sparse_union_add_f32(const int32_t* a_coords, const float* 
                                           const int32_t* na_dev, const int32_t* b_coords, const float* b_feats,
                                           int64_t nb_cap, const int32_t* nb_dev, int C, uint64_t* a_hash_keys,
                                           int32_t* a_hash_vals, int64_t hash_cap, int32_t* out_coords,
-                                          float* out_feats, int32_t* n_out, void* workspace, void* stream) {
-  if (na_cap <= 0 || nb_cap <= 0 || C <= 0) return CNRMA_EINVAL;
+                                          float* out_feats, int64_t out_cap, int32_t* n_out, void* workspace,
+                                          void* stream) {
+  if (na_cap <= 0 || nb_cap <= 0 || C <= 0 || out_cap < na_cap) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
   // workspace: match[nb] int32, idx[nb] int32, flag[nb] u8, n_new int32, scan ws
   char* p = reinterpret_cast<char*>(workspace);
@@ -1870,7 +1881,7 @@ extern "C" int cnrma_sparse_union_add_f32(const int32_t* a_coords, const float* 
                      na_cap, na_dev, C, out_coords, out_feats);
   hipLaunchKernelGGL(union_merge_b_kernel, dim3(grid_for(nb_cap * C, 256, 4096)), dim3(256), 0, st, b_coords, b_feats,
                      nb_cap, nb_dev, C, match, idx, na_cap, na_dev, a_hash_keys, a_hash_vals, hash_cap, out_coords,
-                     out_feats, n_new, n_out);
+                     out_feats, n_new, n_out, out_cap);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

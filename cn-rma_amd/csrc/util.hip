@@ -203,8 +203,21 @@ __device__ __forceinline__ void resolve_digit(const int32_t* __restrict__ hist, 
 }
 
 // block-private LDS histogram of one digit, flushed with (contiguous) global atomics
-__global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
-                                                          uint32_t seed, int pass, int n_keep, SampleWs* __restrict__ ws) {
+// live row count of a select: min(m_dev[0], capacity); the seed may carry a device-side increment (graph replays draw a
+// fresh subset without a new kernel argument)
+__device__ __forceinline__ int64_t select_rows(const int32_t* __restrict__ m_dev, int64_t m_cap) {
+  const int64_t m = m_dev[0];
+  return m < m_cap ? m : m_cap;
+}
+__device__ __forceinline__ uint32_t select_seed(uint32_t seed, const uint32_t* __restrict__ seed_dev) {
+  return seed_dev ? seed + 0x9E3779B9u * seed_dev[0] : seed;
+}
+
+__global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                          const float* __restrict__ scores, uint32_t seed,
+                                                          const uint32_t* __restrict__ seed_dev, int pass, int n_keep,
+                                                          SampleWs* __restrict__ ws) {
+  seed = select_seed(seed, seed_dev);
   __shared__ int h[2048];
   __shared__ int rs[256 / 64 + 1 + 2];
   int32_t prefix[3] = {0, 0, 0};
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restr
   }
   for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
   __syncthreads();
-  const int64_t M = m_dev[0];
+  const int64_t M = select_rows(m_dev, m_cap);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t k = select_key(scores, seed, (uint32_t)i);
     if (key_matches(k, pass, prefix)) atomicAdd(&h[key_digit(k, pass)], 1);
@@ -226,8 +239,11 @@ __global__ __launch_bounds__(256) void sample_hist_kernel(const int32_t* __restr
     if (h[i]) atomicAdd(&ws->hist[pass][i], h[i]);
 }
 
-__global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
-                                                          uint32_t seed, int n_keep, SampleWs* __restrict__ ws) {
+__global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                          const float* __restrict__ scores, uint32_t seed,
+                                                          const uint32_t* __restrict__ seed_dev, int n_keep,
+                                                          SampleWs* __restrict__ ws) {
+  seed = select_seed(seed, seed_dev);
   __shared__ int rs[256 / 64 + 1 + 2];
   int32_t prefix[3];
   int need = n_keep;
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restr
     ws->prefix[0] = prefix[0]; ws->prefix[1] = prefix[1]; ws->prefix[2] = prefix[2];
     ws->need[0] = n_keep; ws->need[3] = need;
   }
-  const int64_t M = m_dev[0];
+  const int64_t M = select_rows(m_dev, m_cap);
   const uint32_t key = ((uint32_t)prefix[0] << 21) | ((uint32_t)prefix[1] << 10) | (uint32_t)prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     if (select_key(scores, seed, (uint32_t)i) == key) {
@@ -251,9 +267,12 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restr
 }
 
 // second-level select, only active when the tie list overflowed: digit histogram of the row index over the tie rows
-__global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
-                                                              uint32_t seed, int pass, SampleWs* __restrict__ ws) {
+__global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                              const float* __restrict__ scores, uint32_t seed,
+                                                              const uint32_t* __restrict__ seed_dev, int pass,
+                                                              SampleWs* __restrict__ ws) {
   if (ws->tie_count <= 256) return;
+  seed = select_seed(seed, seed_dev);
   __shared__ int h[2048];
   __shared__ int rs[256 / 64 + 1 + 2];
   int32_t prefix2[3] = {0, 0, 0};
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __r
   }
   for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
   __syncthreads();
-  const int64_t M = m_dev[0];
+  const int64_t M = select_rows(m_dev, m_cap);
   const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     if (select_key(scores, seed, (uint32_t)i) != key) continue;
@@ -277,10 +296,13 @@ __global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __r
     if (h[i]) atomicAdd(&ws->hist2[pass][i], h[i]);
 }
 
-__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, const float* __restrict__ scores,
-                                                          uint32_t seed, const SampleWs* __restrict__ ws, int n_keep,
+__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                          const float* __restrict__ scores, uint32_t seed,
+                                                          const uint32_t* __restrict__ seed_dev,
+                                                          const SampleWs* __restrict__ ws, int n_keep,
                                                           uint8_t* __restrict__ mask) {
-  const int64_t M = m_dev[0];
+  seed = select_seed(seed, seed_dev);
+  const int64_t M = select_rows(m_dev, m_cap);
   __shared__ int32_t tie_bound;     // rows with the threshold key are kept when their index <= tie_bound
   __shared__ int rs[256 / 64 + 1 + 2];
   int32_t prefix2[3] = {0, 0, 0};
@@ -314,6 +336,9 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
     const uint32_t k = select_key(scores, seed, (uint32_t)i);
     mask[i] = (all || k < key || (k == key && (int32_t)i <= tie_bound)) ? 1 : 0;
   }
+  // rows between the live count and the capacity are not part of the tensor: never kept
+  for (int64_t i = M + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m_cap; i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] = 0;
 }
 
 }  // namespace
@@ -321,35 +346,40 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
 extern "C" size_t cnrma_sample_workspace_bytes(void) { return sizeof(SampleWs); }
 
 static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, int n_keep, uint32_t seed,
-                      uint8_t* mask, void* workspace, hipStream_t st) {
+                      const uint32_t* seed_dev, uint8_t* mask, void* workspace, hipStream_t st) {
   if (m_cap <= 0 || n_keep <= 0 || m_cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
   SampleWs* ws = reinterpret_cast<SampleWs*>(workspace);
-  hipError_t e = hipMemsetAsync(ws, 0, sizeof(SampleWs), st);
+  hipError_t e = cnrma_fill_bytes(ws, 0, sizeof(SampleWs), st);
   if (e != hipSuccess) return -(int)e;
   int blocks = (int)(m_cap / 2048 + 1);
   if (blocks > 1024) blocks = 1024;
   for (int pass = 0; pass < 3; ++pass)
-    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, n_keep, ws);
-  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, n_keep, ws);
+    hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, pass,
+                       n_keep, ws);
+  hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, n_keep, ws);
   for (int pass = 0; pass < 3; ++pass)        // no-ops unless more than 256 rows carry the threshold key
-    hipLaunchKernelGGL(sample_tie_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, pass, ws);
-  hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, scores, seed, ws, n_keep, mask);
+    hipLaunchKernelGGL(sample_tie_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, pass,
+                       ws);
+  hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, ws, n_keep,
+                     mask);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
 
-// mask[0..M) (M = m_dev[0] <= m_cap, read on the device): exactly min(M, n_keep) ones, uniformly random subset
-extern "C" int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask,
-                                 void* workspace, void* stream) {
-  return run_select(m_dev, nullptr, m_cap, n_keep, seed, mask, workspace, as_stream(stream));
+// mask[0..m_cap): exactly min(M, n_keep) ones among the first M = min(m_dev[0], m_cap) rows (uniformly random subset),
+// zeros behind them
+extern "C" int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, const uint32_t* seed_dev,
+                                 uint8_t* mask, void* workspace, void* stream) {
+  if (m_dev == nullptr) return CNRMA_EINVAL;
+  return run_select(m_dev, nullptr, m_cap, n_keep, seed, seed_dev, mask, workspace, as_stream(stream));
 }
 
 // mask[0..n): ones at the min(n, k) rows with the LARGEST scores (ties by smaller index) -- the keep-set of
 // torch.topk(scores, k) without the sort; n = n_dev[0] read on the device
 extern "C" int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, uint8_t* mask,
                                    void* workspace, void* stream) {
-  if (scores == nullptr) return CNRMA_EINVAL;
-  return run_select(n_dev, scores, n_cap, k, 0u, mask, workspace, as_stream(stream));
+  if (scores == nullptr || n_dev == nullptr) return CNRMA_EINVAL;
+  return run_select(n_dev, scores, n_cap, k, 0u, nullptr, mask, workspace, as_stream(stream));
 }
 
 extern "C" size_t cnrma_scan_workspace_bytes(int64_t n) {

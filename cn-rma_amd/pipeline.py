@@ -11,13 +11,14 @@ backbone and the Atlas reconstruction network replaced by their outputs (feature
 import torch
 
 from . import _lib, rma
+from . import plan as P
 from . import sparse as S
 
 
 class SceneConfig:
     def __init__(self, dims, voxel_size=0.04, origin=(0.0, 0.0, 0.0), stride=4, n_steps=300, thr=0.05,
                  max_points=500000, voxel_size_fcaf3d=0.01, ray_marching_type="neus", depth_points=None,
-                 sampler="device"):
+                 sampler="device", sample_seed=None):
         self.dims = tuple(dims)
         self.voxel_size = voxel_size
         self.origin = tuple(origin)
@@ -29,6 +30,7 @@ class SceneConfig:
         self.ray_marching_type = ray_marching_type
         self.depth_points = depth_points
         self.sampler = sampler
+        self.sample_seed = sample_seed        # device sampler: fixed seed (None = a fresh subset per call)
 
 
 class StageTimer:
@@ -108,7 +110,7 @@ def forward_scene(cfg, backbone, head, features_nchw, projections, tsdf, offset=
     proj_inv = proj_inv.to(feats.device, non_blocking=True)
     coords, pfeats, info = rma.aggregate_points(
         feats, proj_inv, tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr, cfg.ray_marching_type,
-        cfg.depth_points, offset=offset, max_points=cfg.max_points, sampler=cfg.sampler, mask=mask)
+        cfg.depth_points, offset=offset, max_points=cfg.max_points, sampler=cfg.sampler, mask=mask, seed=cfg.sample_seed)
     tm.mark("rma")
     x, _ = S.voxelize(coords, pfeats, cfg.voxel_size_fcaf3d)
     tm.mark("voxelize")
@@ -122,6 +124,130 @@ def forward_scene(cfg, backbone, head, features_nchw, projections, tsdf, offset=
     out.update(bboxes=bboxes, scores=scores, M=info["M"], M_selected=info["M_selected"], M_unique=len(x),
                level_rows=[len(l) for l in levels], head_rows=[len(c[0]) for c in cen], stage_ms=tm.result())
     return out
+
+
+class StaticScene:
+    """One scene forward as a replayable HIP graph: the whole launch sequence of forward_scene() (dense unprojection,
+    march, selection, voxelisation, MinkResNet34, neck/head, decode -- ~350 launches) captured once and replayed per
+    scene with a single host call; no device->host read, no allocation, no Python in between.
+
+    build() runs the scene eagerly once under a recording plan.Plan (every data-dependent row count is read back, as
+    the reference does at nonzero() / in ME's coordinate manager), derives capacities (recorded size x `margin`) and
+    re-runs the sequence in static mode -- once plainly (this creates the trace's device constants and is compared with
+    the eager result by the tests), once under stream capture.  run() then costs: one layout kernel (the 2D backbone's
+    NCHW maps -> the static channels-last buffer), three small input copies, one graph launch.  The outputs are static
+    buffers, valid until the next run() of this object; `status` (device int32) counts violated capacity / branch
+    assumptions -- non-zero means the scene outgrew the plan and must be re-run eagerly (forward_scene)."""
+
+    def __init__(self, cfg, backbone, head, device, margin=1.2, dense=True, stream=None):
+        self.cfg, self.backbone, self.head = cfg, backbone, head
+        self.device = torch.device(device)
+        self.margin, self.dense = margin, dense
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self.graph = None
+        self.plan = None
+        self.out = None
+        self._copied = None
+
+    # ---- inputs --------------------------------------------------------------------------------------------------
+    def _alloc_inputs(self, features_nchw, tsdf):
+        V, C, H, W = features_nchw.shape
+        dev = self.device
+        self.nhwc = torch.empty((V, H, W, C), dtype=torch.float32, device=dev)
+        self.proj_scaled = torch.empty((V, 3, 4), dtype=torch.float32, device=dev)
+        self.proj_inv = torch.empty((V, 4, 4), dtype=torch.float32, device=dev)
+        self.tsdf = torch.empty(tuple(self.cfg.dims), dtype=torch.float32, device=dev)
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._pin_proj = torch.empty((V, 3, 4), dtype=torch.float32, pin_memory=True)
+        self._pin_inv = torch.empty((V, 4, 4), dtype=torch.float32, pin_memory=True)
+
+    def _load(self, features_nchw, projections, tsdf):
+        """stage one scene's inputs into the static buffers (on self.stream, which must be current)"""
+        if self._copied is not None:
+            self._copied.synchronize()           # the previous scene's copies out of the pinned buffers have executed
+        rma.to_nhwc(features_nchw, out=self.nhwc)
+        p = projections.detach().to("cpu", torch.float32)
+        self._pin_proj.copy_(rma.scale_projection(p, self.cfg.stride))
+        self._pin_inv.copy_(rma.projection_inverse(p, self.cfg.stride))      # host LAPACK, as ray_marching.py:96-102
+        self.proj_scaled.copy_(self._pin_proj, non_blocking=True)
+        self.proj_inv.copy_(self._pin_inv, non_blocking=True)
+        self.tsdf.copy_(tsdf.reshape(self.tsdf.shape), non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record()
+
+    # ---- the launch sequence ---------------------------------------------------------------------------------------
+    def _trace(self):
+        cfg, plan = self.cfg, self.plan
+        plan.begin_static()
+        out = {}
+        with P.using(plan), torch.no_grad():
+            if self.dense:
+                out["volume"], out["count"] = rma.backproject_accum(self.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin,
+                                                                    cfg.stride, proj_scaled=self.proj_scaled)
+            coords, feats, n_sel, info = rma.aggregate_points_static(
+                self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
+                max_points=cfg.max_points, seed=0x5EED if cfg.sample_seed is None else cfg.sample_seed,
+                seed_dev=self.seed_dev)
+            x, _ = S.voxelize(coords, feats, cfg.voxel_size_fcaf3d, n_dev=n_sel)
+            levels = self.backbone(x)
+            cen, box, cls, pts, css = map(list, self.head(levels, fused=True))
+            bboxes, scores, valid, sizes = self.head.get_bboxes_static(cen, box, cls, pts, css)
+            status = plan.status(self.device)
+            self.seed_dev.add_(1)                # the next replay draws a fresh point subset
+            # every live count of the pass in ONE small tensor (read together with the detections, if at all)
+            counts = torch.cat([info["M"].view(1), n_sel.view(1), x.cs.n_dev.view(1)] + [l.cs.n_dev.view(1) for l in levels] +
+                               [c[0].n_dev.view(1) for c in css]).to(torch.int32)
+        plan.end_static()
+        out.update(bboxes=bboxes, scores=scores, valid=valid, sizes=sizes, status=status, counts=counts,
+                   n_levels=len(levels))
+        return out
+
+    def build(self, features_nchw, projections, tsdf, capture=True):
+        """calibrate on this scene (eager), then trace statically and capture.  Returns the eager result (for checks)."""
+        _lib.require_gpu()
+        with torch.cuda.stream(self.stream):
+            self.plan = P.Plan(self.margin)
+            with P.using(self.plan):
+                eager = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense)
+            self._alloc_inputs(features_nchw, tsdf)
+            self._load(features_nchw, projections, tsdf)
+            self.out = self._trace()                         # plain static run: creates the trace's constants
+            self.stream.synchronize()
+            if capture:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.out = self._trace()
+                self.stream.synchronize()
+        return eager
+
+    def run(self, features_nchw, projections, tsdf):
+        """enqueue one scene on self.stream; returns the static output dict (device tensors, valid until the next run)"""
+        with torch.cuda.stream(self.stream):
+            self._load(features_nchw, projections, tsdf)
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.out = self._trace()
+        return self.out
+
+    @staticmethod
+    def detections(out):
+        """static outputs -> (bboxes [K,*], scores [K,n_cls], info) like forward_scene; ONE device->host read.  Raises
+        when the scene violated an assumption of the plan (the caller re-runs it with forward_scene)."""
+        L = len(out["sizes"])
+        host = _lib.read_ints(torch.cat((out["status"].view(-1), out["valid"].view(-1), out["counts"].view(-1))))
+        if host[0] != 0:
+            raise _lib.CnrmaError(f"{host[0]} capacity / branch assumption(s) of the static plan violated: re-run eagerly")
+        valid, counts = host[1:1 + L], host[1 + L:]
+        rows, r0 = [], 0
+        for k, v in zip(out["sizes"], valid):
+            rows.append(torch.arange(r0, r0 + v, device=out["bboxes"].device))
+            r0 += k
+        rows = torch.cat(rows)
+        nl = out["n_levels"]
+        info = dict(M=counts[0], M_selected=counts[1], M_unique=counts[2], level_rows=counts[3:3 + nl],
+                    head_rows=counts[3 + nl:3 + 2 * nl])
+        return out["bboxes"].index_select(0, rows), out["scores"].index_select(0, rows), info
 
 
 def gather_detections(bboxes, scores):

@@ -1,0 +1,135 @@
+"""Size plan of a scene forward: what lets the whole pass run without a single device->host read.
+
+The reference sizes every intermediate tensor on the host (`nonzero()`, ME's coordinate manager: ray_marching.py:781,
+:328-330) -- one synchronisation per data-dependent shape.  Here a forward is run ONCE eagerly under a recording Plan
+(every data-dependent row count is read back as before and appended to `sizes`, every data-dependent branch to
+`flags`); afterwards the same launch sequence runs in *static* mode: each such tensor gets a CAPACITY derived from the
+recorded size (x margin), its live row count stays in a device word that the kernels read (the C-ABI takes a capacity and
+a count pointer everywhere), and nothing is read back.  That sequence is what pipeline.StaticScene captures into a HIP
+graph.  Every capacity / branch assumption is registered with `watch()`; `status()` folds them into one device word
+(0 = all assumptions held) that travels with the detections, so a scene that outgrows its plan is detected and can be
+re-run eagerly.
+"""
+import threading
+
+import torch
+
+_tls = threading.local()
+
+
+def current():
+    """the Plan active on this thread, or None (plain eager execution)"""
+    return getattr(_tls, "plan", None)
+
+
+def static():
+    p = current()
+    return p is not None and p.static
+
+
+class using:
+    def __init__(self, plan):
+        self.plan = plan
+
+    def __enter__(self):
+        self.prev = current()
+        _tls.plan = self.plan
+        return self.plan
+
+    def __exit__(self, *exc):
+        _tls.plan = self.prev
+        return False
+
+
+def _round_up(n, q):
+    return (n + q - 1) // q * q
+
+
+class Plan:
+    def __init__(self, margin=1.2, slack=256):
+        self.margin, self.slack = float(margin), int(slack)
+        self.sizes, self.flags = [], []
+        self.static = False
+        self._reset()
+        self._consts = []          # device constants of the static trace, created by the first (un-captured) static run
+        self.workspaces = {}       # grow-only scratch buffers of the static trace (kept alive with the plan)
+
+    def _reset(self):
+        self._i = self._j = self._c = 0
+        self._watch = []
+        self._amax = None
+
+    # ---- recording (eager calibration run) --------------------------------------------------------------------------
+    def record(self, n):
+        assert not self.static
+        self.sizes.append(int(n))
+        return int(n)
+
+    def record_flag(self, f):
+        assert not self.static
+        self.flags.append(bool(f))
+        return bool(f)
+
+    # ---- static trace -------------------------------------------------------------------------------------------
+    def begin_static(self):
+        self.static = True
+        self._reset()
+
+    def end_static(self):
+        assert self._i == len(self.sizes) and self._j == len(self.flags), \
+            "the static trace consumed a different number of sizes / flags than the calibration run recorded"
+
+    def next_cap(self, bound=None, n_dev=None, lo=0):
+        """capacity of the next data-dependent tensor (recorded size x margin, clipped to a provable bound); n_dev = its
+        live-count word: registered as `lo <= n <= capacity`"""
+        n = self.sizes[self._i]
+        self._i += 1
+        cap = _round_up(int(n * self.margin) + self.slack, 64)
+        if bound is not None:
+            cap = min(cap, int(bound))
+        cap = max(cap, 1)
+        if n_dev is not None:
+            self.watch(n_dev, lo, cap)
+        return cap
+
+    def next_flag(self):
+        f = self.flags[self._j]
+        self._j += 1
+        return f
+
+    def watch(self, n_dev, lo, hi):
+        """assumption of the static trace: lo <= n_dev[0] <= hi"""
+        self._watch.append((n_dev.view(-1)[:1], int(lo), int(hi)))
+
+    def const(self, builder):
+        """a small device constant of the static trace: built by the first static run (outside graph capture, where a
+        host->device copy is allowed), reused in sequence order by every later one"""
+        if self._c == len(self._consts):
+            self._consts.append(builder())
+        t = self._consts[self._c]
+        self._c += 1
+        return t
+
+    def workspace(self, nbytes, device):
+        buf = self.workspaces.get(device)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.workspaces[device] = buf
+        return buf
+
+    def amax_slot(self, device, words):
+        """a zeroed magnitude bound for a conv epilogue, carved from chunks that are (re-)zeroed inside the trace"""
+        if self._amax is None or self._amax[1] >= 64:
+            self._amax = [torch.zeros(64 * words, dtype=torch.float32, device=device), 0]
+        i = self._amax[1]
+        self._amax[1] = i + 1
+        return self._amax[0][i * words:(i + 1) * words]
+
+    def status(self, device):
+        """int32 [1] on the device: number of violated assumptions (0 = the static results are valid)"""
+        if not self._watch:
+            return torch.zeros(1, dtype=torch.int32, device=device)
+        vals = torch.cat([w[0].to(torch.int32) for w in self._watch])
+        lo = self.const(lambda: torch.tensor([w[1] for w in self._watch], dtype=torch.int32, device=device))
+        hi = self.const(lambda: torch.tensor([w[2] for w in self._watch], dtype=torch.int32, device=device))
+        return ((vals < lo) | (vals > hi)).sum().to(torch.int32).view(1)

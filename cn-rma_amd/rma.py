@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import plan as P
 from ._lib import call, ptr, stream
 
 
@@ -36,20 +37,23 @@ def scale_projection(projection, stride):
     return p
 
 
-def to_nhwc(features):
+def to_nhwc(features, out=None):
     """features [V,C,H,W] (reference layout) -> channels-last [V,H,W,C] on the device (one HIP pass)."""
     _lib.require_gpu()
     features = _f32(features)
     V, C, H, W = features.shape
-    out = torch.empty((V, H, W, C), dtype=torch.float32, device=features.device)
+    if out is None:
+        out = torch.empty((V, H, W, C), dtype=torch.float32, device=features.device)
+    assert out.shape == (V, H, W, C) and out.is_contiguous() and out.dtype == torch.float32
     call("cnrma_nchw_to_nhwc_f32", ptr(features), ptr(out), V, C, H, W, stream())
     return out
 
 
-def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stride):
+def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stride, proj_scaled=None):
     """Dense unprojection of all views + mean (ray_marching.py:21-69, :220-257) in one kernel.
 
-    features_nhwc [V,H,W,C] device fp32; projections [V,3,4] full-resolution (scaled here by `stride`).
+    features_nhwc [V,H,W,C] device fp32; projections [V,3,4] full-resolution (scaled here by `stride`), or
+    proj_scaled [V,3,4] = scale_projection(projections, stride) already on the device (no host work at all).
     Returns volume [C,X,Y,Z] (mean over the views that see the voxel, 0 elsewhere) and count [X,Y,Z] int32;
     the reference's `valid` is `count > 0`.
     """
@@ -57,7 +61,7 @@ def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stri
     V, H, W, C = features_nhwc.shape
     X, Y, Z = dims
     dev = features_nhwc.device
-    proj = _f32(scale_projection(projections.to(torch.float32), stride)).to(dev)
+    proj = proj_scaled if proj_scaled is not None else _f32(scale_projection(projections.to(torch.float32), stride)).to(dev)
     volume = torch.empty((C, X, Y, Z), dtype=torch.float32, device=dev)
     count = torch.empty((X, Y, Z), dtype=torch.int32, device=dev)
     call("cnrma_backproject_accum_f32", ptr(features_nhwc), ptr(proj), V, C, H, W, X, Y, Z, float(voxel_size),
@@ -175,10 +179,12 @@ class _March:
         return cnt, wsum, kept, overflow
 
     def emit_rows(self, row_offset, n_out, kept, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat,
-                  feat_stride, out_sample=None):
+                  feat_stride, out_sample=None, n_out_dev=None):
+        """n_out = rows of the output buffers; n_out_dev = device word with the live row count (None: all n_out)"""
         rec = torch.empty((int(n_out), 4), dtype=torch.int32, device=self.dev)
         call("cnrma_rma_neus_emit_rows_f32", ptr(self.pinv), ptr(self.feat), self.V, self.C, self.H, self.W, self.N,
-             self.t_one, ptr(row_offset), int(n_out), ptr(kept), kept.shape[1], ptr(sel_index), ptr(rec), ptr(w_div), float(add[0]),
+             self.t_one, ptr(row_offset), int(n_out), ptr(n_out_dev), ptr(kept), kept.shape[1], ptr(sel_index),
+             sel_index.numel() if sel_index is not None else 0, ptr(rec), ptr(w_div), float(add[0]),
              float(add[1]), float(add[2]), out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, ptr(out_sample),
              stream())
 
@@ -216,15 +222,16 @@ def mask_to_index(mask_u8):
 _SAMPLE_CALLS = [0]
 
 
-def sample_mask_device(m_dev, M, n_keep, seed=None):
-    """uint8 [M] keep-mask with exactly min(M, n_keep) ones: a uniformly random subset drawn ON THE DEVICE (device-side
-    stand-in for sample_points' np.random.choice; deterministic in `seed`, advancing per call when seed is None)."""
+def sample_mask_device(m_dev, M, n_keep, seed=None, seed_dev=None):
+    """uint8 [M] keep-mask with exactly min(m, n_keep) ones among the first m = min(m_dev[0], M) rows (zeros behind):
+    a uniformly random subset drawn ON THE DEVICE (device-side stand-in for sample_points' np.random.choice;
+    deterministic in `seed`, advancing per call when seed is None; seed_dev: device word mixed into the seed)."""
     if seed is None:
         _SAMPLE_CALLS[0] += 1
         seed = (0x9E3779B9 * _SAMPLE_CALLS[0] + int(torch.initial_seed())) & 0xFFFFFFFF
     mask = torch.empty(M, dtype=torch.uint8, device=m_dev.device)
     ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=m_dev.device)
-    call("cnrma_sample_mask", m_dev.data_ptr(), M, int(n_keep), int(seed), ptr(mask), ptr(ws), stream())
+    call("cnrma_sample_mask", m_dev.data_ptr(), M, int(n_keep), int(seed), ptr(seed_dev), ptr(mask), ptr(ws), stream())
     return mask
 
 
@@ -265,7 +272,7 @@ def rma_view_rows(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_ste
 
 def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
                      select_grids=0, offset=(0.0, 0.0, 0.0), max_points=None, sampler="numpy", mask=None,
-                     reference_quirks=True):
+                     reference_quirks=True, seed=None):
     """Fused aggregate_2d_features_ray_marching (:260-307) + switch_pointcloud test path (:339-407).
 
     Returns (coords [Ms,3], feats [Ms,C], info).  feats = feature * (w / mean(w)) with the mean over ALL M rows of
@@ -280,7 +287,7 @@ def aggregate_points(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_
     st = aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids,
                          reference_quirks)
     # the one read-back the reference also has (nonzero(), :781): total row count (+ the record-overflow guard)
-    return aggregate_finish(st, _lib.read_ints(st["readback"]), offset, max_points, sampler, mask)
+    return aggregate_finish(st, _lib.read_ints(st["readback"]), offset, max_points, sampler, mask, seed)
 
 
 def aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05, mode="neus",
@@ -310,8 +317,9 @@ def aggregate_begin(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_s
                 readback=readback)
 
 
-def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, sampler="numpy", mask=None):
-    """second half of aggregate_points; readback = st["readback"] as host ints"""
+def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, sampler="numpy", mask=None, seed=None):
+    """second half of aggregate_points; readback = st["readback"] as host ints; seed: of the device sampler (None =
+    a fresh one per call)"""
     m, single_march, off, kept, mean_w, m_total, cnt = (st[k] for k in ("m", "single_march", "off", "kept", "mean_w",
                                                                          "m_total", "cnt"))
     M = int(readback[0])
@@ -319,6 +327,8 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
         raise _lib.CnrmaError("kept-sample record overflow: a ray kept more than 1/thr samples")
     if M == 0:
         raise TypeError("no valid points in any view (ray_marching.py:300)")
+    if P.current() is not None:
+        P.current().record(M)
     sel = None
     Ms = M
     if mask is not None or (max_points is not None and M > max_points):
@@ -329,7 +339,7 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
                 mask = np.zeros(M, dtype=bool)
                 mask[np.random.choice(M, max_points, replace=False)] = True
             elif sampler == "device":
-                mask = sample_mask_device(m_total, M, max_points)
+                mask = sample_mask_device(m_total, M, max_points, seed=seed)
             else:
                 raise ValueError(f"unknown sampler {sampler!r}")
         if isinstance(mask, np.ndarray):
@@ -349,6 +359,40 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
         m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
     info = dict(M=M, M_selected=Ms, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m)
     return coords, feats, info
+
+
+def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05,
+                            offset=(0.0, 0.0, 0.0), max_points=None, seed=0, seed_dev=None, reference_quirks=True):
+    """aggregate_points() without a device->host read (the static trace of plan.Plan; NeuS single-march only): the row
+    count M stays on the device, the selection always goes through the device sampler (it keeps every row when
+    M <= max_points) and the outputs are capacity-sized.  Returns (coords [cap,3], feats [cap,C], n_dev int32 [1], info);
+    rows >= n_dev[0] are undefined."""
+    plan = P.current()
+    assert plan is not None and plan.static
+    m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0)
+    if m.kept_cap() <= 0:
+        raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
+    cnt, wsum, kept, overflow = m.march()
+    if reference_quirks:
+        _drop_single_sample_views(cnt, wsum, m.V)
+    off = exclusive_scan(cnt)
+    ws = torch.empty(_lib.load().cnrma_scan_workspace_bytes(m.R), dtype=torch.uint8, device=m.dev)
+    wtot = torch.empty(1, dtype=torch.float64, device=m.dev)
+    mean_w = torch.empty(1, dtype=torch.float32, device=m.dev)
+    call("cnrma_sum_f64", ptr(wsum), ptr(wtot), m.R, ptr(ws), stream())
+    m_total = off[m.R:]
+    call("cnrma_rma_mean_weight", ptr(wtot), m_total.data_ptr(), ptr(mean_w), stream())
+    M_cap = plan.next_cap(bound=m.R * kept.shape[1], n_dev=m_total, lo=1)      # lo = 1: M == 0 is the reference's TypeError
+    plan.watch(overflow, 0, 0)
+    n_keep = int(max_points) if max_points is not None else M_cap
+    mask = sample_mask_device(m_total, M_cap, n_keep, seed=seed, seed_dev=seed_dev)
+    sel, n_sel = mask_to_index(mask)
+    cap = min(M_cap, n_keep)
+    coords = torch.empty((cap, 3), dtype=torch.float32, device=m.dev)
+    feats = torch.empty((cap, m.C), dtype=torch.float32, device=m.dev)
+    m.emit_rows(off, cap, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C, n_out_dev=n_sel)
+    info = dict(M=m_total, M_selected=n_sel, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m)
+    return coords, feats, n_sel, info
 
 
 def aggregate_points_backward(info, grad_feats):

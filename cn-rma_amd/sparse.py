@@ -24,6 +24,7 @@ import threading
 import torch
 
 from . import _lib
+from . import plan as P
 from ._lib import call, ptr, stream
 
 
@@ -67,11 +68,29 @@ def scene_counts(scene_col, n_scenes):
     return _lib.read_ints(torch.stack([(scene_col == b).sum() for b in range(n_scenes)]))
 
 
+def _count(n_out, bound, lo=0):
+    """row count of a tensor a kernel has just produced (n_out: device int32 [1]) -> (n, n_dev).
+    Eager: the count is read back (n exact, n_dev None) and recorded when a Plan is calibrating; static trace: n is the
+    planned CAPACITY and the live count stays on the device (n_dev = n_out), registered as `lo <= n_out <= capacity`."""
+    plan = P.current()
+    if plan is not None and plan.static:
+        return plan.next_cap(bound, n_out, lo), n_out
+    n = _lib.read_ints(n_out)[0]
+    if plan is not None:
+        plan.record(n)
+    return n, None
+
+
 class CoordSet:
-    def __init__(self, coords, stride, cmap=None, n_batch=1):
+    """n = number of rows (eager) or their capacity (static trace; then n_dev is the device word holding the live count
+    and rows >= n_dev[0] are undefined -- every kernel gets both)."""
+
+    def __init__(self, coords, stride, cmap=None, n_batch=1, n=None, n_dev=None):
         assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
-        self.C = coords.contiguous()
-        self.n = coords.shape[0]
+        self.n = coords.shape[0] if n is None else int(n)
+        self.n_dev = n_dev
+        assert n_dev is None or n_batch <= 1, "the static trace runs one scene per pass"
+        self.C = coords[:self.n].contiguous()
         self.stride = int(stride)
         self.device = coords.device
         self.n_batch = n_batch     # number of scenes in the tensor (the reference is structurally 1 per GPU)
@@ -95,7 +114,7 @@ class CoordSet:
     def cmap(self):
         if self._map is None:
             m = CoordMap(self.n, self.device)
-            call("cnrma_sparse_build_map", ptr(self.C), self.n, None, ptr(m.keys), ptr(m.vals), m.cap, stream())
+            call("cnrma_sparse_build_map", ptr(self.C), self.n, ptr(self.n_dev), ptr(m.keys), ptr(m.vals), m.cap, stream())
             self._map = m
         return self._map
 
@@ -103,16 +122,7 @@ class CoordSet:
         """output sites of a stride-`factor` conv / pool: unique(floor(p / s') * s'), s' = factor * stride."""
         ns = self.stride * factor
         if ns not in self._children:
-            m = CoordMap(self.n, self.device)
-            out = torch.empty((self.n, 4), dtype=torch.int32, device=self.device)
-            n_out = torch.empty(1, dtype=torch.int32, device=self.device)
-            ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(self.n), dtype=torch.uint8, device=self.device)
-            call("cnrma_sparse_stride_coords", ptr(self.C), self.n, None, ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
-                 ptr(n_out), ptr(ws), stream())
-            n = _lib.read_ints(n_out)[0]
-            child = CoordSet(out[:n], ns, m, self.n_batch)
-            child.scene_major = self.scene_major          # first-occurrence order keeps the scenes apart and in order
-            self._children[ns] = child
+            self.prefetch_strided(1, factor)
         return self._children[ns]
 
     def prefetch_strided(self, levels, factor=2):
@@ -124,20 +134,39 @@ class CoordSet:
             ns *= factor
             cs = cs._children[ns]
             levels -= 1
-        src_C, src_ndev, cap = cs.C, None, cs.n
+        src_C, src_ndev, cap = cs.C, cs.n_dev, cs.n
         if levels <= 0 or cap == 0:
             return
         ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(cap), dtype=torch.uint8, device=self.device)
+        plan = P.current()
+        if plan is not None and plan.static:
+            # static trace: every level gets its planned capacity (hash table sized for it); the coordinate buffer keeps
+            # the provable bound (rows of the level above), so a scene that outgrows the plan cannot write out of bounds
+            for _ in range(levels):
+                ns *= factor
+                out = torch.empty((cap, 4), dtype=torch.int32, device=self.device)
+                n_out = torch.empty(1, dtype=torch.int32, device=self.device)
+                cap_k = plan.next_cap(cap, n_out)
+                m = CoordMap(cap_k, self.device)
+                call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap,
+                     ptr(out), cap_k, ptr(n_out), ptr(ws), stream())
+                child = CoordSet(out, ns, m, self.n_batch, n=cap_k, n_dev=n_out)
+                cs._children[ns] = child
+                cs, src_C, src_ndev, cap = child, child.C, n_out, cap_k
+            return
         for _ in range(levels):
             ns *= factor
             m = CoordMap(cap, self.device)
             out = torch.empty((cap, 4), dtype=torch.int32, device=self.device)
             n_out = torch.empty(1, dtype=torch.int32, device=self.device)
             call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
-                 ptr(n_out), ptr(ws), stream())
+                 0, ptr(n_out), ptr(ws), stream())
             todo.append((ns, out, n_out, m))
             src_C, src_ndev = out, n_out
         counts = _lib.read_ints(torch.cat([t[2] for t in todo]))
+        if plan is not None:
+            for n in counts:
+                plan.record(n)
         for (ns_k, out, _, m), n in zip(todo, counts):
             if m.cap > 8 * _next_pow2(max(2 * n, 16)):
                 m = None                      # a far over-sized table scatters the probes: rebuild compactly on first use
@@ -160,15 +189,15 @@ class CoordSet:
                 nbr.fill_(-1)
             elif method == "auto" and out_set is self and kernel_size % 2 == 1 and kernel_size > 1:
                 m = self.cmap
-                call("cnrma_sparse_kernel_map_symmetric", ptr(self.C), self.n, None, ptr(m.keys), ptr(m.vals), m.cap,
+                call("cnrma_sparse_kernel_map_symmetric", ptr(self.C), self.n, ptr(self.n_dev), ptr(m.keys), ptr(m.vals), m.cap,
                      ptr(offs), K, ptr(nbr), stream())
             elif method == "auto" and strided and kernel_size in (1, 2, 3):
                 m = out_set.cmap
-                call("cnrma_sparse_kernel_map_strided", ptr(self.C), self.n, None, self.stride, kernel_size, ptr(m.keys),
-                     ptr(m.vals), m.cap, ptr(nbr), out_set.n, stream())
+                call("cnrma_sparse_kernel_map_strided", ptr(self.C), self.n, ptr(self.n_dev), self.stride, kernel_size,
+                     ptr(m.keys), ptr(m.vals), m.cap, ptr(nbr), out_set.n, stream())
             else:
                 m = self.cmap
-                call("cnrma_sparse_kernel_map", ptr(out_set.C), out_set.n, None, ptr(m.keys), ptr(m.vals), m.cap,
+                call("cnrma_sparse_kernel_map", ptr(out_set.C), out_set.n, ptr(out_set.n_dev), ptr(m.keys), ptr(m.vals), m.cap,
                      ptr(offs), K, ptr(nbr), stream())
             self._nbr[key] = (nbr, out_set)   # keep out_set alive so that id() stays unique
         return self._nbr[key][0]
@@ -190,7 +219,7 @@ class SparseTensor:
             n, C = self.F.shape
             out = torch.zeros(_AMAX_WORDS, dtype=torch.float32, device=self.F.device)
             if n:
-                call("cnrma_absmax_f32", ptr(self.F.contiguous()), n, None, C, ptr(out), stream())
+                call("cnrma_absmax_f32", ptr(self.F.contiguous()), n, ptr(self.cs.n_dev), C, ptr(out), stream())
             self.amax = out
         return self.amax
 
@@ -199,7 +228,7 @@ class SparseTensor:
         if self._split is None:
             n, C = self.F.shape
             sp = torch.empty((n + 1, C // 8, 3, 8), dtype=torch.bfloat16, device=self.F.device)
-            call("cnrma_sparse_split_features", ptr(self.F.contiguous()), max(n, 1), None, C, ptr(sp), stream()) if n else sp.zero_()
+            call("cnrma_sparse_split_features", ptr(self.F.contiguous()), max(n, 1), ptr(self.cs.n_dev), C, ptr(sp), stream()) if n else sp.zero_()
             self._split = sp
         return self._split
 
@@ -237,16 +266,16 @@ class SparseTensor:
     def decomposed_coordinates(self):
         return [self.cs.C[p, 1:] for p in self.decomposition_permutations]
 
-    def features_at_coordinates(self, query_coords_float):
+    def features_at_coordinates(self, query_coords_float, n_dev=None):
         q = query_coords_float.to(torch.int32).contiguous()
-        return interpolate(self, q)
+        return interpolate(self, q, n_dev)
 
     def __add__(self, other):
         return union_add(self, other)
 
 
 # --------------------------------------------------------------------------------------------------------------
-def _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order):
+def _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, m_dev=None, out_cap=0):
     coords = coords.contiguous().float()
     feats = feats.contiguous().float()
     M, C = feats.shape
@@ -257,20 +286,26 @@ def _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order):
     src = torch.empty(M, dtype=torch.int32, device=dev)
     n_out = torch.empty(1, dtype=torch.int32, device=dev)
     ws = torch.empty(_lib.load().cnrma_voxelize_workspace_bytes(M), dtype=torch.uint8, device=dev)
-    call("cnrma_voxelize_f32", ptr(coords), ptr(feats), M, C, float(voxel_size), int(batch_id),
+    call("cnrma_voxelize_f32", ptr(coords), ptr(feats), M, ptr(m_dev), C, float(voxel_size), int(batch_id),
          {"first": 0, "morton": 1}[row_order], ptr(m.keys), ptr(m.vals),
-         m.cap, ptr(out_c), ptr(out_f), ptr(src), ptr(n_out), ptr(ws), stream())
+         m.cap, ptr(out_c), ptr(out_f), ptr(src), out_cap, ptr(n_out), ptr(ws), stream())
     return out_c, out_f, src, n_out, m
 
 
-def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton"):
+def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton", n_dev=None):
     """ME.utils.batch_sparse_collate + ME.SparseTensor (ray_marching.py:328-330): floor(coord / voxel_size),
     first occurrence wins.  row_order "first" = rows in first-occurrence order, "morton" = rows sorted by the
-    Morton code of the voxel (ME's own order is implementation-defined).  Returns (SparseTensor @ stride 1,
-    src_index int32 = source row of every output row)."""
+    Morton code of the voxel (ME's own order is implementation-defined).  n_dev: device word with the live number of
+    input rows (static trace).  Returns (SparseTensor @ stride 1, src_index int32 = source row of every output row)."""
     _lib.require_gpu()
-    out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order)
-    n = _lib.read_ints(n_out)[0]
+    if P.static():
+        plan = P.current()
+        cap = plan.next_cap(coords.shape[0])
+        out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, n_dev, cap)
+        plan.watch(n_out, 1, cap)
+        return SparseTensor(out_f[:cap], CoordSet(out_c, 1, m, n=cap, n_dev=n_out)), src[:cap]
+    out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, n_dev)
+    n = _count(n_out, coords.shape[0])[0]
     if _train(feats):                     # training: the surviving rows through torch indexing (keeps the graph)
         return SparseTensor(feats.index_select(0, src[:n].long()), CoordSet(out_c[:n], 1, m)), src[:n]
     return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
@@ -282,6 +317,7 @@ def sparse_collate(list_of_coords_feats, voxel_size):
         return voxelize(*list_of_coords_feats[0], voxel_size, 0)[0]
     _lib.require_gpu()
     parts = [_voxelize_enqueue(c, f, voxel_size, b, "morton") for b, (c, f) in enumerate(list_of_coords_feats)]
+    assert not P.static(), "the static trace runs one scene per pass"
     counts = _lib.read_ints(torch.cat([p[3] for p in parts]))       # ONE device->host read for all scenes
     C = torch.cat([p[0][:n] for p, n in zip(parts, counts)])
     if _train(*[f for _, f in list_of_coords_feats]):
@@ -311,6 +347,8 @@ _WS = {}
 def _workspace(nbytes, device):
     """grow-only scratch buffer per (device, stream): reuse is stream-ordered, so concurrent streams (several scenes in
     flight on one GPU) must not share it"""
+    if P.static():
+        return P.current().workspace(nbytes, device)
     key = (device, stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -336,6 +374,8 @@ def _amax_slot(device):
     """a zeroed magnitude bound (cnrma_amax_bytes: 64 words, one per 64-byte line) for a kernel's running |output|
     maximum: bounds are carved from a chunk of 64 that is zeroed once (one memset per 64 convolutions) and never reused,
     so a tensor's bound stays valid as long as it lives"""
+    if P.static():                   # inside the trace: the chunk's memset is part of the captured sequence
+        return P.current().amax_slot(device, _AMAX_WORDS)
     pool = getattr(_tls, "amax_pool", None)
     key = (device, stream())
     if pool is None or pool[0] != key or pool[2] >= 64:
@@ -414,7 +454,7 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             out_amax = _amax_slot(x.device)
             call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
                  ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),
-                 out_cs.n, None, ptr(ws), ws_bytes, stream())
+                 out_cs.n, ptr(out_cs.n_dev), ptr(ws), ws_bytes, stream())
             return SparseTensor(out, out_cs, None, out_amax)
         if prec == "bf16x6" and Cin % 32 == 0:
             # pre-split companions (PRESPLIT): measured on MI355X at the ScanNet shape they do not pay -- the kernel is
@@ -423,11 +463,11 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             if PRESPLIT and Cout % 8 == 0:
                 out_split = torch.empty((out_cs.n + 1, Cout // 8, 3, 8), dtype=torch.bfloat16, device=x.device)
             call("cnrma_sparse_conv_bf16x6", ptr(x.F.contiguous()), ptr(in_split), x.cs.n, Cin, ptr(nbr), K, ptr(split_weights(weight)),
-                 Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_split), out_cs.n, None, ptr(ws),
+                 Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_split), out_cs.n, ptr(out_cs.n_dev), ptr(ws),
                  ws_bytes, stream())
         else:
             call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
-                 ptr(res), ACT[act], ptr(out), out_cs.n, None, ptr(ws), ws_bytes, stream())
+                 ptr(res), ACT[act], ptr(out), out_cs.n, ptr(out_cs.n_dev), ptr(ws), ws_bytes, stream())
     return SparseTensor(out, out_cs, out_split)
 
 
@@ -550,20 +590,22 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
         prec = precision or CONV_PRECISION
         if prec == "f16x3" and Cin % 32 == 0:
             out_amax = _amax_slot(x.device)
-            call("cnrma_sparse_convtr_gen_f16x3", ptr(x.C), ptr(x.F.contiguous()), ptr(x.absmax()), n, None, Cin, half,
+            call("cnrma_sparse_convtr_gen_f16x3", ptr(x.C), ptr(x.F.contiguous()), ptr(x.absmax()), n, ptr(x.cs.n_dev), Cin, half,
                  ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f),
                  ptr(out_amax), stream())
         elif prec == "bf16x6" and Cin % 32 == 0:
             if PRESPLIT and Cout % 8 == 0:
                 out_split = torch.empty((8 * n + 1, Cout // 8, 3, 8), dtype=torch.bfloat16, device=x.device)
             in_split = x.split() if (PRESPLIT or x._split is not None) else None
-            call("cnrma_sparse_convtr_gen_bf16x6", ptr(x.C), ptr(x.F.contiguous()), ptr(in_split), n, None, Cin, half,
+            call("cnrma_sparse_convtr_gen_bf16x6", ptr(x.C), ptr(x.F.contiguous()), ptr(in_split), n, ptr(x.cs.n_dev), Cin, half,
                  ptr(split_weights(weight)), Cout, ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f),
                  ptr(out_split), stream())
         else:
-            call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, Cin, half, ptr(w), Cout,
+            call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, ptr(x.cs.n_dev), Cin, half, ptr(w), Cout,
                  ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
-    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch), out_split, out_amax)
+    # the kernels write child k of parent i at row k * n_live + i: the live rows stay contiguous, 8 per parent
+    nd = x.cs.n_dev * 8 if x.cs.n_dev is not None else None
+    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch, n_dev=nd), out_split, out_amax)
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -604,8 +646,8 @@ def max_pool(x, kernel_size=2, stride=2):
         return SparseTensor(_MaxPoolFn.apply(x.F, nbr, out_cs.n), out_cs)
     out = torch.empty((out_cs.n, C), dtype=torch.float32, device=x.device)
     if out_cs.n:
-        call("cnrma_sparse_maxpool_f32", ptr(x.F.contiguous()), C, ptr(nbr), nbr.shape[1], ptr(out), out_cs.n, None,
-             stream())
+        call("cnrma_sparse_maxpool_f32", ptr(x.F.contiguous()), C, ptr(nbr), nbr.shape[1], ptr(out), out_cs.n,
+             ptr(out_cs.n_dev), stream())
     return SparseTensor(out, out_cs, None, x.amax)       # a maximum over a subset: the input's bound still holds
 
 
@@ -634,8 +676,8 @@ def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
     src = x.F.contiguous()
     if x.cs.n_batch <= 1:
         if n:
-            call("cnrma_sparse_instnorm_f32", ptr(src), n, None, C, ptr(w), ptr(b), float(eps), int(relu), ptr(out), ptr(ws),
-                 stream())
+            call("cnrma_sparse_instnorm_f32", ptr(src), n, ptr(x.cs.n_dev), C, ptr(w), ptr(b), float(eps), int(relu), ptr(out),
+                 ptr(ws), stream())
     else:                                   # statistics per scene (MinkowskiInstanceNorm): one pass per row segment
         assert x.cs.scene_major, "instance norm of a multi-scene tensor needs scene-major rows"
         r0 = 0
@@ -656,14 +698,19 @@ def union_add(a, b):
     na, nb, C = a.cs.n, b.cs.n, a.F.shape[1]
     dev = a.device
     m = CoordMap(na + nb, dev)
-    call("cnrma_sparse_build_map", ptr(a.C), na, None, ptr(m.keys), ptr(m.vals), m.cap, stream())
+    call("cnrma_sparse_build_map", ptr(a.C), na, ptr(a.cs.n_dev), ptr(m.keys), ptr(m.vals), m.cap, stream())
     out_c = torch.empty((na + nb, 4), dtype=torch.int32, device=dev)
     out_f = torch.empty((na + nb, C), dtype=torch.float32, device=dev)
     n_out = torch.empty(1, dtype=torch.int32, device=dev)
     ws = torch.empty(_lib.load().cnrma_union_workspace_bytes(nb), dtype=torch.uint8, device=dev)
-    call("cnrma_sparse_union_add_f32", ptr(a.C), ptr(a.F.contiguous()), na, None, ptr(b.C), ptr(b.F.contiguous()), nb,
-         None, C, ptr(m.keys), ptr(m.vals), m.cap, ptr(out_c), ptr(out_f), ptr(n_out), ptr(ws), stream())
     nbatch = max(a.cs.n_batch, b.cs.n_batch)
+    out_cap = max(na, P.current().next_cap(na + nb)) if P.static() else na + nb
+    call("cnrma_sparse_union_add_f32", ptr(a.C), ptr(a.F.contiguous()), na, ptr(a.cs.n_dev), ptr(b.C), ptr(b.F.contiguous()),
+         nb, ptr(b.cs.n_dev), C, ptr(m.keys), ptr(m.vals), m.cap, ptr(out_c), ptr(out_f), out_cap, ptr(n_out), ptr(ws),
+         stream())
+    if P.static():
+        P.current().watch(n_out, 0, out_cap)
+        return SparseTensor(out_f[:out_cap], CoordSet(out_c, a.cs.stride, m, nbatch, n=out_cap, n_dev=n_out))
     if nbatch > 1:          # row count and rows per scene with ONE device->host read
         live = torch.arange(na + nb, device=dev) < n_out
         scene = out_c[:, 0]
@@ -671,7 +718,7 @@ def union_add(a, b):
                                                    for s_ in range(nbatch)]))
         n, counts = got[0], got[1:]
     else:
-        n, counts = _lib.read_ints(n_out)[0], None
+        n, counts = _count(n_out, na + nb)[0], None
     cs = CoordSet(out_c[:n], a.cs.stride, m, nbatch)
     cs._counts = counts
     if _train(a.F, b.F):            # training: the kernel placed the rows (a's first, then b's new ones); sum through torch
@@ -682,15 +729,16 @@ def union_add(a, b):
     return SparseTensor(out_f[:n], cs)
 
 
-def interpolate(score, query_coords):
-    """score.features_at_coordinates(query): linear interpolation on score's lattice (fcaf3d_head.py:129)."""
+def interpolate(score, query_coords, n_dev=None):
+    """score.features_at_coordinates(query): linear interpolation on score's lattice (fcaf3d_head.py:129).
+    query_coords int32 [n,4]; n_dev: device word with the live number of queries (static trace)."""
     _lib.require_gpu()
     assert score.F.shape[1] == 1
     n = query_coords.shape[0]
     out = torch.empty((n, 1), dtype=torch.float32, device=score.device)
     m = score.cs.cmap
     if n:
-        call("cnrma_sparse_interp_f32", ptr(query_coords.contiguous()), n, None, ptr(score.F.contiguous()), ptr(m.keys),
+        call("cnrma_sparse_interp_f32", ptr(query_coords.contiguous()), n, ptr(n_dev), ptr(score.F.contiguous()), ptr(m.keys),
              ptr(m.vals), m.cap, score.cs.stride, ptr(out), stream())
     return out
 
@@ -703,13 +751,18 @@ def prune(x, keep_mask, n_keep=None, counts=None):
     n, C = x.F.shape
     mask = keep_mask.to(torch.uint8).contiguous()
     sel, n_sel = mask_to_index(mask)
-    k = _lib.read_ints(n_sel)[0] if n_keep is None else int(n_keep)
+    nd = None
+    if P.static():            # n_keep = upper bound of the kept rows; their number stays on the device
+        assert n_keep is not None
+        k, nd = min(int(n_keep), n), n_sel
+    else:
+        k = _lib.read_ints(n_sel)[0] if n_keep is None else int(n_keep)
     out_c = torch.empty((k, 4), dtype=torch.int32, device=x.device)
     out_f = torch.empty((k, C), dtype=torch.float32, device=x.device)
     if n:
-        call("cnrma_sparse_prune_f32", ptr(x.C), ptr(x.F.contiguous()), n, None, C, ptr(sel), ptr(out_c), ptr(out_f),
+        call("cnrma_sparse_prune_f32", ptr(x.C), ptr(x.F.contiguous()), n, ptr(x.cs.n_dev), C, ptr(sel), ptr(out_c), ptr(out_f),
              stream())
-    cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch)
+    cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch, n_dev=nd)
     cs._counts = counts
     if _train(x.F):
         return SparseTensor(x.F.index_select(0, torch.nonzero(mask).view(-1)), cs)
@@ -762,14 +815,20 @@ def select_decode(ids, cls_score, centerness, bbox_pred, points, yaw_parametriza
     return boxes, scores
 
 
-def topk_mask(scores, k):
-    """uint8 keep-mask of the k largest scores (ties -> smaller index): row set of torch.topk(scores, k), no sort"""
+def topk_mask(scores, k, n_dev=None):
+    """uint8 keep-mask of the k largest scores (ties -> smaller index): row set of torch.topk(scores, k), no sort.
+    n_dev: device word with the live number of scores (rows behind it are never kept)."""
     _lib.require_gpu()
     scores = scores.contiguous().view(-1).float()
     n = scores.numel()
     mask = torch.empty(n, dtype=torch.uint8, device=scores.device)
-    n_dev = torch.tensor([n], dtype=torch.int32, device=scores.device) if n not in _NDEV else _NDEV[n]
-    _NDEV[n] = n_dev
+    if n_dev is None:
+        key = (scores.device, n)
+        n_dev = _NDEV.get(key)
+        if n_dev is None:
+            if len(_NDEV) > 256:
+                _NDEV.clear()
+            n_dev = _NDEV[key] = torch.full((1,), n, dtype=torch.int32, device=scores.device)
     ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=scores.device)
     call("cnrma_topk_mask_f32", ptr(scores), ptr(n_dev), n, int(k), ptr(mask), ptr(ws), stream())
     return mask
@@ -782,7 +841,7 @@ def row_max(feats):
     n, C = feats.shape
     out = torch.empty((n, 1), dtype=torch.float32, device=feats.device)
     if n:
-        call("cnrma_rowmax_f32", ptr(feats.contiguous()), n, None, C, ptr(out), stream())
+        call("cnrma_rowmax_f32", ptr(feats.contiguous()), n, None, C, ptr(out), stream())      # dead rows: harmless values
     return out
 
 

@@ -68,12 +68,18 @@ def camera_projections(V, dims, voxel_size=0.04, img_hw=(480, 640)):
     return torch.from_numpy(np.stack(out).astype(np.float32))
 
 
-def make_scene(shape="S", seed=0, boxes=0, V=None):
-    """Returns dict(features[V,1,C,H,W], projection[V,1,3,4], tsdf[1,1,X,Y,Z], dims, voxel_size, origin, stride)."""
+def make_scene(shape="S", seed=0, boxes=0, V=None, device=None):
+    """Returns dict(features[V,1,C,H,W], projection[V,1,3,4], tsdf[1,1,X,Y,Z], dims, voxel_size, origin, stride).
+    device: draw the feature maps directly on that device (the north-star shape holds 12.6 GB of them per scene; the
+    values then come from the device generator's stream, not the CPU one -- geometry and TSDF are unchanged)."""
     Vd, C, Hf, Wf, dims, stride = SHAPES[shape] if isinstance(shape, str) else shape
     V = V or Vd
-    g = torch.Generator().manual_seed(seed)
-    feats = torch.randn(V, 1, C, Hf, Wf, generator=g, dtype=torch.float32)
+    if device is not None and torch.device(device).type != "cpu":
+        g = torch.Generator(device=device).manual_seed(seed)
+        feats = torch.randn(V, 1, C, Hf, Wf, generator=g, dtype=torch.float32, device=device)
+    else:
+        g = torch.Generator().manual_seed(seed)
+        feats = torch.randn(V, 1, C, Hf, Wf, generator=g, dtype=torch.float32)
     proj = camera_projections(V, dims, img_hw=(Hf * stride, Wf * stride)).view(V, 1, 3, 4)
     tsdf = room_tsdf(dims, boxes=boxes, seed=seed)
     return dict(features=feats, projection=proj, tsdf=tsdf, dims=tuple(dims), voxel_size=0.04,

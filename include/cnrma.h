@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 1
+#define CNRMA_ABI_VERSION 2
 
 int cnrma_abi_version(void);
 
@@ -118,22 +118,28 @@ int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, in
 int cnrma_rma_neus_rows_backward_f32(const float* grad_out_feat, int grad_stride, int V, int C, int H, int W,
                                      const int32_t* row_offset, const void* kept, int cap, const int32_t* sel_index,
                                      const float* w_div, float* grad_feat_nhwc, void* stream);
+/* n_out = capacity of the output (rows of `records`, grid size); n_out_dev (may be NULL) = device word with the live number of
+ * output rows (the n_sel of cnrma_mask_to_index); sel_cap = entries of sel_index (rows >= sel_cap are dropped). */
 int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
-                                 int n_steps, float t_one, const int32_t* row_offset, int64_t n_out, const void* kept,
-                                 int cap, const int32_t* sel_index, void* records, const float* w_div, float addx,
-                                 float addy, float addz, float* out_xyz, int xyz_stride, float* out_w, int w_stride,
-                                 float* out_feat, int feat_stride, int32_t* out_sample, void* stream);
+                                 int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
+                                 const int32_t* n_out_dev, const void* kept, int cap, const int32_t* sel_index,
+                                 int64_t sel_cap, void* records, const float* w_div, float addx, float addy, float addz,
+                                 float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                                 int feat_stride, int32_t* out_sample, void* stream);
 
 /* Device-side replacement of sample_points()'s np.random.choice(M, n_keep, replace=False)
  * (fcaf3d_transforms.py:283-296): mask[0..M) gets exactly min(M, n_keep) ones, a uniformly random subset that is a
- * deterministic function of `seed` (smallest n_keep 32-bit hash keys, ties by index).  M = m_dev[0] is read on the
- * device (no host sync); m_cap bounds the grid.  Same distribution as the reference, different random stream. */
+ * deterministic function of `seed` (smallest n_keep 32-bit hash keys, ties by index).  M = min(m_dev[0], m_cap) is read
+ * on the device (no host sync); mask has m_cap entries, those behind M are set to 0.  seed_dev (may be NULL): device word
+ * mixed into the seed, so that replays of a captured launch sequence draw fresh subsets.  Same distribution as the
+ * reference, different random stream. */
 size_t cnrma_sample_workspace_bytes(void);
-int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, uint8_t* mask, void* workspace,
-                      void* stream);
+int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, const uint32_t* seed_dev,
+                      uint8_t* mask, void* workspace, void* stream);
 /* keep-mask of the k largest scores (ties -> smaller index): the row set of torch.topk(scores, k) as used by the
  * pts_threshold pruning (fcaf3d_head.py:131-137) and nms_pre (:252-256), by 3-pass radix select instead of a sort.
- * n = n_dev[0] (device); workspace: cnrma_sample_workspace_bytes(). */
+ * n = min(n_dev[0], n_cap) (device); mask has n_cap entries, those behind n are set to 0;
+ * workspace: cnrma_sample_workspace_bytes(). */
 int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, uint8_t* mask,
                         void* workspace, void* stream);
 
@@ -186,14 +192,16 @@ int cnrma_select_rows_f32(const float* points, int64_t M, int C, const int32_t* 
  * strided level).
  * hash_keys uint64[hash_cap], hash_vals int32[hash_cap]: open-addressing table, hash_cap a power of two >= 2*M;
  * on return it maps voxel key -> output row (reusable as the coordinate map of the level).
+ * M = capacity of the input, m_dev (may be NULL) = device word with its live row count.  out_cap (0 = M): rows of the
+ * output buffers; unique voxels beyond it are dropped and left unmapped (n_out still counts them: n_out > out_cap tells).
  * out_coords int32[Mu][4] (b,x,y,z), out_feats[Mu][C], out_src int32[Mu], n_out[0] = Mu (device).
  * workspace: cnrma_voxelize_workspace_bytes(M).
  * ---------------------------------------------------------------------------------------------------------- */
 size_t cnrma_voxelize_workspace_bytes(int64_t M);
-int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, int C, float voxel_size, int batch_id,
-                       int row_order, uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap,
-                       int32_t* out_coords, float* out_feats, int32_t* out_src, int32_t* n_out, void* workspace,
-                       void* stream);
+int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, const int32_t* m_dev, int C,
+                       float voxel_size, int batch_id, int row_order, uint64_t* hash_keys, int32_t* hash_vals,
+                       int64_t hash_cap, int32_t* out_coords, float* out_feats, int32_t* out_src, int64_t out_cap,
+                       int32_t* n_out, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * a10-a11  sparse operators (replace the MinkowskiEngine v0.5.4 surface used by
@@ -210,10 +218,11 @@ int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, const int32_t* 
 
 /* strided output coordinate set: unique(floor(p / new_stride) * new_stride) in first-occurrence order
  * (MinkowskiConvolution / MinkowskiMaxPooling with stride 2: fcaf3d_backbone.py:26-31, BasicBlock stride 2).
- * Builds the output map (hash) as well.  workspace: cnrma_voxelize_workspace_bytes(n_cap). */
+ * Builds the output map (hash) as well.  out_cap (0 = n_cap): rows of out_coords; sites beyond it are dropped and left
+ * unmapped (table value -1), n_out still counts them.  workspace: cnrma_voxelize_workspace_bytes(n_cap). */
 int cnrma_sparse_stride_coords(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int new_stride,
                                uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap, int32_t* out_coords,
-                               int32_t* n_out, void* workspace, void* stream);
+                               int64_t out_cap, int32_t* n_out, void* workspace, void* stream);
 
 /* neighbour table ("kernel map", output-stationary): nbr[No][K] = input row at out_coord + offset[k], or -1.
  * offsets int32 [K][3] in coordinate units (already multiplied by the tensor stride), k with x fastest. */
@@ -330,12 +339,13 @@ int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_
 /* union-add of two sparse tensors at the same tensor stride (`inputs[i] + x`, fcaf3d_head.py:114):
  * output rows = all rows of A (in order) followed by the rows of B that are not in A.
  * a_hash maps A's coords -> A rows.  out_coords [Na+Nb cap][4], out_feats likewise; n_out device word.
- * On return the A hash additionally maps B-only coords -> their new rows (it becomes the union's map). */
+ * On return the A hash additionally maps B-only coords -> their new rows (it becomes the union's map).
+ * out_cap (>= na_cap): rows of the output buffers; B-only rows beyond it are dropped (n_out still counts them). */
 size_t cnrma_union_workspace_bytes(int64_t nb);
 int cnrma_sparse_union_add_f32(const int32_t* a_coords, const float* a_feats, int64_t na_cap, const int32_t* na_dev,
                                const int32_t* b_coords, const float* b_feats, int64_t nb_cap, const int32_t* nb_dev,
                                int C, uint64_t* a_hash_keys, int32_t* a_hash_vals, int64_t hash_cap,
-                               int32_t* out_coords, float* out_feats, int32_t* n_out, void* workspace,
+                               int32_t* out_coords, float* out_feats, int64_t out_cap, int32_t* n_out, void* workspace,
                                void* stream);
 
 /* features_at_coordinates (linear interpolation on the coarser lattice, fcaf3d_head.py:129):

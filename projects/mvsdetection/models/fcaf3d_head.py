@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from cnrma_amd import nn as snn
+from cnrma_amd import plan as P
 from cnrma_amd import sparse as S
 
 from ..registry import BBOX_ASSIGNERS, HEADS, HAVE_MMDET, build_assigner
@@ -201,11 +202,24 @@ class FCAF3DHead(nn.Module):
         """keep the top `pts_threshold` rows per scene by the interpolated max-class score of the coarser level"""
         if self.pts_threshold < 0:
             return x
+        plan = P.current()
+        if plan is not None and plan.static:
+            # static trace (one scene): the branch of the calibration run, its premise registered as an assumption
+            if plan.next_flag():
+                plan.watch(x.cs.n_dev, 0, self.pts_threshold)
+                return x
+            with torch.no_grad():
+                interpolated = S.interpolate(scores, x.C, x.cs.n_dev)
+                mask = S.topk_mask(interpolated, self.pts_threshold, n_dev=x.cs.n_dev)   # keeps every row when n <= threshold
+            return S.prune(x, mask, n_keep=self.pts_threshold)
         with torch.no_grad():
             counts = x.cs.batch_counts()
-            if all(c <= self.pts_threshold for c in counts):
+            skip = all(c <= self.pts_threshold for c in counts)
+            if plan is not None:
+                plan.record_flag(skip)
+            if skip:
                 return x                                # the top-k keeps every row: pruning is the identity
-            interpolated = scores.features_at_coordinates(x.C.float())
+            interpolated = S.interpolate(scores, x.C)
             # radix-select keep-mask instead of torch.topk's sort (same row set; ties by index)
             kept = [min(c, self.pts_threshold) for c in counts]
             if len(counts) == 1:
@@ -223,7 +237,9 @@ class FCAF3DHead(nn.Module):
 
     def _head_weights(self):
         """the three 1x1 head convolutions as ONE [128, 1+R+n_cls] GEMM (+ bias row for the class logits)"""
-        if self._fused_head is None or self._fused_head[0].device != self.cls_conv.kernel.device:
+        params = (self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel, self.cls_conv.bias)
+        tag = tuple((t.data_ptr(), t._version, t.device) for t in params)       # in-place updates / load_state_dict bump _version
+        if self._fused_head is None or self._fused_head[2] != tag:
             with torch.no_grad():
                 w = torch.cat((self.centerness_conv.kernel, self.reg_conv.kernel, self.cls_conv.kernel), dim=1)
                 n_out = w.shape[1]
@@ -231,8 +247,8 @@ class FCAF3DHead(nn.Module):
                 w = torch.cat((w, w.new_zeros(w.shape[0], pad)), dim=1).contiguous()
                 b = torch.zeros(w.shape[1], device=w.device)
                 b[1 + self.n_reg_outs:n_out] = self.cls_conv.bias.view(-1)
-            self._fused_head = (w, b.contiguous())
-        return self._fused_head
+            self._fused_head = (w, b.contiguous(), tag)
+        return self._fused_head[:2]
 
     def forward_single(self, x, scale, fused=False):
         if self.training or (x.cs.n_batch > 1 and not fused):
@@ -286,8 +302,11 @@ class FCAF3DHead(nn.Module):
     def _get_bboxes_single(self, centernesses, bbox_preds, cls_scores, points, scene_id=None, save_path=None):
         mlvl_bboxes, mlvl_scores = [], []
         nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
+        plan = P.current()
         for centerness, bbox_pred, cls_score, point in zip(centernesses, bbox_preds, cls_scores, points):
             ids = None
+            if plan is not None:
+                plan.record_flag(len(cls_score) > nms_pre > 0)
             if len(cls_score) > nms_pre > 0:
                 max_scores = S.max_scores(cls_score, centerness)                            # :249-250 (ranking key only)
                 _, ids = max_scores.topk(nms_pre)                                           # :252-256
@@ -309,6 +328,36 @@ class FCAF3DHead(nn.Module):
                                                [x[i] for x in cls_scores], [x[i] for x in points],
                                                scene_ids[i] if scene_ids is not None else None, save_path))
         return out
+
+    def get_bboxes_static(self, centernesses, bbox_preds, cls_scores, points, coord_sets):
+        """_get_bboxes_single inside the static trace (plan.Plan; one scene, forward(..., fused=True) outputs): no row
+        count is read back.  Per level the branch of the calibration run is replayed -- more rows than nms_pre: the
+        nms_pre best by max class score x centerness (dead rows ranked -inf), else all rows -- and its premise registered.
+        Returns (bboxes [K,6|7], scores [K,n_cls], valid int32 [L], sizes): level l owns rows [sum(sizes[:l]), +sizes[l]) of
+        which the first valid[l] are detections (the reference's row order within the level)."""
+        plan = P.current()
+        nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
+        boxes, scores, valid, sizes = [], [], [], []
+        for cen, box, cls, pts, cs in zip(centernesses, bbox_preds, cls_scores, points, coord_sets):
+            cen, box, cls, pts, cs = cen[0], box[0], cls[0], pts[0], cs[0]
+            cap, n_dev = cs.n, cs.n_dev
+            if plan.next_flag():
+                assert cap > nms_pre
+                plan.watch(n_dev, nms_pre + 1, cap)
+                ms = S.max_scores(cls, cen)
+                live = torch.arange(cap, device=ms.device, dtype=torch.int32) < n_dev
+                ids = torch.where(live, ms, torch.full_like(ms, float("-inf"))).topk(nms_pre)[1]
+                k = nms_pre
+                valid.append(plan.const(lambda: torch.full((1,), nms_pre, dtype=torch.int32, device=ms.device)))
+            else:
+                plan.watch(n_dev, 0, min(cap, nms_pre) if nms_pre > 0 else cap)
+                ids, k = None, cap
+                valid.append(n_dev.view(1))
+            bx, sc = S.select_decode(ids, cls, cen, box, pts, self.yaw_parametrization)
+            boxes.append(bx)
+            scores.append(sc)
+            sizes.append(k)
+        return torch.cat(boxes), torch.cat(scores), torch.cat(valid), sizes
 
     def get_bboxes_fused(self, centernesses, bbox_preds, cls_scores, points, scenes, n_scenes):
         """decode of forward(..., fused=True): per level ONE row set for all scenes + the rows' scene ids.  Per scene the

@@ -143,7 +143,7 @@ def test_library_exports_every_declared_symbol():
     assert len(decl) >= 30
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/cnrma.h but not exported"
-    assert lib.cnrma_abi_version() == 1
+    assert lib.cnrma_abi_version() == _lib.ABI_VERSION
 
 
 def test_ctypes_table_matches_header():

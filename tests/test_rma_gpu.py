@@ -34,7 +34,7 @@ def test_host_projection_inverse_close_to_golden(name):
 
 def test_library_is_the_hip_build(device):
     from cnrma_amd import _lib
-    assert _lib.load().cnrma_abi_version() == 1
+    assert _lib.load().cnrma_abi_version() == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 30, 40), (2, 32, 17, 23), (1, 5, 9, 7), (2, 64, 33, 65)])
