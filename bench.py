@@ -1,17 +1,28 @@
 """bench.py -- scenes/s of the CN-RMA hot path (dense unprojection -> RMA -> voxelise -> FCAF3D -> decode), forward.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S|St|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NS|S|St|tiny]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One "step" = one synthetic scene per GPU through the whole hot path (features and TSDF already resident in HBM:
-they are the outputs of the 2D backbone / Atlas 3D network, which are outside the path).  Scenes are independent,
-so N GPUs process N scenes per step (weak scaling) and finish with the variable-length all-gather of detections
-over RCCL.  Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+Workload = the configuration BASELINE.json's metric is quoted on: NS = 40 views x 256 channels x 480x640 feature planes
+into a 192^3 grid (SURVEY.md 8d "Headline (NS)"); the ScanNet-config shape S (40 x 32ch x 120x160 -> 192x192x80) is
+measured in the same run and printed as the labelled block "S" of the same JSON line.
+
+A *scene* goes through the whole path as ONE replayed HIP graph (pipeline.StaticScene: ~350 launches, no device->host
+read); inputs (feature maps as the 2D backbone writes them, NCHW fp32, and the TSDF) are resident in HBM; `--slots`
+graphs on their own streams are in flight so that the latency-bound small kernels of one scene overlap the large kernels
+of another.  A *step* = one wave of `scenes_per_step` scenes per GPU (chosen from the warm-up so that the K timed steps
+take >= --window-s seconds; printed in `config`).  >= 8 DISTINCT scenes (own feature tensors, own furniture in the TSDF)
+are rotated.  The K steps are timed three times (each window bracketed by barrier + synchronize, MAX over ranks); `value`
+is the median window.  Scenes are independent: N GPUs process N x scenes_per_step scenes per step (weak scaling), the
+only exchange is ONE all-gather of the padded detections per step over RCCL.
+Rank 0 prints ONE JSON line carrying `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,37 +30,59 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0   # measured float4 copy (same guide)
+MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_F16_PEAK_TFLOPS = 2500.0
+# HBM-side traffic of the dominant kernel per launch from the PMC passes committed under profiles/ (separate rocprofv3
+# --pmc runs: FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM" -- + WRITE_SIZE)
+PMC_TRAFFIC = {
+    # (workload, kernel) -> (bytes per launch, source)   -- filled from profiles/r02_* (see profiles/README.md)
+}
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak (= vector peak)
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
-# HBM-side traffic of the dominant kernel from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of
-# this same command at workload S: FETCH_SIZE x 2 (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md
-# "HBM") + WRITE_SIZE, KB -> bytes), all sparse_conv_bf16x6 launches of one scene / launches per scene
-PMC_CONV_TRAFFIC_S = dict(bytes_per_launch=(2 * 4107.7e6 * 1.024 + 1254.5e6 * 1.024) / 51.0,
-                          source="profiles/r01_f16x3_pmc_FETCH_SIZE.csv + r01_f16x3_pmc_WRITE_SIZE.csv")
-PMC_CONV_TRAFFIC_S_BF16X6 = dict(bytes_per_launch=(2 * 4805.0e6 * 1.024 + 1140.0e6 * 1.024) / 47.0,
-                                 source="profiles/r01_final_pmc_FETCH_SIZE.csv + r01_final_pmc_WRITE_SIZE.csv")
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries the ONE JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--workload", default="S", help="S = ScanNet config (40 views, 32ch 120x160 -> 192x192x80); St; tiny")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="scenes in flight per GPU (each on its own HIP stream + host thread); 1 = strictly sequential")
-    ap.add_argument("--batch", type=int, default=4,
-                    help="scenes per sparse-network pass (their voxels are collated into one multi-scene tensor)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="NS", help="NS = north-star shape (default); S = ScanNet config; St; tiny")
+    ap.add_argument("--slots", type=int, default=2, help="scene graphs in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--scenes", type=int, default=8, help="distinct scenes rotated per GPU")
+    ap.add_argument("--scenes-per-step", type=int, default=0, help="0 = chosen from the warm-up (see --window-s)")
+    ap.add_argument("--window-s", type=float, default=2.0, help="minimum length of one timed window of K steps")
+    ap.add_argument("--windows", type=int, default=3)
+    ap.add_argument("--eager", action="store_true", help="no graphs: the eager path (device->host reads per scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S block and the f32-convolution block")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (torch.distributed.run)
+    BEFORE anything in this process touches the GPU, and exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def build_model(C, device, n_classes=18, n_reg=6):
+    import torch
     from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
     from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
     torch.manual_seed(0)
@@ -61,100 +94,423 @@ def build_model(C, device, n_classes=18, n_reg=6):
     return backbone.to(device).eval(), head.to(device).eval()
 
 
-# positions of (Cin, K, Cout, rows) in the argument lists of the convolution entry points
-CONV_ARGS = {"cnrma_sparse_conv_f32": (1, 3, 5, 11), "cnrma_sparse_conv_bf16x6": (3, 5, 7, 14),
-             "cnrma_sparse_conv_f16x3": (2, 4, 6, 13)}
+# ------------------------------------------------------------------------------------------------------------------
+# per-kernel profile of ONE eager scene (outside the timed region): HIP events around every C-ABI call on the launch
+# stream + the algorithmic work of every convolution (rows, kernel-map pairs)
+# ------------------------------------------------------------------------------------------------------------------
+CONV_CALLS = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_conv_f16x3", "cnrma_sparse_convtr_gen_f32",
+              "cnrma_sparse_convtr_gen_bf16x6", "cnrma_sparse_convtr_gen_f16x3")
 
 
 class KernelProfile:
-    """per C-ABI call HIP-event timing on the launch stream (each timed entry point is exactly one kernel)"""
-    TIMED = ("cnrma_backproject_accum_f32", "cnrma_rma_neus_count_f32", "cnrma_rma_neus_emit_f32",
-             "cnrma_rma_neus_march_f32", "cnrma_sparse_kernel_map_symmetric", "cnrma_sparse_kernel_map_strided",
-             "cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_conv_f16x3", "cnrma_sparse_convtr_gen_f32",
-             "cnrma_nchw_to_nhwc_f32",
-             "cnrma_sparse_kernel_map", "cnrma_sparse_maxpool_f32")
+    TIMED = ("cnrma_backproject_accum_f32", "cnrma_rma_neus_march_f32", "cnrma_rma_neus_emit_rows_f32",
+             "cnrma_sparse_kernel_map_symmetric", "cnrma_sparse_kernel_map_strided", "cnrma_sparse_kernel_map",
+             "cnrma_nchw_to_nhwc_f32", "cnrma_sparse_maxpool_f32", "cnrma_voxelize_f32", "cnrma_sample_mask",
+             "cnrma_sparse_stride_coords", "cnrma_sparse_union_add_f32", "cnrma_sparse_instnorm_f32") + CONV_CALLS
 
     def __init__(self):
-        self.records = []
+        self.records, self.layers = [], []
 
     def install(self):
+        import torch
         from cnrma_amd import _lib
-        self._orig = _lib.call
+        from cnrma_amd import sparse as S
+        self._orig_call, self._orig_conv, self._orig_convtr = _lib.call, S.conv, S.conv_transpose_generative
         prof = self
 
         def timed_call(name, *args):
             if name not in prof.TIMED:
-                return prof._orig(name, *args)
+                return prof._orig_call(name, *args)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            rc = prof._orig(name, *args)
+            rc = prof._orig_call(name, *args)
             b.record()
-            prof.records.append((name, args, a, b))
+            prof.records.append((name, a, b))
             return rc
+
+        def conv(x, weight, kernel_size=3, stride=1, *a, **k):
+            y = prof._orig_conv(x, weight, kernel_size, stride, *a, **k)
+            K = kernel_size ** 3
+            if K == 1 and stride == 1:
+                pairs = y.cs.n
+            else:
+                pairs = int((x.cs.neighbours(y.cs, kernel_size, x.cs.stride) >= 0).sum())
+            prof.layers.append(dict(K=K, Cin=x.F.shape[1], Cout=y.F.shape[1], n_in=x.cs.n, n_out=y.cs.n, pairs=pairs, taps=K))
+            return y
+
+        def convtr(x, weight, *a, **k):
+            y = prof._orig_convtr(x, weight, *a, **k)
+            prof.layers.append(dict(K=8, Cin=x.F.shape[1], Cout=y.F.shape[1], n_in=x.cs.n, n_out=y.cs.n, pairs=y.cs.n, taps=1))
+            return y
         for mod in ("cnrma_amd._lib", "cnrma_amd.rma", "cnrma_amd.sparse"):
             sys.modules[mod].call = timed_call
+        S.conv, S.conv_transpose_generative = conv, convtr
+        sys.modules["cnrma_amd.nn"].S.conv = conv
 
     def uninstall(self):
+        from cnrma_amd import sparse as S
         for mod in ("cnrma_amd._lib", "cnrma_amd.rma", "cnrma_amd.sparse"):
-            sys.modules[mod].call = self._orig
+            sys.modules[mod].call = self._orig_call
+        S.conv, S.conv_transpose_generative = self._orig_conv, self._orig_convtr
 
-    def summary(self):
+    def summary(self, reps):
+        import torch
         torch.cuda.synchronize()
         agg = {}
-        for name, args, a, b in self.records:
+        conv_ms = []
+        for name, a, b in self.records:
             ms = a.elapsed_time(b)
-            d = agg.setdefault(name, dict(ms=0.0, n=0, flops=0.0))
+            d = agg.setdefault(name, dict(ms=0.0, n=0))
             d["ms"] += ms
             d["n"] += 1
-            if name in CONV_ARGS:
-                cin, k, cout, rows = (args[i] for i in CONV_ARGS[name])
-                d["flops"] += 2.0 * k * cin * cout * rows      # dense-K upper bound (executed MFMA work)
-        return agg
+            if name in CONV_CALLS:
+                conv_ms.append(ms)
+        kern = {k: dict(ms_per_scene=v["ms"] / reps, launches_per_scene=v["n"] / reps) for k, v in agg.items()}
+        assert len(conv_ms) == len(self.layers), (len(conv_ms), len(self.layers))
+        n = len(self.layers) // reps
+        layers = []
+        for i in range(n):                       # same layer over the repetitions
+            L = dict(self.layers[i])
+            L["ms"] = sum(conv_ms[i + r * n] for r in range(reps)) / reps
+            layers.append(L)
+        return kern, layers
 
 
-def algorithmic_bytes_dense(V, C, H, W, dims):
+def algorithmic_bytes(V, C, H, W, dims, Ms, Mu, layers):
+    """compulsory traffic of one scene, SURVEY.md 8(d) (every input read once, every output written once, fp32)"""
     G = dims[0] * dims[1] * dims[2]
-    return 4 * V * C * H * W + 4 * C * G + 4 * G + 48 * V
+    b_dense = 4 * V * C * H * W + 4 * C * G + 4 * G + 48 * V
+    b_rma = 4 * G + 4 * Ms * C + 4 * Ms * (3 + C)          # selection fused into the emission: only kept rows move
+    b_vox = 4 * Ms * (3 + C) + 16 * Mu + 4 * Mu * C
+    b_conv = sum(4 * L["n_in"] * L["Cin"] + 4 * L["n_out"] * L["Cout"] + 4 * L["K"] * L["Cin"] * L["Cout"] + 8 * L["pairs"]
+                 for L in layers)
+    return dict(dense=b_dense, rma=b_rma, voxelize=b_vox, conv=b_conv, scene=b_dense + b_rma + b_vox + b_conv)
 
 
-def cpu_baseline(shape_name, n_views=2, n_points=25000):
-    """The oracle (a CPU port of the reference's algorithm) timed on this host's cores on a bounded sample."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a CPU restatement of the reference's algorithm) on this host's cores
+# ------------------------------------------------------------------------------------------------------------------
+def _timeit(fn, warm=1, reps=3, budget_s=20.0):
+    """1 warm-up + up to `reps` repetitions within a time budget; returns (best seconds, repetitions done)"""
+    t0 = time.perf_counter()
+    for _ in range(warm):
+        fn()
+    first = time.perf_counter() - t0
+    times = []
+    while len(times) < reps and (not times or (time.perf_counter() - t0) + min(times) < budget_s):
+        t1 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t1)
+    return (min(times) if times else first), len(times), first
+
+
+def cpu_baseline(shape_name, Ms_full, C):
+    """The oracle timed on this host: dense unprojection and RMA on a BOUNDED sample (the work is uniform per view, per
+    channel and per image row, so the sample scales linearly; what was sampled is said in `sample`), the sparse network on
+    the FULL selected point set.  All host cores, 1 warm-up + up to 3 repetitions per leg inside a time budget."""
+    import torch
     from cnrma_amd import synth
     from oracle import rma_oracle as O
-    from oracle import sparse_oracle as SO
+    from oracle import sparse_torch as ST
     from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
     from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
-    cores = min(os.cpu_count() or 1, 16)      # bounded: the oracle's torch ops do not scale past a few cores
+    # torch's intra-op pool: all cores up to 64 -- on the 256-core host of the MI355X box 16 and 64 threads run the oracle's
+    # legs equally fast, 256 threads run them 60x SLOWER (oversubscribed barriers; scripts/cpu_threads_probe.py)
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
-    V_full = synth.SHAPES[shape_name][0]
-    sc = synth.make_scene(shape_name, seed=0, V=n_views)
+    V_full, C_full, H, W, dims, stride = synth.SHAPES[shape_name]
+    big = H * W * 300 > 5e7                  # NS: 92 M samples per view in the oracle's [rays, steps] arrays
+    n_views = 1 if big else 2
+    C_s = min(C_full, 32)                    # channels of the sample (the gather / store work is linear in C)
+    rows = H // 4 if big else H              # image rows of the RMA sample (one ray per pixel: linear in rows)
+    shape = (n_views, C_s, H, W, dims, stride)
+    sc = synth.make_scene(shape, seed=0)
     proj, feat, tsdf = sc["projection"][:, 0], sc["features"][:, 0], sc["tsdf"][0, 0]
-    t0 = time.time()
-    O.backproject_accum(sc["dims"], 0.04, sc["origin"], proj, feat, sc["stride"])
-    t_dense = time.time() - t0
-    t0 = time.time()
-    pts = O.aggregate_rma(proj, feat, tsdf, sc["dims"], 0.04, sc["origin"], sc["stride"])
-    t_rma = time.time() - t0
+    log(f"  dense leg: {n_views} view(s) x {C_s} channels")
+    t_dense, r_dense, _ = _timeit(lambda: [O.backproject_view(sc["dims"], 0.04, sc["origin"], O.scale_projection(proj[v], stride),
+                                                             feat[v]) for v in range(n_views)], reps=3, budget_s=12.0)
+    keep = {}
+    feat_r = feat[:, :, :rows].contiguous()  # the top `rows` image rows: ray (u, v) only depends on its own pixel
+
+    def rma_leg():
+        keep["pts"] = O.aggregate_rma(proj, feat_r, tsdf, sc["dims"], 0.04, sc["origin"], stride)
+    log(f"  RMA leg: {n_views} view(s) x {rows} of {H} rows")
+    t_rma, r_rma, _ = _timeit(rma_leg, reps=3, budget_s=20.0)
+    pts = keep["pts"]
     torch.manual_seed(0)
-    backbone = FCAF3DBackbone(feat.shape[1], 34).eval()
+    backbone = FCAF3DBackbone(C, 34).eval()
     head = FCAF3DHead(18, (64, 128, 256, 512), 128, 6, 0.01, 200000, None, test_cfg=dict(nms_pre=1000)).eval()
+    backbone.init_weights()
     head.init_weights()
-    sel = pts[torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(0))[:n_points].sort()[0]]
-    t0 = time.time()
-    Cq, Fq, _ = O.voxelize(sel[:, :3], sel[:, 3:], 0.01)
-    res = SO.head_forward(head, SO.backbone_forward(backbone, Cq.numpy(), Fq.numpy()))
-    SO.get_bboxes(head, res)
-    t_sparse = time.time() - t0
-    full_points = 500000
-    est = (t_dense + t_rma) * V_full / n_views + t_sparse * full_points / max(1, sel.shape[0])
+    # a full-size point set for the sparse leg: the sampled rows (randomly thinned, or repeated with a one-voxel offset
+    # per copy) with full-width random features -- its cost depends on the voxel structure, not on the feature values
+    if pts.shape[0] >= Ms_full:
+        pick = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(0))[:Ms_full].sort()[0]
+        xyz = pts[pick, :3]
+    else:
+        reps_needed = -(-Ms_full // pts.shape[0])
+        xyz = torch.cat([pts[:, :3] + torch.tensor([0.0, 0.0, 0.01 * r]) for r in range(reps_needed)])[:Ms_full]
+    f = torch.randn(xyz.shape[0], C, generator=torch.Generator().manual_seed(1))
+
+    def sparse_leg():
+        Cq, Fq, _ = O.voxelize(xyz, f, 0.01)
+        res = ST.head_forward(head, ST.backbone_forward(backbone, Cq.numpy(), Fq.numpy()))
+        ST.get_bboxes(head, res)
+    log(f"  sparse leg: {xyz.shape[0]} points x {C} channels")
+    t_sparse, r_sparse, _ = _timeit(sparse_leg, reps=3, budget_s=25.0)
+    dense_scene = t_dense / n_views * V_full * (C_full / C_s)
+    rma_scene = t_rma / n_views * V_full * (H / rows)
+    est = dense_scene + rma_scene + t_sparse
     return dict(value=1.0 / est, unit="scenes/s", cores=cores, kind="port",
-                sample=f"oracle (torch-CPU/numpy port of the reference algorithm): dense+RMA on {n_views} of {V_full} views "
-                       f"({t_dense:.2f}s+{t_rma:.2f}s, scaled x{V_full / n_views:.0f}) + voxelise/FCAF3D/decode on "
-                       f"{sel.shape[0]} of {full_points} points ({t_sparse:.2f}s, scaled x{full_points / max(1, sel.shape[0]):.0f})")
+                stage_s=dict(dense=dense_scene, rma=rma_scene, sparse=t_sparse),
+                sample=f"oracle/ (torch-CPU restatement of the reference, {cores} threads of {os.cpu_count()} host cores -- more "
+                       f"threads ran slower --, best of up to 3 reps after 1 warm-up): dense unprojection on {n_views} of {V_full} views x {C_s} of {C_full} channels "
+                       f"({t_dense:.2f} s, {r_dense} reps); RMA on {n_views} of {V_full} views x {rows} of {H} image rows "
+                       f"({t_rma:.2f} s, {r_rma} reps); both scaled linearly to the scene ({dense_scene:.1f} s + {rma_scene:.1f} s); "
+                       f"voxelise + FCAF3D + decode on a FULL {Ms_full}-point set ({t_sparse:.2f} s, {r_sparse} reps, fp32 port "
+                       f"oracle/sparse_torch.py)")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """>= n_scenes distinct synthetic scenes of one shape resident in HBM + `slots` captured scene graphs"""
+
+    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6):
+        import torch
+        from cnrma_amd import pipeline, synth
+        self.torch, self.pipeline = torch, pipeline
+        self.name, self.device, self.rank, self.world, self.args = name, device, rank, world, args
+        self.V, self.C, self.H, self.W, self.dims, self.stride = synth.SHAPES[name]
+        self.scenes = []
+        for i in range(args.scenes):
+            sc = synth.make_scene(name, seed=1000 * rank + i, boxes=2 + i % 4, device=device)
+            self.scenes.append(dict(features=sc["features"][:, 0].contiguous(), projection=sc["projection"][:, 0],
+                                    tsdf=sc["tsdf"][0, 0].to(device)))
+        self.input_bytes = sum(s["features"].numel() * 4 + s["tsdf"].numel() * 4 for s in self.scenes)
+        self.backbone, self.head = build_model(self.C, device, n_classes, n_reg)
+        self.cfg = pipeline.SceneConfig(self.dims, stride=self.stride, max_points=500000, sampler="device")
+        self.det_w = (6 if n_reg == 6 else 7) + n_classes
+        self.slots = []
+        self._k = 0
+
+    def build(self):
+        torch, pipeline = self.torch, self.pipeline
+        if self.args.eager:
+            return
+        first = pipeline.StaticScene(self.cfg, self.backbone, self.head, self.device)
+        for s in self.scenes:                                    # capacities cover every scene of the rotation
+            first.calibrate(s["features"], s["projection"], s["tsdf"])
+        s0 = self.scenes[0]
+        first.build(s0["features"], s0["projection"], s0["tsdf"])
+        self.slots = [first]
+        for _ in range(1, self.args.slots):
+            st = pipeline.StaticScene(self.cfg, self.backbone, self.head, self.device)
+            st.build(s0["features"], s0["projection"], s0["tsdf"], plan=first.plan)
+            self.slots.append(st)
+        self.bad = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in self.slots]
+        self.det = None
+
+    def alloc_step_buffers(self, sps):
+        torch = self.torch
+        self.sps = sps
+        if self.args.eager:
+            return
+        torch.cuda.synchronize()
+        n_det, n_lvl = self.slots[0].out["bboxes"].shape[0], self.slots[0].out["valid"].shape[0]     # padded rows, levels
+        self.det = torch.zeros((sps, n_det, self.det_w), dtype=torch.float32, device=self.device)
+        self.det_valid = torch.zeros((sps, n_lvl), dtype=torch.int32, device=self.device)
+        if self.world > 1:
+            self.det_all = torch.empty((self.world,) + tuple(self.det.shape), dtype=torch.float32, device=self.device)
+            self.valid_all = torch.empty((self.world, sps, n_lvl), dtype=torch.int32, device=self.device)
+
+    def step(self):
+        """one wave of sps scenes on this GPU (+ one all-gather of the detections when there are several ranks)"""
+        torch = self.torch
+        if self.args.eager:
+            for j in range(self.sps):
+                s = self.scenes[self._k % len(self.scenes)]
+                self._k += 1
+                self.last = self.pipeline.forward_scene(self.cfg, self.backbone, self.head, s["features"], s["projection"], s["tsdf"])
+            return
+        main = torch.cuda.current_stream()
+        for j in range(self.sps):
+            s = self.scenes[self._k % len(self.scenes)]
+            i = self._k % len(self.slots)
+            self._k += 1
+            st = self.slots[i]
+            out = st.run(s["features"], s["projection"], s["tsdf"])
+            with torch.cuda.stream(st.stream):                  # results leave the slot's static buffers in stream order
+                nb = out["bboxes"].shape[1]
+                self.det[j, :, :nb].copy_(out["bboxes"], non_blocking=True)
+                self.det[j, :, nb:].copy_(out["scores"], non_blocking=True)
+                self.det_valid[j].copy_(out["valid"], non_blocking=True)
+                self.bad[i] += out["status"]
+            self.last_out = out
+        if self.world > 1:
+            import torch.distributed as dist
+            for st in self.slots:
+                main.wait_stream(st.stream)
+            dist.all_gather_into_tensor(self.det_all, self.det)
+            dist.all_gather_into_tensor(self.valid_all, self.det_valid)
+            for st in self.slots:                               # the next wave overwrites det: after the collective
+                st.stream.wait_stream(main)
+
+    def violations(self):
+        if self.args.eager:
+            return 0
+        self.torch.cuda.synchronize()
+        return int(sum(int(b.item()) for b in self.bad))
+
+    def sizes(self):
+        if self.args.eager:
+            o = self.last
+            return dict(M_rows=o["M"], M_selected=o["M_selected"], M_unique=o["M_unique"], level_rows=o["level_rows"],
+                        head_rows=o["head_rows"])
+        _, _, info = self.pipeline.StaticScene.detections(self.last_out)
+        return dict(M_rows=info["M"], M_selected=info["M_selected"], M_unique=info["M_unique"], level_rows=info["level_rows"],
+                    head_rows=info["head_rows"])
+
+
+def time_windows(wl, args, world, barrier):
+    """warm-up, choice of scenes_per_step, then `windows` windows of exactly `steps` steps; returns per-window seconds"""
+    import torch
+    sps = args.scenes_per_step or max(2, len(wl.slots))
+    wl.alloc_step_buffers(sps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(max(1, args.warmup)):
+        wl.step()
+    barrier()
+    warm = (time.perf_counter() - t0) / max(1, args.warmup) / sps        # seconds per scene, warm-up estimate
+    if not args.scenes_per_step:
+        want = args.window_s / max(1, args.steps) / max(warm, 1e-6)
+        q = max(1, len(wl.slots))
+        sps = int(min(256, max(q, -(-int(want + 0.999) // q) * q)))
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([sps], dtype=torch.int64, device=wl.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sps = int(t.item())
+        wl.alloc_step_buffers(sps)
+        for _ in range(2):                                               # warm passes at the final wave size
+            wl.step()
+    barrier()
+    secs = []
+    for _ in range(max(1, args.windows)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device=wl.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        secs.append(dt)
+    return sps, secs
+
+
+def measure(name, device, rank, world, args, barrier, precision=None):
+    """build + time one workload; returns the result block"""
+    import torch
+    from cnrma_amd import sparse as S
+    prev = S.CONV_PRECISION
+    if precision:
+        S.CONV_PRECISION = precision
+    try:
+        log(f"workload {name}{' (' + precision + ' conv)' if precision else ''}: generating {args.scenes} scenes")
+        wl = Workload(name, device, rank, world, args)
+        log("calibrating + capturing the scene graphs")
+        wl.build()
+        log("timing")
+        c0 = os.times()
+        sps, secs = time_windows(wl, args, world, barrier)
+        c1 = os.times()
+        bad = wl.violations()
+        med = sorted(secs)[len(secs) // 2]
+        block = dict(value=world * args.steps * sps / med, ms_per_step=med / args.steps * 1e3, ms_per_scene=med / args.steps / sps * 1e3,
+                     scenes_per_step=sps, windows_scenes_per_s=[world * args.steps * sps / s for s in secs],
+                     window_s=med, plan_violations=bad, distinct_scenes=len(wl.scenes), input_GB=wl.input_bytes / 1e9,
+                     host_cpu_cores_busy=round(((c1.user - c0.user) + (c1.system - c0.system)) / max(sum(secs), 1e-9), 2))
+        block.update(wl.sizes())
+        log(f"{name}: {block['value']:.1f} scenes/s, {block['ms_per_scene']:.2f} ms/scene, windows "
+            f"{[round(x, 1) for x in block['windows_scenes_per_s']]}, {sps} scenes/step, violations {bad}")
+        return wl, block
+    finally:
+        S.CONV_PRECISION = prev
+
+
+def profile_block(wl, block, name):
+    """per-kernel times (HIP events, eager pass outside the timed region), conv layer table, roofline objects"""
+    import torch
+    from cnrma_amd import pipeline
+    prof = KernelProfile()
+    s = wl.scenes[0]
+    reps = 2
+    pipeline.forward_scene(wl.cfg, wl.backbone, wl.head, s["features"], s["projection"], s["tsdf"])     # warm
+    prof.install()
+    try:
+        for _ in range(reps):
+            pipeline.forward_scene(wl.cfg, wl.backbone, wl.head, s["features"], s["projection"], s["tsdf"])
+    finally:
+        prof.uninstall()
+    kern, layers = prof.summary(reps)
+    stage = pipeline.forward_scene(wl.cfg, wl.backbone, wl.head, s["features"], s["projection"], s["tsdf"], timing=True)["stage_ms"]
+    B = algorithmic_bytes(wl.V, wl.C, wl.H, wl.W, wl.dims, block["M_selected"], block["M_unique"], layers)
+    dense_ms = kern["cnrma_backproject_accum_f32"]["ms_per_scene"]
+    kern["cnrma_backproject_accum_f32"].update(algorithmic_GB=B["dense"] / 1e9, GBps=B["dense"] / 1e6 / dense_ms,
+                                               frac_hbm=B["dense"] / 1e6 / dense_ms / HBM_PEAK_GBS)
+    conv_ms = sum(L["ms"] for L in layers)
+    F_alg = sum(2.0 * L["pairs"] * L["Cin"] * L["Cout"] for L in layers)
+    F_dense = sum(2.0 * L["taps"] * L["n_out"] * L["Cin"] * L["Cout"] for L in layers)     # every tap of every output row
+    conv = dict(ms_per_scene=conv_ms, launches=len(layers), pairs=int(sum(L["pairs"] for L in layers)),
+                algorithmic_TFLOP=F_alg / 1e12, algorithmic_TFLOPps=F_alg / 1e9 / conv_ms,
+                occupancy_pairs_over_K_rows=F_alg / F_dense, algorithmic_GB=B["conv"] / 1e9,
+                frac_f16_mfma_peak_x3=3.0 * F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS,
+                frac_f32_mfma_peak=F_alg / 1e9 / conv_ms / MFMA_F32_PEAK_TFLOPS,
+                note="algorithmic = 2*pairs*Cin*Cout per layer (SURVEY 8d); the default f16x3 path spends 3 fp16 MFMA products "
+                     "per fp32 product, so the fp16-MFMA fraction is quoted on 3x the algorithmic flops")
+    block["kernels"] = kern
+    block["stage_ms"] = stage
+    block["conv"] = conv
+    block["conv_layers"] = [dict(K=L["K"], Cin=L["Cin"], Cout=L["Cout"], rows=L["n_out"], pairs=L["pairs"], ms=round(L["ms"], 4))
+                            for L in layers]
+    ms_scene = block["ms_per_scene"]
+    block["algorithmic_GB_per_scene"] = {k: v / 1e9 for k, v in B.items()}
+    block["whole_path_hbm"] = dict(GBps=B["scene"] / 1e6 / ms_scene, frac_of_8TBps=B["scene"] / 1e6 / ms_scene / HBM_PEAK_GBS,
+                                   frac_of_6p3TBps=B["scene"] / 1e6 / ms_scene / HBM_ACHIEVABLE_GBS)
+    # ---- roofline of the dominant kernel
+    times = {"dense": dense_ms, "conv": conv_ms, "march": kern.get("cnrma_rma_neus_march_f32", {}).get("ms_per_scene", 0.0),
+             "nhwc": kern.get("cnrma_nchw_to_nhwc_f32", {}).get("ms_per_scene", 0.0)}
+    dominant = max(times, key=times.get)
+    if dominant in ("dense", "nhwc", "march"):
+        # the march is cache-resident VALU work and the layout pass is not algorithmic traffic: the HBM-bound kernel the
+        # metric is about is the dense unprojection; report it (and say which kernel is actually the longest)
+        tr = PMC_TRAFFIC.get((name, "dense"))
+        roof = dict(kernel="backproject_accum kernel (cnrma_backproject_accum_f32)", bound="hbm", achieved=B["dense"] / 1e6 / dense_ms,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=B["dense"] / 1e6 / dense_ms / HBM_PEAK_GBS,
+                    traffic=tr[0] if tr else None, traffic_source=tr[1] if tr else None, launch_ms=dense_ms,
+                    algorithmic_bytes_per_launch=B["dense"], longest_kernel=dominant,
+                    note="algorithmic bytes = 4*V*C*H*W + 4*C*G + 4*G + 48*V (SURVEY 8d) / HIP-event launch time on the launch "
+                         "stream (eager pass outside the timed region)")
+    else:
+        tr = PMC_TRAFFIC.get((name, "conv"))
+        roof = dict(kernel="sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_f16x3), all launches of one scene",
+                    bound="mfma", achieved=3.0 * F_alg / 1e9 / conv_ms, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=3.0 * F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS, traffic=tr[0] if tr else None,
+                    traffic_source=tr[1] if tr else None, launch_ms=conv_ms / max(1, len(layers)),
+                    note="achieved = 3 x algorithmic flops (2*pairs*Cin*Cout; 3 fp16 products per fp32 product) / summed launch "
+                         f"time; fp32-equivalent {F_alg / 1e9 / conv_ms:.1f} TFLOP/s")
+    return roof
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -163,7 +519,7 @@ def main():
     backend = os.environ.get("CNRMA_BENCH_BACKEND", "nccl")
     if os.environ.get("CNRMA_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
-    from cnrma_amd import _lib, pipeline, rma, synth
+    from cnrma_amd import _lib
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -172,188 +528,66 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=device if backend == "nccl" else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    V, C, H, W, dims, stride = synth.SHAPES[args.workload]
-    sc = synth.make_scene(args.workload, seed=rank)
-    feat = sc["features"][:, 0].to(device)
-    proj = sc["projection"][:, 0]                       # host copy (tiny): the inverse is a host LAPACK call
-    tsdf = sc["tsdf"][0, 0].to(device)
-    backbone, head = build_model(C, device)
-    cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
-
-    scene_in = dict(features=feat, projection=proj, tsdf=tsdf)
-
-    def step():
-        out = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
-        dets = pipeline.gather_detections(out["bboxes"], out["scores"])
-        return out, dets
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n):
-        """n scenes; with --streams S > 1, S host threads each drive their own HIP stream so that the small
-        latency-bound kernels of one scene overlap the big kernels of another (scenes are independent).  The RCCL
-        all-gather of detections is issued by the main thread, in scene order, once the workers have joined
-        (collectives of one communicator must not be enqueued concurrently from several threads)."""
-        if args.streams <= 1 and args.batch <= 1:
-            o = None
-            for _ in range(n):
-                o, _ = step()
-            return o
-        import threading
-        dets = [None] * n
-        last = [None] * args.streams
-        errs = []
-
-        B = max(1, args.batch)
-        groups = [list(range(g, min(n, g + B))) for g in range(0, n, B)]       # scene ids per network pass
-
-        nxt = [0]
-        lock = threading.Lock()
-
-        def take():                          # dynamic hand-out: no worker is left with an extra pass at the end
-            with lock:
-                i = nxt[0]
-                nxt[0] += 1
-            return groups[i] if i < len(groups) else None
-
-        def worker(w):
-            try:
-                torch.cuda.set_device(local_rank)
-                with torch.cuda.stream(streams[w]):
-                    while True:
-                        g = take()
-                        if g is None:
-                            break
-                        if B == 1:
-                            outs = [pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)]
-                        else:
-                            outs = pipeline.forward_scenes(cfg, backbone, head, [scene_in] * len(g))
-                        for i, o in zip(g, outs):
-                            dets[i] = (o["bboxes"], o["scores"])
-                        last[w] = outs[-1]
-                    streams[w].synchronize()
-            except Exception as e:          # noqa: BLE001
-                errs.append(e)
-        ts = [threading.Thread(target=worker, args=(w,)) for w in range(args.streams)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        if errs:
-            raise errs[0]
-        if world > 1:
-            for b, sc_ in dets:
-                pipeline.gather_detections(b, sc_)
-        return next(o for o in last if o is not None)
-
-    args.streams = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=device) for _ in range(args.streams)] if (args.streams > 1 or args.batch > 1) else []
-    step()                                   # one sequential scene first: fills the weight / offset caches
-    torch.cuda.synchronize()
-    out = run_steps(max(args.warmup, args.streams * max(1, args.batch)))
-    barrier()
-    c0 = os.times()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    c1 = os.times()
-    host_cpu = ((c1.user - c0.user) + (c1.system - c0.system)) / dt      # cores kept busy by this rank's threads
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt
-
+    wl, main_block = measure(args.workload, device, rank, world, args, barrier)
+    V, C, H, W, dims, stride = wl.V, wl.C, wl.H, wl.W, wl.dims, wl.stride
     result = {
-        "metric": "scenes/sec fwd (40-view->192^3-class voxel grid): dense unprojection + RMA + voxelise + FCAF3D + decode",
-        "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "scenes/sec fwd (40-view->192^3 voxel): dense unprojection + RMA + voxelise + FCAF3D + decode",
+        "value": main_block["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": main_block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}), grid "
-                               f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000, "
-                               f"FCAF3D MinkResNet34 + head (18 classes), 1 scene per GPU per step "
-                               f"({max(1, args.batch)} scenes share one sparse-network pass, {args.streams} passes in flight)",
+        "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}, NCHW fp32 as the 2D "
+                               f"backbone writes them; the layout pass to channels-last is inside the timed path), grid "
+                               f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000 (device sampler: "
+                               f"a uniformly random subset like np.random.choice, other random stream), FCAF3D MinkResNet34 + "
+                               f"head (18 classes); {main_block['distinct_scenes']} distinct scenes per GPU rotated "
+                               f"({main_block['input_GB']:.1f} GB of inputs), one HIP graph per scene, {len(wl.slots) or 1} in flight",
+                   "step": f"{main_block['scenes_per_step']} scenes per GPU (value = n_gpus*steps*scenes_per_step / median window)",
                    "arithmetic": "geometry / aggregation / epilogues fp32 (bit-exact vs the reference's CPU path); sparse "
-                                 "convolutions: fp32 operands as two fp16 pieces under a per-tensor power-of-two scale, "
-                                 "hh+hm+mh on the fp16 MFMA with fp32 accumulation (error <= 3*2^-22 per product; outputs "
-                                 "within 2e-6 of the fp32 oracle)",
-                   "host_cpu_cores_busy": round(host_cpu, 2), "host_cores": os.cpu_count(),
-                   "scenes_in_flight": args.streams * max(1, args.batch), "scenes_per_network_pass": max(1, args.batch),
-                   "M_rows": out["M"], "M_selected": out["M_selected"], "M_unique": out["M_unique"],
-                   "level_rows": out["level_rows"], "head_rows": out["head_rows"]},
+                                 "convolutions f16x3: fp32 operands as two fp16 pieces under a per-tensor power-of-two scale, "
+                                 "hh+hm+mh on the fp16 MFMA with fp32 accumulation (error <= 3*2^-22 per product); block "
+                                 "`f32_conv` = the same run with exact-fp32 MFMA convolutions",
+                   "host_cores": os.cpu_count()},
     }
+    for k in ("scenes_per_step", "ms_per_scene", "windows_scenes_per_s", "window_s", "plan_violations", "host_cpu_cores_busy"):
+        result[k] = main_block[k]
+    for k in ("M_rows", "M_selected", "M_unique", "level_rows", "head_rows"):
+        result["config"][k] = main_block[k]
 
     if rank == 0 and not args.no_profile:
-        # ---- per-kernel durations (HIP events on the launch stream), outside the timed region
-        prof = KernelProfile()
-        prof.install()
-        reps = 3
-        for _ in range(reps):
-            out2 = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf, timing=False)
-        prof.uninstall()
-        agg = prof.summary()
-        kern = {k: dict(ms_per_scene=v["ms"] / reps, launches_per_scene=v["n"] / reps) for k, v in agg.items()}
-        dense_ms = agg["cnrma_backproject_accum_f32"]["ms"] / agg["cnrma_backproject_accum_f32"]["n"]
-        dense_bytes = algorithmic_bytes_dense(V, C, H, W, dims)
-        kern["cnrma_backproject_accum_f32"].update(algorithmic_GB=dense_bytes / 1e9,
-                                                   GBps=dense_bytes / 1e6 / dense_ms,
-                                                   frac_hbm=dense_bytes / 1e6 / dense_ms / HBM_PEAK_GBS)
-        for name, mult, peak in (("cnrma_sparse_conv_f32", 1.0, MFMA_F32_PEAK_TFLOPS),
-                                 ("cnrma_sparse_conv_bf16x6", 6.0, MFMA_BF16_PEAK_TFLOPS),
-                                 ("cnrma_sparse_conv_f16x3", 3.0, MFMA_BF16_PEAK_TFLOPS)):
-            if name in agg:
-                c = agg[name]
-                kern[name].update(fp32_equiv_TFLOP=c["flops"] / reps / 1e12, fp32_equiv_TFLOPps=c["flops"] / 1e9 / c["ms"],
-                                  executed_matrix_TFLOPps=mult * c["flops"] / 1e9 / c["ms"],
-                                  frac_mfma_peak=mult * c["flops"] / 1e9 / c["ms"] / peak)
-        dominant = max(kern, key=lambda k: kern[k]["ms_per_scene"])
-        if dominant == "cnrma_sparse_conv_f16x3":
-            c = agg[dominant]
-            ach = 3.0 * c["flops"] / 1e9 / c["ms"]
-            result["roofline"] = {"kernel": "sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_f16x3)", "bound": "mfma",
-                                  "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                                  "traffic": PMC_CONV_TRAFFIC_S["bytes_per_launch"] if args.workload == "S" else None,
-                                  "traffic_source": PMC_CONV_TRAFFIC_S["source"] if args.workload == "S" else None,
-                                  "note": "22-bit conv as 3 fp16 MFMA products per operand pair (2-way split under a "
-                                          "per-tensor power-of-two scale); achieved = executed fp16 matrix flops "
-                                          "(3 x 2*K*Cin*Cout*rows per launch) / launch time, averaged over the launches "
-                                          "of one scene; peak = dense fp16/bf16 MFMA 2.5 PFLOP/s; fp32-equivalent rate = "
-                                          f"{c['flops'] / 1e9 / c['ms']:.1f} TFLOP/s vs 157.3 fp32-MFMA peak"}
-        elif dominant == "cnrma_sparse_conv_bf16x6":
-            c = agg[dominant]
-            ach = 6.0 * c["flops"] / 1e9 / c["ms"]
-            result["roofline"] = {"kernel": "sparse_conv_bf16x6_kernel (cnrma_sparse_conv_bf16x6)", "bound": "mfma",
-                                  "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                                  "traffic": PMC_CONV_TRAFFIC_S_BF16X6["bytes_per_launch"] if args.workload == "S" else None,
-                                  "traffic_source": PMC_CONV_TRAFFIC_S_BF16X6["source"] if args.workload == "S" else None,
-                                  "note": "fp32-grade conv as 6 bf16 MFMA products per operand pair (3-way exact split); "
-                                          "achieved = executed bf16 matrix flops (6 x 2*K*Cin*Cout*rows per launch) / "
-                                          "launch time, averaged over the launches of one scene; fp32-equivalent rate = "
-                                          f"{c['flops'] / 1e9 / c['ms']:.1f} TFLOP/s vs 157.3 fp32-MFMA peak"}
-        elif dominant == "cnrma_sparse_conv_f32":
-            c = agg[dominant]
-            ach = c["flops"] / 1e9 / c["ms"]
-            result["roofline"] = {"kernel": "sparse_conv_mfma_kernel (cnrma_sparse_conv_f32)", "bound": "mfma",
-                                  "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                                  "note": "fp32 MFMA (v_mfma_f32_32x32x2_f32); flops = executed 2*K*Cin*Cout*rows per launch"}
-        else:
-            ach = dense_bytes / 1e6 / dense_ms
-            result["roofline"] = {"kernel": "backproject_accum_coop_kernel (cnrma_backproject_accum_f32)", "bound": "hbm",
-                                  "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": None}
-        result["kernels"] = kern
-        st = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf, timing=True)["stage_ms"]
-        result["stage_ms"] = st
+        log("per-kernel profile (eager pass)")
+        result["roofline"] = profile_block(wl, main_block, args.workload)
+        for k in ("kernels", "stage_ms", "conv", "conv_layers", "algorithmic_GB_per_scene", "whole_path_hbm"):
+            result[k] = main_block[k]
+    Ms_full = main_block["M_selected"]
+    del wl
+    torch.cuda.empty_cache()
+
+    if not args.no_secondary:
+        # ---- the same workload with exact-fp32 MFMA convolutions (every rank takes part: the windows hold collectives)
+        wl32, b32 = measure(args.workload, device, rank, world, args, barrier, precision="f32")
+        result["f32_conv"] = {k: b32[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step", "windows_scenes_per_s",
+                                                  "plan_violations")}
+        result["f32_conv"]["note"] = "CONV_PRECISION='f32': v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain"
+        del wl32
+        torch.cuda.empty_cache()
+        if args.workload != "S":
+            wls, bs = measure("S", device, rank, world, args, barrier)
+            if rank == 0 and not args.no_profile:
+                bs["roofline"] = profile_block(wls, bs, "S")
+            bs["workload"] = "S: ScanNet config shape, V=40, C=32, 120x160 maps (stride 4), grid 192x192x80 (BASELINE configs[1])"
+            result["S"] = bs
+            del wls
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.workload if args.workload in ("S", "St") else "tiny")
+        name = args.workload if args.workload in ("NS", "S", "St") else "tiny"
+        log("cpu baseline (oracle on the host cores)")
+        result["cpu_baseline"] = cpu_baseline(name, Ms_full, C)
+        log("done")
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -202,13 +202,29 @@ class StaticScene:
                    n_levels=len(levels))
         return out
 
-    def build(self, features_nchw, projections, tsdf, capture=True):
-        """calibrate on this scene (eager), then trace statically and capture.  Returns the eager result (for checks)."""
+    def calibrate(self, features_nchw, projections, tsdf):
+        """one eager forward under a recording plan; several calls (several scenes of the configuration) are merged:
+        capacities then cover the largest of them.  Returns the eager result."""
         _lib.require_gpu()
         with torch.cuda.stream(self.stream):
-            self.plan = P.Plan(self.margin)
-            with P.using(self.plan):
+            plan = P.Plan(self.margin)
+            with P.using(plan):
                 eager = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense)
+        self.plan = plan if self.plan is None else self.plan.merge(plan)
+        return eager
+
+    def build(self, features_nchw, projections, tsdf, capture=True, plan=None):
+        """calibrate on this scene (eager) unless calibrate() has been called or a finished `plan` of the same
+        configuration is handed in (its sizes/flags are copied), then trace statically and capture.
+        Returns the eager result of the calibration done here (None otherwise)."""
+        _lib.require_gpu()
+        eager = None
+        if plan is not None:
+            self.plan = P.Plan(self.margin)
+            self.plan.sizes, self.plan.flags = list(plan.sizes), list(plan.flags)
+        elif self.plan is None:
+            eager = self.calibrate(features_nchw, projections, tsdf)
+        with torch.cuda.stream(self.stream):
             self._alloc_inputs(features_nchw, tsdf)
             self._load(features_nchw, projections, tsdf)
             self.out = self._trace()                         # plain static run: creates the trace's constants

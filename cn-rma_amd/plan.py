@@ -70,6 +70,16 @@ class Plan:
         self.flags.append(bool(f))
         return bool(f)
 
+    def merge(self, other):
+        """fold another calibration run (another scene of the same configuration) into this plan: capacities cover the
+        larger of the two sizes; a branch the two scenes took differently becomes None = "take the variant that is
+        valid for both" (see next_flag callers)."""
+        assert not self.static and len(self.sizes) == len(other.sizes) and len(self.flags) == len(other.flags), \
+            "calibration runs of one configuration must record the same sequence"
+        self.sizes = [max(a, b) for a, b in zip(self.sizes, other.sizes)]
+        self.flags = [a if a == b else None for a, b in zip(self.flags, other.flags)]
+        return self
+
     # ---- static trace -------------------------------------------------------------------------------------------
     def begin_static(self):
         self.static = True

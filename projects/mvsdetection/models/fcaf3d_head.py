@@ -205,7 +205,7 @@ class FCAF3DHead(nn.Module):
         plan = P.current()
         if plan is not None and plan.static:
             # static trace (one scene): the branch of the calibration run, its premise registered as an assumption
-            if plan.next_flag():
+            if plan.next_flag():                     # True: no calibration scene needed pruning; None (scenes differ) -> prune
                 plan.watch(x.cs.n_dev, 0, self.pts_threshold)
                 return x
             with torch.no_grad():
@@ -341,14 +341,17 @@ class FCAF3DHead(nn.Module):
         for cen, box, cls, pts, cs in zip(centernesses, bbox_preds, cls_scores, points, coord_sets):
             cen, box, cls, pts, cs = cen[0], box[0], cls[0], pts[0], cs[0]
             cap, n_dev = cs.n, cs.n_dev
-            if plan.next_flag():
+            flag = plan.next_flag()
+            if flag or (flag is None and cap > nms_pre > 0):
+                # None: the calibration scenes disagreed -- the top-k form is valid on both sides (all live rows when
+                # there are fewer than nms_pre, then in score order instead of row order)
                 assert cap > nms_pre
-                plan.watch(n_dev, nms_pre + 1, cap)
+                plan.watch(n_dev, nms_pre + 1 if flag else 0, cap)
                 ms = S.max_scores(cls, cen)
                 live = torch.arange(cap, device=ms.device, dtype=torch.int32) < n_dev
                 ids = torch.where(live, ms, torch.full_like(ms, float("-inf"))).topk(nms_pre)[1]
                 k = nms_pre
-                valid.append(plan.const(lambda: torch.full((1,), nms_pre, dtype=torch.int32, device=ms.device)))
+                valid.append(torch.clamp(n_dev.view(1), max=nms_pre).to(torch.int32))
             else:
                 plan.watch(n_dev, 0, min(cap, nms_pre) if nms_pre > 0 else cap)
                 ids, k = None, cap

@@ -145,3 +145,40 @@ def test_compute_centerness_matches_reference_golden():
     from projects.mvsdetection.models.fcaf3d_head import compute_centerness
     z = np.load(os.path.join(GOLDEN, "decode.npz"))
     assert torch.equal(compute_centerness(torch.from_numpy(z["centerness_in"])), torch.from_numpy(z["centerness_out"]))
+
+
+def test_fp32_torch_port_matches_the_fp64_oracle():
+    """oracle/sparse_torch.py (the multi-threaded fp32 restatement timed as bench.py's cpu_baseline) against the fp64
+    numpy oracle on a random surface-like point set: every level's coordinate set identical, head outputs close"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import sparse_torch as ST
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
+    rng = np.random.RandomState(0)
+    n = 4000
+    uv = rng.randint(0, 160, size=(n, 2))
+    z = (40 + 8 * np.sin(uv[:, 0] / 17.0) + rng.randint(0, 3, size=n)).astype(np.int64)
+    coords = np.unique(np.concatenate((np.zeros((n, 1), dtype=np.int64), uv, z[:, None]), axis=1), axis=0)
+    feats = rng.randn(len(coords), 8).astype(np.float32)
+    torch.manual_seed(0)
+    backbone = FCAF3DBackbone(8, 34).eval()
+    head = FCAF3DHead(18, (64, 128, 256, 512), 128, 6, 0.01, 300, None, test_cfg=dict(nms_pre=50)).eval()
+    backbone.init_weights()
+    head.init_weights()
+    lv64 = SO.backbone_forward(backbone, coords, feats)
+    lv32 = ST.backbone_forward(backbone, coords, feats)
+    for (c64, f64, _), (cs32, f32) in zip(lv64, lv32):
+        assert np.array_equal(c64, cs32.C.numpy())
+        np.testing.assert_allclose(f32.numpy(), f64, rtol=2e-3, atol=2e-3)
+    r64 = SO.head_forward(head, lv64)
+    r32 = ST.head_forward(head, lv32)
+    for a, b in zip(r64, r32):
+        assert a["coords"].shape == tuple(b["coords"].shape)
+        ka = np.lexsort(a["coords"].T[::-1])
+        kb = np.lexsort(b["coords"].numpy().T[::-1])
+        same = (a["coords"][ka] == b["coords"].numpy()[kb]).all(axis=1)
+        assert same.mean() > 0.99              # ties at the pruning threshold may differ
+        np.testing.assert_allclose(b["cls_score"].numpy()[kb][same], a["cls_score"][ka][same], rtol=5e-3, atol=5e-3)
+    b32, s32 = ST.get_bboxes(head, r32)
+    assert torch.isfinite(b32).all() and torch.isfinite(s32).all()
