@@ -195,6 +195,87 @@ __global__ __launch_bounds__(256) void neus_count_kernel(MarchParams p, const fl
   wsum[r] = ws;
 }
 
+// ---- production march (single pass, kept-sample records) -----------------------------------------------------
+// Same arithmetic as neus_march() above, organised for throughput (the reference path marches 12.3 M rays per scene at the
+// north-star shape):
+//  * sigmoid(-tsdf) comes from a per-voxel table built once per scene (cnrma_rma_sigmoid_table_f32: the SAME function
+//    of the SAME value, so the weights are bit-identical) -- removes the exp and one division from every step;
+//  * the three divisions by the voxel size use the correctly rounded reciprocal y = fl(1 / vs) and the quotient
+//    refinement q = a*y; r = fma(-vs, q, a); q = fma(r, y, q); r = fma(-vs, q, a); q = fma(r, y, q) -- the core of the
+//    IEEE division expansion without its reciprocal refinement and range scaling (5 instead of 11 instructions; equal to
+//    a / vs for every sample: tests/test_rma_gpu.py::test_division_by_voxel_size_is_exact and the golden vectors);
+//  * the table value of step n + 2 is fetched while step n is evaluated (the address only depends on n).
+__device__ __forceinline__ float div_by_vs(float a, float vs, float y) {
+  float q = a * y;
+  float r = fmaf(-vs, q, a);
+  q = fmaf(r, y, q);
+  r = fmaf(-vs, q, a);
+  return fmaf(r, y, q);
+}
+
+struct TabSample { float s; bool valid; };
+
+__device__ __forceinline__ TabSample fetch_step(const Ray& r, int n, const MarchParams& p, float inv_vs,
+                                                const float* __restrict__ tab, float s_out) {
+  const float t = (float)n * p.t_one;
+  const float x = r.ox + r.dx * t, y = r.oy + r.dy * t, z = r.oz + r.dz * t;
+  const float fx = rintf(div_by_vs(x - p.ox, p.vs, inv_vs));
+  const float fy = rintf(div_by_vs(y - p.oy, p.vs, inv_vs));
+  const float fz = rintf(div_by_vs(z - p.oz, p.vs, inv_vs));
+  TabSample o;
+  o.valid = (fx >= 0.0f) && (fx < (float)p.X) && (fy >= 0.0f) && (fy < (float)p.Y) && (fz >= 0.0f) && (fz < (float)p.Z);
+  o.s = s_out;
+  if (o.valid) o.s = tab[((int)fx * p.Y + (int)fy) * p.Z + (int)fz];      // X*Y*Z < 2^31 (checked by the entry point)
+  return o;
+}
+
+__global__ __launch_bounds__(256) void neus_march_kernel(MarchParams p, const float* __restrict__ proj_inv,
+                                                         const float* __restrict__ tab, int32_t* __restrict__ count,
+                                                         double* __restrict__ wsum, int2* __restrict__ kept, int cap,
+                                                         int32_t* __restrict__ overflow) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Ray ray; int view, pix;
+  if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
+  const float s_out = sigmoid_neg(1.0f);
+  const float inv_vs = 1.0f / p.vs;
+  int c = 0;
+  double ws = 0.0;
+  int2* mine = kept + r * cap;
+  int a, b;
+  if (clip_steps(ray, p, &a, &b)) {
+    double acc = 1.0;
+    TabSample cur = fetch_step(ray, a, p, inv_vs, tab, s_out);
+    TabSample n1 = cur, n2 = cur;                       // samples a+1, a+2 (only used when inside [a, b])
+    if (a + 1 <= b) n1 = fetch_step(ray, a + 1, p, inv_vs, tab, s_out);
+    for (int n = a; n <= b; ++n) {
+      if (n + 2 <= b) n2 = fetch_step(ray, n + 2, p, inv_vs, tab, s_out);     // in flight during this step
+      float s_next;
+      if (n + 1 <= b) s_next = n1.s;
+      else s_next = (n + 1 <= p.N - 1) ? s_out : cur.s;                        // beyond the clip: outside / :758 repeat
+      const float alpha = fmaxf((cur.s - s_next) / cur.s, 0.0f);              // :759
+      const float T = (float)acc;                                              // :760-762
+      const float w = T * alpha;                                               // :763
+      if (cur.valid && w >= p.thr) {                                           // :765-767
+        if (c < cap) mine[c] = make_int2(__float_as_int(w), n);
+        else atomicAdd(overflow, 1);
+        ++c;
+        ws += (double)w;
+      }
+      acc *= (double)(1.0f - alpha);
+      if ((float)acc < p.thr) break;
+      cur = n1;
+      n1 = n2;
+    }
+  }
+  count[r] = c;
+  wsum[r] = ws;
+}
+
+__global__ __launch_bounds__(256) void sigmoid_table_kernel(const float* __restrict__ tsdf, int64_t n, float* __restrict__ tab) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    tab[i] = sigmoid_neg(tsdf[i]);
+}
+
 // Emission from the kept-sample records, two small kernels:
 //  (1) one lane per ray copies the records of its SELECTED samples to their output position: rec[j] = {ray, step, w};
 //  (2) LPR lanes per OUTPUT row j rebuild the place (o + d*t with the march's arithmetic) and copy the pixel's
@@ -438,17 +519,51 @@ extern "C" int cnrma_rma_neus_count_f32(const float* proj_inv, const float* tsdf
   return 0;
 }
 
-extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y,
-                                        int Z, float voxel_size, float ox, float oy, float oz, int n_steps,
-                                        float t_one, float thr, int32_t* count, double* wsum, void* kept, int cap,
-                                        int32_t* overflow, void* stream) {
+// parity aid: q_fast[i] = div_by_vs(a[i]) next to q_ref[i] = a[i] / vs (the compiler's IEEE expansion)
+__global__ __launch_bounds__(256) void div_check_kernel(const float* __restrict__ a, int64_t n, float vs,
+                                                        float* __restrict__ q_fast, float* __restrict__ q_ref) {
+  const float y = 1.0f / vs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    q_fast[i] = div_by_vs(a[i], vs, y);
+    q_ref[i] = a[i] / vs;
+  }
+}
+
+extern "C" int cnrma_debug_div_by_voxel_size_f32(const float* a, int64_t n, float voxel_size, float* q_fast, float* q_ref,
+                                                 void* stream) {
+  if (n <= 0 || !(voxel_size > 0.0f)) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(div_check_kernel, dim3(4096), dim3(256), 0, as_stream(stream), a, n, voxel_size, q_fast, q_ref);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* table, void* stream) {
+  if (n <= 0 || tsdf == nullptr || table == nullptr) return CNRMA_EINVAL;
+  int64_t blocks = ceil_div(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sigmoid_table_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tsdf, n, table);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const float* sig_table, int V, int H,
+                                        int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                        int n_steps, float t_one, float thr, int32_t* count, double* wsum, void* kept,
+                                        int cap, int32_t* overflow, void* stream) {
   if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr) return CNRMA_EINVAL;
+  if (tsdf == nullptr && sig_table == nullptr) return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
   int64_t R = (int64_t)V * H * W;
   hipError_t e = cnrma_fill_bytes(overflow, 0, sizeof(int32_t), as_stream(stream));
   if (e != hipSuccess) return -(int)e;
-  hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
-                     proj_inv, tsdf, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
+  if (sig_table != nullptr && (int64_t)X * Y * Z < ((int64_t)1 << 31)) {
+    hipLaunchKernelGGL(neus_march_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p, proj_inv,
+                       sig_table, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
+  } else {
+    if (tsdf == nullptr) return CNRMA_EINVAL;
+    hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
+                       proj_inv, tsdf, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
+  }
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

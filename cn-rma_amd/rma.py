@@ -20,6 +20,9 @@ from . import plan as P
 from ._lib import call, ptr, stream
 
 
+SIGMOID_TABLE = True     # production march: table-driven kernel (False: the per-step sigmoid kernel, kept for A/B runs)
+
+
 def _f32(t):
     return t.contiguous().to(torch.float32)
 
@@ -174,8 +177,13 @@ class _March:
         kept = torch.empty((self.R, cap, 2), dtype=torch.int32, device=self.dev)
         overflow = torch.empty(1, dtype=torch.int32, device=self.dev)
         self._overflow = overflow
-        call("cnrma_rma_neus_march_f32", ptr(self.pinv), ptr(self.tsdf), self.V, self.H, self.W, self.X, self.Y, self.Z,
-             self.vs, *self.org, self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow), stream())
+        tab = None
+        if SIGMOID_TABLE:        # sigmoid(-tsdf) once per voxel instead of once per marched step (bit-identical)
+            tab = torch.empty_like(self.tsdf)
+            call("cnrma_rma_sigmoid_table_f32", ptr(self.tsdf), self.tsdf.numel(), ptr(tab), stream())
+        call("cnrma_rma_neus_march_f32", ptr(self.pinv), ptr(self.tsdf), ptr(tab), self.V, self.H, self.W, self.X, self.Y,
+             self.Z, self.vs, *self.org, self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow),
+             stream())
         return cnt, wsum, kept, overflow
 
     def emit_rows(self, row_offset, n_out, kept, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat,

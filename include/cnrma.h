@@ -107,9 +107,16 @@ int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const floa
  * their output position (records: scratch of 16 bytes x n_out), then one 8-lane group per OUTPUT row (n_out of them)
  * writes the row -- nothing is re-marched.
  * Same destination description and arithmetic (place = o + d * (n * t_one)) as cnrma_rma_neus_emit_f32. */
-int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, int V, int H, int W, int X, int Y, int Z,
-                             float voxel_size, float ox, float oy, float oz, int n_steps, float t_one, float thr,
-                             int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow, void* stream);
+/* sig_table (may be NULL): table[voxel] = sigmoid(-tsdf[voxel]) with the reference's CPU arithmetic, built once per scene by
+ * cnrma_rma_sigmoid_table_f32 -- the march then reads it instead of evaluating the sigmoid at every step (same function of
+ * the same value: bit-identical weights).  With sig_table == NULL the TSDF is read and the sigmoid evaluated per step. */
+int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* table, void* stream);
+/* parity aid: the march's division by the voxel size (reciprocal + two quotient refinements) next to the IEEE division */
+int cnrma_debug_div_by_voxel_size_f32(const float* a, int64_t n, float voxel_size, float* q_fast, float* q_ref, void* stream);
+int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const float* sig_table, int V, int H, int W, int X,
+                             int Y, int Z, float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
+                             float thr, int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow,
+                             void* stream);
 
 /* Backward of cnrma_rma_neus_emit_rows_f32 w.r.t. the feature maps (training; the weights carry no
  * gradient: the reference computes them under torch.no_grad(), ray_marching.py:705).

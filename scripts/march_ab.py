@@ -1,0 +1,25 @@
+"""A/B of the march kernels (per-step sigmoid vs table-driven) at a workload shape: HIP-event times, interleaved"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cnrma_amd import rma, synth
+wl = sys.argv[1] if len(sys.argv) > 1 else "NS"
+dev = torch.device("cuda:0")
+V, C, H, W, dims, stride = synth.SHAPES[wl]
+sc = synth.make_scene((V, 8, H, W, dims, stride), seed=0, boxes=3)
+feat = rma.to_nhwc(sc["features"][:, 0].to(dev))
+pinv = rma.projection_inverse(sc["projection"][:, 0], stride).to(dev)
+tsdf = sc["tsdf"][0, 0].to(dev)
+m = rma._March(feat, pinv, tsdf, dims, 0.04, (0, 0, 0), 300, 0.05, "neus", 0)
+res = {}
+for rep in range(4):
+    for mode in (False, True):
+        rma.SIGMOID_TABLE = mode
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); out = m.march(); b.record(); torch.cuda.synchronize()
+        res.setdefault(mode, []).append(a.elapsed_time(b))
+        res[("out", mode)] = out
+print(wl, "per-step sigmoid kernel ms:", [round(x, 3) for x in res[False]])
+print(wl, "table kernel (+table build) ms:", [round(x, 3) for x in res[True]])
+c0, w0, k0, _ = res[("out", False)]; c1, w1, k1, _ = res[("out", True)]
+print("counts equal", torch.equal(c0, c1), "wsum equal", torch.equal(w0, w1), "rays", c0.numel(), "kept", int(c0.sum()))

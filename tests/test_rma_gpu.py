@@ -305,3 +305,21 @@ def test_dense_unprojection_backward_vs_oracle_autograd(device):
     (v2 * g.to(device)).sum().backward()
     ref = f_cpu.grad.numpy()
     np.testing.assert_allclose(f_gpu.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("vs", [0.04, 0.01, 0.05, 0.0625, 0.037, 1.0 / 3.0])
+def test_division_by_voxel_size_is_exact(device, vs):
+    """the march divides by the voxel size with the correctly rounded reciprocal and two quotient refinements instead of
+    the full IEEE expansion: the quotients must be bit-identical for every coordinate the march can produce"""
+    from cnrma_amd import _lib
+    from cnrma_amd._lib import call, ptr, stream
+    g = torch.Generator(device=device).manual_seed(int(vs * 1e6))
+    n = 1 << 25
+    parts = [(torch.rand(n // 4, generator=g, device=device) - 0.3) * 30.0,            # coordinates of a room-sized grid
+             (torch.rand(n // 4, generator=g, device=device) - 0.5) * 1e-3,            # around the origin
+             torch.randn(n // 4, generator=g, device=device) * 1e3,                    # far outside
+             (torch.randint(-4000, 4000, (n // 4,), generator=g, device=device).float() + 0.5) * vs]   # near rounding ties
+    a = torch.cat(parts).contiguous()
+    qf, qr = torch.empty_like(a), torch.empty_like(a)
+    call("cnrma_debug_div_by_voxel_size_f32", ptr(a), a.numel(), float(vs), ptr(qf), ptr(qr), stream())
+    assert torch.equal(qf.view(torch.int32), qr.view(torch.int32))
