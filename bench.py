@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="NS", help="NS = north-star shape (default); S = ScanNet config; St; tiny")
-    ap.add_argument("--slots", type=int, default=2, help="scene graphs in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--slots", type=int, default=3, help="scene graphs in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--scenes", type=int, default=8, help="distinct scenes rotated per GPU")
     ap.add_argument("--scenes-per-step", type=int, default=0, help="0 = chosen from the warm-up (see --window-s)")
     ap.add_argument("--window-s", type=float, default=2.0, help="minimum length of one timed window of K steps")

@@ -11,6 +11,8 @@
 // sum in view order; mean = sum / (float)count.  Compiled with -ffp-contract=off.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct DenseParams {
@@ -97,15 +99,23 @@ template <int LPV>
 __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams p, const float* __restrict__ feat,
                                                                      const float* __restrict__ proj,
                                                                      float* __restrict__ volume,
-                                                                     int32_t* __restrict__ count) {
+                                                                     int32_t* __restrict__ count, int chunk_blocks) {
   constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   const int lane = threadIdx.x & 63;
-  // NOTE (measured): giving every XCD one contiguous x-slab of the grid (chunk = (b % 8) * nb/8 + b / 8) cuts the
-  // HBM fetch (each private L2 then holds only its image band) but runs 17 % SLOWER: the frustum makes slabs unequal
-  // and the static map cannot rebalance.  The round-robin interleave below keeps the XCDs evenly loaded; the kernel
-  // is bound by the L1 gather path, not by HBM.
-  const int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+  // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group), each with a
+  // private L2.  A pixel's channel vector is re-read by the ~9 voxels along its ray; with consecutive blocks on
+  // different XCDs every one of those reads misses its L2 (profiles/r02: 22 % hit rate, 80 GB over the fabric per launch
+  // at the north-star shape against 20 GB of compulsory traffic).  Here an XCD group owns whole chunks of `chunk_blocks`
+  // consecutive blocks (one x-plane of the grid) -- chunks c, c + 8, c + 16, ... --, so rays that run inside a plane find
+  // their pixels in the group's L2; the chunks stay interleaved over the whole grid, which keeps the groups evenly
+  // loaded (8 contiguous slabs, one per XCD, measured 17 % slower: the frustum makes slabs unequal).
+  int64_t lb = blockIdx.x;
+  if (chunk_blocks > 0) {
+    const int64_t grp = blockIdx.x & 7, k = blockIdx.x >> 3;
+    lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
+  }
+  const int64_t wave_base = (lb * blockDim.x + threadIdx.x) - lane;
   if (wave_base >= G) return;
   const int64_t g = wave_base + lane;
   const int c0 = blockIdx.y * (4 * LPV);
@@ -158,8 +168,17 @@ template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
                       hipStream_t st) {
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  dim3 grid((unsigned)ceil_div(G, 256), (unsigned)ceil_div(p.C, 4 * LPV));
-  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count);
+  const int64_t nb = ceil_div(G, 256);
+  // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
+  int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
+  if (cb < 32) cb = 32;
+  const char* env = getenv("CNRMA_DENSE_CHUNK");           // tuning / A-B aid: 0 = plain round-robin order
+  if (env != nullptr) cb = atoll(env);
+  int64_t gx = nb;
+  if (cb > 0 && nb >= 16 * cb) gx = ceil_div(ceil_div(nb, cb), 8) * 8 * cb;      // whole chunks for every XCD group
+  else cb = 0;
+  dim3 grid((unsigned)gx, (unsigned)ceil_div(p.C, 4 * LPV));
+  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -197,6 +216,13 @@ extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* 
   if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
   DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
   hipStream_t st = as_stream(stream);
+  const char* lpv = getenv("CNRMA_DENSE_LPV");             // tuning / A-B aid: lanes (x 4 channels) per voxel and sweep
+  if (lpv != nullptr) {
+    const int l = atoi(lpv);
+    if (l == 16 && C % 64 == 0) return launch_accum_coop<16>(p, feat_nhwc, proj, volume, count, st);
+    if (l == 32 && C % 128 == 0) return launch_accum_coop<32>(p, feat_nhwc, proj, volume, count, st);
+    if (l == 4 && C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, st);
+  }
   if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, st);
   if (C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, st);
   if (C % 8 == 0) return launch_accum_coop<2>(p, feat_nhwc, proj, volume, count, st);

@@ -29,19 +29,24 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_sums(const T* __restrict
   if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
 }
 
-// phase B: one block scans the tile sums in place (exclusive), writes the grand total to tile_sum[n_tiles]
+// phase B: one block scans the tile sums in place (exclusive), writes the grand total to tile_sum[n_tiles].
+// Every thread owns a contiguous run of ceil(n_tiles / 1024) sums: ONE block-wide scan (three barriers) whatever the
+// length -- the former loop of 1024-wide scans took 41 rounds of barriers at the north-star shape (87 M rows).
 __global__ __launch_bounds__(1024) void scan_tile_offsets(int32_t* __restrict__ tile_sum, int64_t n_tiles) {
   __shared__ int smem[1024 / 64 + 1];
-  int carry = 0;
-  for (int64_t base = 0; base < n_tiles; base += 1024) {
-    int64_t i = base + threadIdx.x;
-    int v = i < n_tiles ? tile_sum[i] : 0;
-    int total;
-    int ex = block_excl_scan<1024>(v, smem, &total);
-    if (i < n_tiles) tile_sum[i] = ex + carry;
-    carry += total;
+  const int64_t per = (n_tiles + 1023) / 1024;
+  const int64_t lo = (int64_t)threadIdx.x * per;
+  const int64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+  int s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += tile_sum[i];
+  int total;
+  int run = block_excl_scan<1024>(s, smem, &total);
+  for (int64_t i = lo; i < hi; ++i) {
+    const int v = tile_sum[i];
+    tile_sum[i] = run;
+    run += v;
   }
-  if (threadIdx.x == 0) tile_sum[n_tiles] = carry;
+  if (threadIdx.x == 0) tile_sum[n_tiles] = total;
 }
 
 // phase C: rescan each tile with its offset.  MODE 0: out[i] = exclusive sum (and out[n] = total);

@@ -43,15 +43,16 @@ def room_tsdf(dims, voxel_size=0.04, boxes=0, seed=0):
     return torch.from_numpy(tsdf).view(1, 1, X, Y, Z)
 
 
-def camera_projections(V, dims, voxel_size=0.04, img_hw=(480, 640)):
-    """V x 3 x 4 fp32 projection matrices K @ [R|t] in full-resolution pixel units."""
+def camera_projections(V, dims, voxel_size=0.04, img_hw=(480, 640), return_parts=False):
+    """V x 3 x 4 fp32 projection matrices K @ [R|t] in full-resolution pixel units (return_parts: also the intrinsics
+    K [3,3] and the camera -> world poses [V,4,4] they are made of)."""
     X, Y, Z = dims
     ext = np.array([X, Y, Z], dtype=np.float64) * voxel_size
     centre = ext / 2
     H, W = img_hw
     f = 577.0 * W / 1296.0
     K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
-    out = []
+    out, poses = [], []
     for i in range(V):
         a = 2 * math.pi * i / V
         eye = centre + np.array([1.2 * math.cos(a), 1.2 * math.sin(a), 0.2])
@@ -65,7 +66,11 @@ def camera_projections(V, dims, voxel_size=0.04, img_hw=(480, 640)):
         R = np.stack([right, down, fwd])            # world -> camera (x right, y down, z forward)
         t = -R @ eye
         out.append(K @ np.concatenate([R, t[:, None]], axis=1))
-    return torch.from_numpy(np.stack(out).astype(np.float32))
+        pose = np.eye(4)
+        pose[:3, :3], pose[:3, 3] = R.T, eye                  # camera -> world
+        poses.append(pose)
+    proj = torch.from_numpy(np.stack(out).astype(np.float32))
+    return (proj, K, np.stack(poses)) if return_parts else proj
 
 
 def make_scene(shape="S", seed=0, boxes=0, V=None, device=None):
@@ -84,3 +89,47 @@ def make_scene(shape="S", seed=0, boxes=0, V=None, device=None):
     tsdf = room_tsdf(dims, boxes=boxes, seed=seed)
     return dict(features=feats, projection=proj, tsdf=tsdf, dims=tuple(dims), voxel_size=0.04,
                 origin=(0.0, 0.0, 0.0), stride=stride)
+
+
+def write_scannet_like(root, n_scenes=2, V=6, dims=(48, 48, 24), img_hw=(120, 160), seed=0, boxes=2):
+    """A tiny dataset in the directory layout AtlasScanNetDataset reads (datasets/scannet_dataset.py): random JPEG frames
+    with the poses / intrinsics of camera_projections(), the room TSDF at 4 / 8 / 16 cm, an info pickle with two
+    ground-truth boxes per scene.  World frame = the TSDF volume shifted by a per-scene origin, identity axis alignment.
+    Returns the path of the info file."""
+    import os
+    import pickle
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    infos = []
+    for s in range(n_scenes):
+        scene = f"scene{s:04d}_00"
+        origin = np.array([0.2 * s - 0.4, 0.3, -0.1], dtype=np.float32)
+        frames = os.path.join(root, "posed_images", scene)
+        os.makedirs(frames, exist_ok=True)
+        _, K, poses = camera_projections(V, dims, img_hw=img_hw, return_parts=True)
+        K4 = np.eye(4)
+        K4[:3, :3] = K
+        np.savetxt(os.path.join(frames, "intrinsic.txt"), K4)
+        for v in range(V):
+            img = (rng.rand(img_hw[0], img_hw[1], 3) * 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(frames, f"{v:05d}.jpg"), quality=95)
+            pose = poses[v].copy()
+            pose[:3, 3] += origin
+            np.savetxt(os.path.join(frames, f"{v:05d}.txt"), pose)
+        vol_dir = os.path.join(root, "atlas_tsdf", scene)
+        os.makedirs(vol_dir, exist_ok=True)
+        full = room_tsdf(dims, boxes=boxes, seed=seed + s)[0, 0]
+        for level, cm in enumerate((4, 8, 16)):
+            vol = full if level == 0 else torch.nn.functional.avg_pool3d(full[None, None], 2 ** level)[0, 0]
+            np.savez(os.path.join(vol_dir, f"tsdf_{cm:02d}.npz"), origin=origin, tsdf=vol.numpy())
+        ext = np.array(dims, dtype=np.float32) * 0.04
+        gt = np.array([[0.35 * ext[0], 0.4 * ext[1], 0.3 * ext[2], 0.5, 0.4, 0.5],
+                       [0.65 * ext[0], 0.6 * ext[1], 0.35 * ext[2], 0.4, 0.6, 0.4]], dtype=np.float32)
+        gt[:, :3] += origin
+        infos.append(dict(scene=scene, total_image_ids=list(range(V)),
+                          annos=dict(gt_num=2, gt_boxes_upright_depth=gt, **{"class": np.array([1, 3])},
+                                     axis_align_matrix=np.eye(4))))
+    ann = os.path.join(root, "scannet_infos_val.pkl")
+    with open(ann, "wb") as f:
+        pickle.dump(infos, f)
+    return ann

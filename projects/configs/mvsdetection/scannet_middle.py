@@ -1,4 +1,5 @@
-"""ScanNet, stage 3: joint fine-tuning / inference of CN-RMA (reference: ray_marching_scannet.py)."""
+"""ScanNet, stage 2 data dump: with a trained reconstruction network, run the ray-marching aggregation over the TRAIN
+scenes and save every scene's aggregated points ({scene}_vert.npy) for pre-training FCAF3D (reference: scannet_middle.py)."""
 import os
 import sys
 
@@ -15,18 +16,20 @@ NUM_FRAMES_TRAIN, NUM_FRAMES_TEST = 40, 50
 USE_BATCHNORM_TRAIN, USE_BATCHNORM_TEST = True, False
 LOSS_WEIGHT_RECON, LOSS_WEIGHT_DETECTION = 0.5, 1.0
 RAY_MARCHING_TYPE, NEUS_THRESHOLD, DEPTH_POINTS = 'neus', 0.05, None
+MIDDLE_SAVE_PATH = './data/scannet/atlas_middle_data'
+MIDDLE_VISUALIZE_PATH = None
 
-work_dir = './work_dirs/ray_marching_scannet'
-R50_path = None                       # ImageNet ResNet-50 in Detectron2 layout (R-50.pth) when training from scratch
+work_dir = './work_dirs/scannet_middle'
+R50_path = None
 save_path = work_dir + '/results'
-load_from = None                      # e.g. the released ray_marching_neus_300_005.pth
+load_from = None                      # the stage-1 checkpoint (atlas_recon_scannet)
 globals().update(B.schedule(total_epochs=120, lr_steps=[80, 110], work_dir=work_dir))
 
 train_pipeline, test_pipeline = B.detection_pipelines(VOXEL_DIM_TRAIN, VOXEL_DIM_TEST, test_mode='origin')
 data = B.data_cfg('AtlasScanNetDataset', './data/scannet', 'scannet', class_names, train_pipeline, test_pipeline,
-                  NUM_FRAMES_TRAIN, NUM_FRAMES_TEST)
+                  NUM_FRAMES_TRAIN, NUM_FRAMES_TEST, test_split='train')
 model = B.detection_model(n_classes=classes, n_reg_outs=6, with_yaw=False, voxel_dim_train=VOXEL_DIM_TRAIN,
                           voxel_dim_test=VOXEL_DIM_TEST, use_batchnorm_test=USE_BATCHNORM_TEST, save_path=save_path,
                           r50_path=R50_path, ray_marching_type=RAY_MARCHING_TYPE, neus_threshold=NEUS_THRESHOLD,
-                          depth_points=DEPTH_POINTS, loss_weight_recon=LOSS_WEIGHT_RECON,
-                          loss_weight_detection=LOSS_WEIGHT_DETECTION)
+                          depth_points=DEPTH_POINTS, middle_save_path=MIDDLE_SAVE_PATH,
+                          middle_visualize_path=MIDDLE_VISUALIZE_PATH)

@@ -88,3 +88,39 @@ class TransformFeaturesBBoxes(object):
             gt_bboxes.translate(trans)
         return points, gt_bboxes
 
+
+
+@PIPELINES.register_module()
+class AtlasTransformSpaceDetection(object):
+    """World frame of the detection stage (reference :204-266): the scene is translated so that the voxel_dim volume at
+    `origin` covers it -- centred on the scene's TSDF extent (mode 'middle') or anchored at the TSDF origin snapped
+    down by half a metre (mode 'origin').  Training moves the ground-truth boxes along (offset = origin); testing keeps
+    them and records `offset` = -translation, which the detector adds back to every aggregated point
+    (ray_marching.py:364), so the saved boxes are in the original world frame."""
+
+    def __init__(self, voxel_dim, origin=(0, 0, 0), test=False, mode="middle"):
+        assert mode in ("middle", "origin")
+        self.voxel_dim, self.origin, self.test, self.mode = voxel_dim, list(origin), test, mode
+
+    def __call__(self, data):
+        from .atlas_transforms import transform_space
+        tsdf = data["tsdf_dict"]["tsdf_gt_004"]
+        if self.mode == "middle":
+            lo = tsdf.origin[0].float()
+            hi = lo + torch.tensor(tsdf.tsdf_vol.shape) * tsdf.voxel_size
+            end = hi - torch.as_tensor(self.voxel_dim) * tsdf.voxel_size
+            t = -(lo * 0.5 + end * 0.5)
+        else:
+            t = (torch.tensor([.5, .5, .5]) // tsdf.voxel_size) * tsdf.voxel_size - tsdf.origin
+            t = t.view(-1)
+        if self.test:
+            data["offset"] = -t
+        else:
+            data["offset"] = torch.tensor(self.origin, dtype=torch.float32)
+            data["gt_bboxes_3d"].translate(t)
+        T = torch.eye(4)
+        T[:3, 3] = t
+        return transform_space(data, torch.inverse(T), self.voxel_dim, self.origin)
+
+    def __repr__(self):
+        return type(self).__name__

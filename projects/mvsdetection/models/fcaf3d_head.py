@@ -89,30 +89,7 @@ class _AxisAlignedIoU3DLoss(nn.Module):
         return self.loss_weight * loss.sum() / (avg_factor if avg_factor is not None else max(loss.numel(), 1))
 
 
-class GTBoxes:
-    """the three attributes of mmdet3d's DepthInstance3DBoxes the assigner and the loss touch, for use without mmdet3d:
-    tensor [m,7] = (x, y, z_bottom, dx, dy, dz, yaw), gravity_center [m,3], volume [m]"""
-
-    def __init__(self, tensor):
-        self.tensor = tensor.float()
-        if self.tensor.shape[1] == 6:
-            self.tensor = torch.cat((self.tensor, self.tensor.new_zeros(len(self.tensor), 1)), dim=1)
-
-    @property
-    def gravity_center(self):
-        c = self.tensor[:, :3].clone()
-        c[:, 2] += self.tensor[:, 5] / 2
-        return c
-
-    @property
-    def volume(self):
-        return self.tensor[:, 3] * self.tensor[:, 4] * self.tensor[:, 5]
-
-    def __len__(self):
-        return len(self.tensor)
-
-    def to(self, device):
-        return GTBoxes(self.tensor.to(device))
+from ..core.boxes import GTBoxes  # noqa: E402,F401  (kept importable from here: tests and the detector use it)
 
 
 @HEADS.register_module()

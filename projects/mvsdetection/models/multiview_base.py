@@ -1,0 +1,160 @@
+"""What the two detectors of the plugin share (reference: the common halves of models/atlas.py:71-405 and
+models/ray_marching.py:113-257, :547-682): the 2D feature extractor over all views, the dense unprojection-accumulate
+state (`volume`, `valid`), reconstruction outputs, and the mmcv runner protocol (forward / train_step / val_step /
+parse_losses / data_converter)."""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from cnrma_amd import rma
+
+from ..datasets.tsdf import TSDF
+from ..registry import build_backbone, build_head
+
+
+class MultiViewBase(nn.Module):
+    def __init__(self, pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin,
+                 backbone2d_stride, backbone2d, feature_2d, backbone_3d, tsdf_head, save_path):
+        super().__init__()
+        self.fp16_enabled = False
+        # a sub-network given as None is not built: its OUTPUT then comes in as an input (`features`, `tsdf`) -- that
+        # is how the hot path is measured, with the 2D / 3D CNN results resident in HBM
+        self.fpn = build_backbone(backbone2d) if backbone2d is not None else None
+        self.feature_2d = build_backbone(feature_2d) if feature_2d is not None else None
+        self.backbone3d = build_backbone(backbone_3d) if backbone_3d is not None else None
+        self.tsdf_head = build_head(tsdf_head) if tsdf_head is not None else None
+        self.pixel_mean = torch.Tensor(pixel_mean).view(-1, 1, 1)
+        self.pixel_std = torch.Tensor(pixel_std).view(-1, 1, 1)
+        self.voxel_size, self.n_scales = voxel_size, n_scales
+        self.voxel_dim_train, self.voxel_dim_test = voxel_dim_train, voxel_dim_test
+        self.voxel_dim = voxel_dim_test
+        self.save_path = save_path
+        if save_path is not None:
+            os.makedirs(save_path, exist_ok=True)
+        self.origin = torch.tensor(origin, dtype=torch.float32).view(1, 3)
+        self.backbone2d_stride = backbone2d_stride
+
+    # ---- state (reference ray_marching.py:200-209) --------------------------------------------------------------------
+    def initialize_volume(self):
+        self.volume = 0
+        self.valid = 0
+        self._views = []          # (projection [B,3,4], feature [B,C,H,W]) collected by aggregate_2d_features
+
+    def normalizer(self, x):
+        return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
+
+    def backbone2d(self, image):
+        return self.feature_2d(self.fpn(image))
+
+    def init_weights(self):
+        """called by the reference's train.py:219; every sub-module initialises itself at construction"""
+
+    def _features(self, inputs, batched):
+        """feature maps of all views [V,B,C,H',W']: through the 2D network (all views in one batch when the BatchNorm
+        statistics are to be shared, else view by view), or taken from the inputs when there is no 2D network"""
+        if self.fpn is None:
+            f = inputs["features"]
+            return torch.stack(f, dim=1) if isinstance(f, (list, tuple)) else f
+        images = inputs["imgs"].transpose(0, 1)
+        if batched:
+            x = self.backbone2d(self.normalizer(images.reshape(-1, *images.shape[2:])))
+            return x.view(images.shape[0], images.shape[1], *x.shape[1:])
+        return torch.stack([self.backbone2d(self.normalizer(im)) for im in images], dim=0)
+
+    # ---- dense unprojection (reference ray_marching.py:220-257 / atlas.py:120-153) ---------------------------------------
+    def aggregate_2d_features(self, projection, feature):
+        """Collect one view.  The reference adds a full C x G volume per call; here the views are only recorded and
+        clear_3d_features() runs ONE kernel over all of them (sum in view order + mean), which is bit-identical."""
+        self._views.append((projection, feature))
+
+    def clear_3d_features(self):
+        projs = torch.stack([p for p, _ in self._views], dim=0)        # [V,B,3,4]
+        feats = torch.stack([f for _, f in self._views], dim=0)        # [V,B,C,H,W]
+        vols, valids = [], []
+        org = self.origin.view(-1).tolist()
+        for b in range(feats.shape[1]):
+            if torch.is_grad_enabled() and feats.requires_grad:      # training: gradient of the volume -> feature maps
+                vol, cnt = rma.BackprojectAccum.apply(feats[:, b], projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                                                      self.backbone2d_stride)
+            else:
+                nhwc = rma.to_nhwc(feats[:, b])
+                vol, cnt = rma.backproject_accum(nhwc, projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                                                 self.backbone2d_stride)
+            vols.append(vol)
+            valids.append((cnt > 0).unsqueeze(0))
+        self.volume = torch.stack(vols)
+        self.valid = torch.stack(valids)
+        self._views = []
+
+    # ---- reconstruction outputs (reference ray_marching.py:500-545 / atlas.py:232-268) ------------------------------------
+    def post_process(self, outputs, inputs):
+        outs = []
+        for i, vol in enumerate(outputs["scene_tsdf_004"]):
+            tsdf = TSDF(self.voxel_size, self.origin, vol.squeeze(0))
+            tsdf.origin = inputs["offset"][i].view(1, 3)
+            outs.append(dict(scene=inputs["scene"][i], scene_tsdf=tsdf))
+        return outs
+
+    def save_reconstruction(self, outputs, inputs):
+        """{save_path}/{scene}/{scene}.npz for every sample, + {scene}.ply when scikit-image / trimesh are installed"""
+        if "offset" not in inputs or "scene" not in inputs:
+            return []
+        results = self.post_process(outputs, inputs)
+        for r in results:
+            d = os.path.join(self.save_path, r["scene"])
+            os.makedirs(d, exist_ok=True)
+            r["scene_tsdf"].save(os.path.join(d, r["scene"] + ".npz"))
+            try:
+                r["scene_tsdf"].get_mesh().export(os.path.join(d, r["scene"] + ".ply"))
+            except ImportError:
+                pass
+        return results
+
+    # ---- runner protocol (reference ray_marching.py:547-682) --------------------------------------------------------------
+    def forward(self, return_loss=True, rescale=False, **kwargs):
+        if return_loss:
+            return self.forward_train(kwargs)
+        return self.forward_test(self.data_converter(kwargs))
+
+    def data_converter(self, data):
+        """stack the per-sample lists of the DataContainer scatter (reference :653-682)"""
+        for key in ("imgs", "projection", "offset", "axis_align_matrix"):
+            if key in data and isinstance(data[key], (list, tuple)):
+                data[key] = torch.stack(list(data[key]), dim=0)
+        if "tsdf_dict" in data:
+            names = list(data["tsdf_dict"][0].keys())
+            dev = data["projection"].device
+            data["tsdf_list"] = {n: torch.stack([d[n].tsdf_vol.unsqueeze(0) for d in data["tsdf_dict"]], 0).to(dev)
+                                 for n in names}
+            data.pop("tsdf_dict")
+        data.pop("axis_align_matrix", None)
+        return data
+
+    def parse_losses(self, losses):
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f"{name} is not a tensor or list of tensors")
+        loss = sum(v for k, v in log_vars.items() if "loss" in k)
+        log_vars["total_loss"] = loss
+        for name, value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                value = value.data.clone()
+                dist.all_reduce(value.div_(dist.get_world_size()))
+            log_vars[name] = value.item() if isinstance(value, torch.Tensor) else float(value)
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        data = self.data_converter(data)
+        loss, log_vars = self.parse_losses(self(**data))
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["projection"]))
+
+    def val_step(self, data, optimizer=None):
+        return self(**data, return_loss=False)

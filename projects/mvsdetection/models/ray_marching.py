@@ -24,6 +24,7 @@ from cnrma_amd import sparse as S
 
 from ..datasets.pipelines.fcaf3d_transforms import TransformFeaturesBBoxes, sample_points
 from ..registry import DETECTORS, build_backbone, build_head
+from .multiview_base import MultiViewBase
 
 
 def backproject(voxel_dim, voxel_size, origin, projection, features):
@@ -49,7 +50,7 @@ def get_ray_parameter(projection, features):
 
 
 @DETECTORS.register_module()
-class RayMarching(nn.Module):
+class RayMarching(MultiViewBase):
     def __init__(self, pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin,
                  backbone2d_stride, backbone2d, feature_2d, backbone_3d, tsdf_head, detection_backbone,
                  detection_head, feature_transform, save_path, loss_weight_recon=1.0, loss_weight_detection=1.0,
@@ -57,35 +58,19 @@ class RayMarching(nn.Module):
                  train_cfg=None, test_cfg=None, pretrained=None, use_feature_transform=True,
                  ray_marching_type="neus", depth_points=None, neus_threshold=None, middle_save_path=None,
                  middle_visualize_path=None, point_sampler="numpy"):
-        super().__init__()
-        self.fp16_enabled = False
-        # sub-networks outside the hot path are optional: None = their outputs come in as inputs
-        self.fpn = build_backbone(backbone2d) if backbone2d is not None else None
-        self.feature_2d = build_backbone(feature_2d) if feature_2d is not None else None
-        self.backbone3d = build_backbone(backbone_3d) if backbone_3d is not None else None
-        self.tsdf_head = build_head(tsdf_head) if tsdf_head is not None else None
+        super().__init__(pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin, backbone2d_stride,
+                         backbone2d, feature_2d, backbone_3d, tsdf_head, save_path)
         self.detection_backbone = build_backbone(detection_backbone)
         self.detection_head = build_head(detection_head)
         if not use_feature_transform:
             feature_transform = None
         self.feature_transform = TransformFeaturesBBoxes(**feature_transform) if feature_transform is not None else None
-        self.pixel_mean = torch.Tensor(pixel_mean).view(-1, 1, 1)
-        self.pixel_std = torch.Tensor(pixel_std).view(-1, 1, 1)
-        self.voxel_size = voxel_size
-        self.n_scales = n_scales
-        self.voxel_dim_train = voxel_dim_train
-        self.voxel_dim_test = voxel_dim_test
         self.voxel_size_fcaf3d = voxel_size_fcaf3d
         self.use_batchnorm_train = use_batchnorm_train
         self.use_batchnorm_test = use_batchnorm_test
-        self.save_path = save_path
-        if save_path is not None:
-            os.makedirs(save_path, exist_ok=True)
         self.loss_weight_recon = loss_weight_recon
         self.loss_weight_detection = loss_weight_detection
         self.max_points = max_points
-        self.origin = torch.tensor(origin, dtype=torch.float32).view(1, 3)
-        self.backbone2d_stride = backbone2d_stride
         self.ray_marching_type = ray_marching_type
         self.neus_threshold = neus_threshold
         self.depth_points = depth_points
@@ -96,50 +81,11 @@ class RayMarching(nn.Module):
         self.middle_save_path = middle_save_path
         self.middle_visualize_path = middle_visualize_path
         self.point_sampler = point_sampler
-        self.voxel_dim = voxel_dim_test
         self.initialize_volume()
 
-    # ---- state (reference :200-209) --------------------------------------------------------------------------
     def initialize_volume(self):
-        self.volume = 0
-        self.valid = 0
+        super().initialize_volume()
         self.points_detection = []
-        self._views = []          # (projection [B,3,4], feature [B,C,H,W]) collected by aggregate_2d_features
-
-    def normalizer(self, x):
-        return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
-
-    def backbone2d(self, image):
-        return self.feature_2d(self.fpn(image))
-
-    def init_weights(self):
-        pass
-
-    # ---- dense unprojection (reference :220-257) ------------------------------------------------------------------
-    def aggregate_2d_features(self, projection, feature):
-        """Collect one view.  The reference adds a full C x G volume per call; here the views are only recorded and
-        clear_3d_features() runs ONE kernel over all of them (sum in view order + mean), which is bit-identical."""
-        self._views.append((projection, feature))
-
-    def clear_3d_features(self):
-        projs = torch.stack([p for p, _ in self._views], dim=0)        # [V,B,3,4]
-        feats = torch.stack([f for _, f in self._views], dim=0)        # [V,B,C,H,W]
-        B = feats.shape[1]
-        vols, valids = [], []
-        org = self.origin.view(-1).tolist()
-        for b in range(B):
-            if torch.is_grad_enabled() and feats.requires_grad:      # training: gradient of the volume -> feature maps
-                vol, cnt = rma.BackprojectAccum.apply(feats[:, b], projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
-                                                      self.backbone2d_stride)
-            else:
-                nhwc = rma.to_nhwc(feats[:, b])
-                vol, cnt = rma.backproject_accum(nhwc, projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
-                                                 self.backbone2d_stride)
-            vols.append(vol)
-            valids.append((cnt > 0).unsqueeze(0))
-        self.volume = torch.stack(vols)
-        self.valid = torch.stack(valids)
-        self._views = []
 
     # ---- ray marching (reference :260-307, :687-956) ---------------------------------------------------------------
     def _rows(self, projection, features, tsdf, mode, thr=None, k=0, grids=300):
@@ -214,17 +160,7 @@ class RayMarching(nn.Module):
                                                                   inputs.get("scene"), self.save_path)
         return losses
 
-    # ---- top level (reference :409-521, :592-682) -----------------------------------------------------------------------
-    def _features(self, inputs, batched):
-        if self.fpn is None:
-            f = inputs["features"]
-            return torch.stack(f, dim=1) if isinstance(f, (list, tuple)) else f      # [V,B,C,H,W]
-        images = inputs["imgs"].transpose(0, 1)
-        if batched:
-            x = self.backbone2d(self.normalizer(images.reshape(-1, *images.shape[2:])))
-            return x.view(images.shape[0], images.shape[1], *x.shape[1:])
-        return torch.stack([self.backbone2d(self.normalizer(im)) for im in images], dim=0)
-
+    # ---- top level (reference :409-521) -----------------------------------------------------------------------------
     def _run(self, inputs, test):
         self.voxel_dim = self.voxel_dim_test if test else self.voxel_dim_train
         self.initialize_volume()
@@ -233,16 +169,23 @@ class RayMarching(nn.Module):
         for projection, feature in zip(projections, features):
             self.aggregate_2d_features(projection, feature)
         self.clear_3d_features()
-        recon_loss = {}
+        recon_loss, recon_result = {}, None
         if self.backbone3d is not None:
             recon_result, recon_loss = self.tsdf_head(self.backbone3d(self.volume), inputs.get("tsdf_list"))
             tsdf = recon_result["scene_tsdf_004"]
-        else:
+        elif "tsdf" in inputs:
             tsdf = inputs["tsdf"]
+        else:                                            # no 3D network and no TSDF input: march on the ground truth
+            tsdf = inputs["tsdf_list"]["tsdf_gt_004"]
         self.aggregate_2d_features_ray_marching(projections, features, tsdf)
         detection_loss = self.fcaf3d_detection(inputs, self.points_detection, test=test)
         losses = {k: v * self.loss_weight_recon for k, v in recon_loss.items()}
         losses.update({k: v * self.loss_weight_detection for k, v in detection_loss.items()})
+        if test and recon_result is not None and self.save_path is not None:
+            results = self.save_reconstruction(recon_result, inputs)                         # {scene}.npz (+ .ply)
+            if self.middle_save_path is not None and results:
+                self.save_middle_result(results[0]["scene"], self.points_detection[0], results[0]["scene_tsdf"].origin,
+                                        self.middle_save_path, self.middle_visualize_path)
         return losses
 
     def forward_train(self, inputs):
@@ -252,47 +195,22 @@ class RayMarching(nn.Module):
         self._run(inputs, test=True)
         return [{}]
 
-    def forward(self, return_loss=True, rescale=False, **kwargs):
-        if return_loss:
-            return self.forward_train(kwargs)
-        return self.forward_test(self.data_converter(kwargs))
-
-    def data_converter(self, data):
-        """stack the per-sample lists of the DataContainer scatter (reference :653-682)"""
-        for key in ("imgs", "projection", "offset", "axis_align_matrix"):
-            if key in data and isinstance(data[key], (list, tuple)):
-                data[key] = torch.stack(list(data[key]), dim=0)
-        if "tsdf_dict" in data:
-            names = list(data["tsdf_dict"][0].keys())
-            dev = data["projection"].device
-            data["tsdf_list"] = {n: torch.stack([d[n].tsdf_vol.unsqueeze(0) for d in data["tsdf_dict"]], 0).to(dev)
-                                 for n in names}
-            data.pop("tsdf_dict")
-        data.pop("axis_align_matrix", None)
-        return data
-
-    def parse_losses(self, losses):
-        log_vars = OrderedDict()
-        for name, value in losses.items():
-            if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
-            elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
-            else:
-                raise TypeError(f"{name} is not a tensor or list of tensors")
-        loss = sum(v for k, v in log_vars.items() if "loss" in k)
-        log_vars["total_loss"] = loss
-        for name, value in log_vars.items():
-            if dist.is_available() and dist.is_initialized():
-                value = value.data.clone()
-                dist.all_reduce(value.div_(dist.get_world_size()))
-            log_vars[name] = value.item() if isinstance(value, torch.Tensor) else float(value)
-        return loss, log_vars
-
-    def train_step(self, data, optimizer):
-        data = self.data_converter(data)
-        loss, log_vars = self.parse_losses(self(**data))
-        return dict(loss=loss, log_vars=log_vars, num_samples=len(data["projection"]))
-
-    def val_step(self, data, optimizer=None):
-        return self(**data, return_loss=False)
+    def save_middle_result(self, scene_id, coords, offset, save_path, visualize_path=None):
+        """dump the aggregated points of a scene ([M, 3 + C], coordinates moved by `offset`, at most max_points rows drawn
+        like sample_points) as {scene}_vert.npy: the "middle" data the FCAF3D pre-training configs read
+        (reference :959-991)"""
+        pts = coords.detach().cpu().clone()
+        pts[:, :3] += torch.as_tensor(offset).detach().cpu().view(1, 3)
+        if self.max_points is not None and pts.shape[0] > self.max_points:
+            keep = np.zeros(pts.shape[0], dtype=bool)
+            keep[np.random.choice(pts.shape[0], self.max_points, replace=False)] = True
+            pts = pts[torch.from_numpy(keep)]
+        os.makedirs(save_path, exist_ok=True)
+        np.save(os.path.join(save_path, scene_id + "_vert.npy"), pts.numpy())
+        if visualize_path is not None:                       # ASCII .ply of the positions (the reference uses open3d)
+            d = os.path.join(visualize_path, scene_id)
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, scene_id + "_points.ply"), "w") as f:
+                f.write(f"ply\nformat ascii 1.0\nelement vertex {pts.shape[0]}\nproperty float x\nproperty float y\n"
+                        "property float z\nend_header\n")
+                np.savetxt(f, pts[:, :3].numpy(), fmt="%.6f")

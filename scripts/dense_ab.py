@@ -1,0 +1,30 @@
+"""dense unprojection kernel at a workload shape under different block orders (CNRMA_DENSE_CHUNK): HIP-event times"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cnrma_amd import rma, synth
+wl = sys.argv[1] if len(sys.argv) > 1 else "NS"
+dev = torch.device("cuda:0")
+V, C, H, W, dims, stride = synth.SHAPES[wl]
+sc = synth.make_scene(wl, seed=0, device=dev)
+feat = rma.to_nhwc(sc["features"][:, 0])
+del sc["features"]
+proj = rma.scale_projection(sc["projection"][:, 0], stride).to(dev)
+ref = None
+for chunk in sys.argv[2:]:
+    if chunk.startswith("lpv"):
+        os.environ["CNRMA_DENSE_LPV"] = chunk[3:]
+        os.environ.pop("CNRMA_DENSE_CHUNK", None)
+    elif chunk == "default":
+        os.environ.pop("CNRMA_DENSE_CHUNK", None)
+    else:
+        os.environ["CNRMA_DENSE_CHUNK"] = chunk
+    ts = []
+    for rep in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); vol, cnt = rma.backproject_accum(feat, None, dims, 0.04, (0, 0, 0), stride, proj_scaled=proj); b.record()
+        torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    if ref is None:
+        ref = (vol.clone(), cnt.clone())
+    print(wl, "chunk", chunk, "ms", [round(t, 3) for t in ts], "same", torch.equal(vol, ref[0]) and torch.equal(cnt, ref[1]), flush=True)
+    del vol, cnt

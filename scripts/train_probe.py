@@ -12,6 +12,7 @@ C = sc["features"].shape[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = runpy.run_path(os.path.join(root, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
 m = dict(cfg["model"])
+m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)
 m.update(save_path="/tmp/cnrma_train_probe", voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]),
          use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34))
 torch.manual_seed(0)

@@ -118,6 +118,14 @@ def load_reference_atlas3d():
     return b3, ah
 
 
+def load_reference_2d():
+    """Returns (fpn module, backbone2d module) of the reference (ResNet-FPN + pyramid-to-one-map head)."""
+    install_stubs()
+    fpn = importlib.import_module("projects.mvsdetection.models.fpn")
+    b2 = importlib.import_module("projects.mvsdetection.models.backbone2d")
+    return fpn, b2
+
+
 def make_raymarching(rm, voxel_dim, voxel_size=0.04, origin=(0.0, 0.0, 0.0), stride=4, rtype="neus",
                      thr=0.05, depth_points=None, max_points=None):
     import torch

@@ -210,6 +210,34 @@ def run_atlas3d():
     print("atlas3d.npz", {k: v.shape for k, v in out.items() if "feat" in k or "tsdf" in k})
 
 
+CFG_2D = dict(
+    fpn=dict(bottom_up_cfg=dict(input_channels=3, norm="BN", depth=50, out_features=["res2", "res3", "res4", "res5"], num_groups=1,
+                                width_per_group=64, stride_in_1x1=True, res5_dilation=1, res2_out_channels=256,
+                                stem_out_channels=64, freeze_at=2),
+             in_features=["res2", "res3", "res4", "res5"], out_channels=256, norm="BN", fuse_type="sum"),
+    head=dict(feature_strides={"p2": 4, "p3": 8, "p4": 16, "p5": 32, "p6": 64},
+              feature_channels={"p2": 256, "p3": 256, "p4": 256, "p5": 256, "p6": 256}, output_dim=32, output_stride=4, norm="BN"))
+
+
+def run_backbone2d():
+    """the reference's ResNet-50 FPN + AtlasFPNFeature (the shipped configuration) on a small image; the weights are a
+    function of their state-dict key (tests/helpers.py), so only input and outputs are kept"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import fill_state_deterministic
+    fpn_m, b2_m = R.load_reference_2d()
+    fpn = fill_state_deterministic(fpn_m.FPNDetectron(**CFG_2D["fpn"])).eval()
+    head = fill_state_deterministic(b2_m.AtlasFPNFeature(**CFG_2D["head"])).eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 64, 96, generator=g) * 40.0
+    with torch.no_grad():
+        pyr = fpn(x)
+        y = head(pyr)
+    out = dict(x=x.numpy(), y=y.numpy(), p2=pyr["p2"].numpy(), p6=pyr["p6"].numpy(),
+               fpn_keys=np.array(sorted(fpn.state_dict())), head_keys=np.array(sorted(head.state_dict())))
+    np.savez_compressed(os.path.join(HERE, "backbone2d.npz"), **out)
+    print("backbone2d.npz", y.shape, {k: tuple(v.shape) for k, v in pyr.items()})
+
+
 def main():
     torch.set_num_threads(8)
     rm, head, tr, ts = R.load_reference()
@@ -225,7 +253,12 @@ def main():
     run_decode(head)
     run_point_transforms(tr)
     run_atlas3d()
+    run_backbone2d()
 
+
+if __name__ == "__main__" and "--backbone2d" in sys.argv:
+    run_backbone2d()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--atlas3d" in sys.argv:
     run_atlas3d()

@@ -36,3 +36,26 @@ def bits_equal(a, b):
 
 def count_mismatch(a, b):
     return int(np.count_nonzero(~bits_equal(a, b)))
+
+
+def fill_state_deterministic(module):
+    """every floating tensor of the state dict <- a function of its KEY only (golden tests of networks too large to keep
+    their weights as fixtures: the reference-side generator and the test fill both models identically)"""
+    import zlib
+    with torch.no_grad():
+        for k, v in sorted(module.state_dict().items()):
+            if not v.dtype.is_floating_point:
+                continue
+            g = torch.Generator().manual_seed(zlib.crc32(k.encode()))
+            r = torch.randn(v.shape, generator=g)
+            if k.endswith("running_var"):
+                r = r.abs() * 0.5 + 0.5
+            elif k.endswith("norm.weight"):
+                r = 1.0 + 0.1 * r
+            elif k.endswith(("norm.bias", "running_mean", ".bias")):
+                r = 0.1 * r
+            else:
+                fan_in = max(1, v[0].numel()) if v.dim() > 1 else 1
+                r = r * (2.0 / fan_in) ** 0.5
+            v.copy_(r)
+    return module

@@ -135,3 +135,64 @@ def test_single_process_gather_is_identity():
     b, s = torch.rand(4, 6), torch.rand(4, 18)
     out = pipeline.gather_detections(b, s)
     assert len(out) == 1 and out[0][0] is b and out[0][1] is s
+
+
+def test_every_name_the_reference_registers_is_registered():
+    """projects/mvsdetection/__init__.py:2-23 of the reference"""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection import registry as R
+    if R.HAVE_MMDET:
+        pytest.skip("real mmdet registries in use")
+    want = dict(DETECTORS=["RayMarching", "Atlas"],
+                BACKBONES=["FCAF3DBackbone", "AtlasBackbone3D", "AtlasFPNFeature", "FPNDetectron", "ResNetDetectron"],
+                HEADS=["FCAF3DHead", "AtlasTSDFHead"], BBOX_ASSIGNERS=["FCAF3DAssigner"],
+                PIPELINES=["AtlasResizeImage", "AtlasIntrinsicsPoseToProjection", "AtlasRandomTransformSpaceRecon",
+                           "AtlasTestTransformSpaceRecon", "AtlasToTensor", "AtlasCollectData", "AtlasTransformSpaceDetection",
+                           "TransformFeaturesBBoxes"],
+                DATASETS=["AtlasScanNetDataset", "AtlasARKitDataset"])
+    for reg, names in want.items():
+        for n in names:
+            assert getattr(R, reg).get(n) is not None, f"{n} missing from {reg}"
+    from projects.mvsdetection import TSDF  # noqa: F401
+
+
+@pytest.mark.parametrize("name,kind", [("scannet_middle.py", "RayMarching"), ("arkit_middle.py", "RayMarching"),
+                                       ("atlas_recon_scannet.py", "Atlas"), ("atlas_recon_arkit.py", "Atlas")])
+def test_stage_configs_build(name, kind, tmp_path):
+    """the four remaining config files of the reference: full key set, built through the registry"""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model
+    cfg = _cfg(name)
+    m = dict(cfg["model"])
+    m["save_path"] = str(tmp_path / "results")
+    if "middle_save_path" in m:
+        m["middle_save_path"] = str(tmp_path / "middle")
+    model = build_model(m)
+    assert type(model).__name__ == kind
+    keys = set(model.state_dict())
+    # the 2D / 3D networks carry the reference's checkpoint prefixes
+    for k in ("fpn.bottom_up.stem.conv1.weight", "fpn.fpn_lateral5.weight", "fpn.fpn_output2.norm.running_mean",
+              "feature_2d.p5.4.norm.weight", "backbone3d.layers_down.0.0.conv1.weight", "tsdf_head.decoders.0.weight"):
+        assert k in keys, k
+    for split in ("train", "val", "test"):
+        assert cfg["data"][split]["type"] in ("AtlasScanNetDataset", "AtlasARKitDataset")
+        assert [t["type"] for t in cfg["data"][split]["pipeline"]][0] == "AtlasResizeImage"
+
+
+def test_save_middle_result_writes_the_pretraining_points(tmp_path):
+    """reference ray_marching.py:959-991: {scene}_vert.npy = [M', 3 + C] with the offset added and at most max_points rows"""
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model
+    m = dict(_cfg("scannet_middle.py")["model"])
+    m.update(save_path=str(tmp_path / "r"), middle_save_path=str(tmp_path / "mid"), backbone2d=None, feature_2d=None,
+             backbone_3d=None, tsdf_head=None, max_points=50)
+    model = build_model(m)
+    pts = torch.arange(200 * 5, dtype=torch.float32).view(200, 5)
+    np.random.seed(1)
+    model.save_middle_result("sceneX", pts, torch.tensor([[1.0, 2.0, 3.0]]), m["middle_save_path"], str(tmp_path / "vis"))
+    out = np.load(tmp_path / "mid" / "sceneX_vert.npy")
+    assert out.shape == (50, 5)
+    rows = (out[:, 3] - 3) / 5                       # feature column 3 of source row i is 5 i + 3
+    assert np.all(np.diff(rows) > 0)                 # order preserved
+    np.testing.assert_allclose(out[:, :3], pts.numpy()[rows.astype(int), :3] + [1, 2, 3])
+    assert (tmp_path / "vis" / "sceneX" / "sceneX_points.ply").exists()

@@ -18,6 +18,7 @@ def _model(tmp_path, dims, device, max_points):
     from projects.mvsdetection.registry import build_model
     cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
     m = dict(cfg["model"])
+    m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)      # hot path only: features / TSDF come in
     m.update(save_path=str(tmp_path / "results"), voxel_dim_test=list(dims), voxel_dim_train=list(dims), max_points=max_points)
     m["detection_backbone"] = dict(type="FCAF3DBackbone", in_channels=8, depth=34)
     model = build_model(m)
@@ -90,6 +91,7 @@ def test_raymarching_with_atlas3d_predicts_its_own_tsdf(device, tmp_path):
     C = sc["features"].shape[2]
     cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
     m = dict(cfg["model"])
+    m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)      # hot path only: features / TSDF come in
     m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
              detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34),
              backbone_3d=dict(type="AtlasBackbone3D", channels=[C, 16, 32], layers_down=[1, 1, 1], layers_up=[1, 1], drop=0.0,
@@ -130,6 +132,7 @@ def test_raymarching_train_step(device, tmp_path):
     C = sc["features"].shape[2]
     cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
     m = dict(cfg["model"])
+    m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)      # hot path only: features / TSDF come in
     m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
              use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14))
     torch.manual_seed(2)
@@ -171,6 +174,7 @@ def test_raymarching_train_step_with_atlas3d(device, tmp_path):
     X, Y, Z = sc["dims"]
     cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
     m = dict(cfg["model"])
+    m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)      # hot path only: features / TSDF come in
     m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
              use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14),
              backbone_3d=dict(type="AtlasBackbone3D", channels=[C, 16, 32], layers_down=[1, 1, 1], layers_up=[1, 1], drop=0.0,
