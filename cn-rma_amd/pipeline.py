@@ -266,6 +266,32 @@ class StaticScene:
         return out["bboxes"].index_select(0, rows), out["scores"].index_select(0, rows), info
 
 
+def gather_padded_detections(det, valid, det_all=None, valid_all=None):
+    """ONE fixed-size exchange of a step's detections: det [S, K, W] = the padded raw boxes + scores of the
+    S scenes a rank processed in the step, valid [S, L] = live rows per level.  Returns det_all [world, S, K, W] and
+    valid_all [world, S, L].  No counts are read back: the padded blocks are small (<= 4000 x 25 floats per scene) and the
+    row counts travel beside them.  Over RCCL (backend "nccl") this is two all_gather_into_tensor calls on device
+    memory; other backends (gloo in the CPU / single-device tests) go through host lists."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return det.unsqueeze(0), valid.unsqueeze(0)
+    W = dist.get_world_size()
+    if det_all is None:
+        det_all = torch.empty((W,) + tuple(det.shape), dtype=det.dtype, device=det.device)
+        valid_all = torch.empty((W,) + tuple(valid.shape), dtype=valid.dtype, device=valid.device)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(det_all, det)
+        dist.all_gather_into_tensor(valid_all, valid)
+    else:
+        d, v = det.cpu(), valid.cpu()
+        ds, vs = [torch.empty_like(d) for _ in range(W)], [torch.empty_like(v) for _ in range(W)]
+        dist.all_gather(ds, d)
+        dist.all_gather(vs, v)
+        det_all.copy_(torch.stack(ds))
+        valid_all.copy_(torch.stack(vs))
+    return det_all, valid_all
+
+
 def gather_detections(bboxes, scores):
     """variable-length all-gather of one scene's detections per rank over RCCL: first the row counts,
     then one padded [K_max, box+cls] block per rank.  Returns a list (per rank) of (bboxes, scores)."""

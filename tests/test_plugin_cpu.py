@@ -107,6 +107,14 @@ def _worker(rank, world, port, q):
         gr = torch.Generator().manual_seed(r)
         eb, es = torch.rand(5 + 3 * r, 6, generator=gr), torch.rand(5 + 3 * r, 18, generator=gr)
         ok = ok and torch.equal(b, eb) and torch.equal(s, es)
+    # the per-step exchange of bench.py: fixed-size padded blocks + live counts, no host read of any count
+    det = torch.full((3, 7, 4), float(rank)) + torch.arange(3).view(3, 1, 1)
+    val = torch.tensor([[rank, 1], [2, rank], [rank, rank]], dtype=torch.int32)
+    det_all, val_all = pipeline.gather_padded_detections(det, val)
+    ok = ok and tuple(det_all.shape) == (world, 3, 7, 4) and tuple(val_all.shape) == (world, 3, 2)
+    for r in range(world):
+        ok = ok and torch.equal(det_all[r], torch.full((3, 7, 4), float(r)) + torch.arange(3).view(3, 1, 1))
+        ok = ok and torch.equal(val_all[r], torch.tensor([[r, 1], [2, r], [r, r]], dtype=torch.int32))
     # scene sharding: scene i -> rank i mod W covers every scene exactly once
     mine = [i for i in range(7) if i % world == rank]
     allv = [None] * world
