@@ -99,7 +99,8 @@ template <int LPV>
 __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams p, const float* __restrict__ feat,
                                                                      const float* __restrict__ proj,
                                                                      float* __restrict__ volume,
-                                                                     int32_t* __restrict__ count, int chunk_blocks) {
+                                                                     int32_t* __restrict__ count, int chunk_blocks,
+                                                                     int64_t n_phys) {
   constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   const int lane = threadIdx.x & 63;
@@ -110,13 +111,17 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
   // consecutive blocks (one x-plane of the grid) -- chunks c, c + 8, c + 16, ... --, so rays that run inside a plane find
   // their pixels in the group's L2; the chunks stay interleaved over the whole grid, which keeps the groups evenly
   // loaded (8 contiguous slabs, one per XCD, measured 17 % slower: the frustum makes slabs unequal).
-  int64_t lb = blockIdx.x;
+  // persistent form: the grid may be smaller than the number of logical blocks (gridDim.x a multiple of 8, so that
+  // b % 8 -- the XCD group -- is the same for every logical block a workgroup takes); each workgroup walks
+  // pb = blockIdx.x, blockIdx.x + gridDim.x, ...
+  for (int64_t pb = blockIdx.x; pb < n_phys; pb += gridDim.x) {
+  int64_t lb = pb;
   if (chunk_blocks > 0) {
-    const int64_t grp = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int64_t grp = pb & 7, k = pb >> 3;
     lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
   }
   const int64_t wave_base = (lb * blockDim.x + threadIdx.x) - lane;
-  if (wave_base >= G) return;
+  if (wave_base >= G) continue;
   const int64_t g = wave_base + lane;
   const int c0 = blockIdx.y * (4 * LPV);
   float wx = 0.f, wy = 0.f, wz = 0.f;
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
     }
   }
   if (blockIdx.y == 0 && in_grid) count[g] = cnt;
+  }
 }
 
 template <int LPV>
@@ -177,8 +183,12 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   int64_t gx = nb;
   if (cb > 0 && nb >= 16 * cb) gx = ceil_div(ceil_div(nb, cb), 8) * 8 * cb;      // whole chunks for every XCD group
   else cb = 0;
-  dim3 grid((unsigned)gx, (unsigned)ceil_div(p.C, 4 * LPV));
-  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb);
+  int64_t launch_x = gx;
+  const char* pe = getenv("CNRMA_DENSE_PERSIST");          // tuning aid: workgroups per CU and channel sweep of a persistent grid
+  const int per_cu = pe != nullptr ? atoi(pe) : 0;
+  if (per_cu > 0 && gx > (int64_t)256 * per_cu) launch_x = (int64_t)256 * per_cu;     // a multiple of 8
+  dim3 grid((unsigned)launch_x, (unsigned)ceil_div(p.C, 4 * LPV));
+  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb, gx);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
