@@ -60,6 +60,9 @@ SIGNATURES = {
     "cnrma_sparse_conv_f16_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights_f16": (c_int, [P, I, I, I, P, P]),
     "cnrma_sparse_conv_f16x3": (c_int, [P, P, I, P, I, P, I, P, P, P, I, P, P, L, P, P, c_size_t, P]),
+    "cnrma_sparse_conv_bf16_weight_bytes": (c_size_t, [I, I, I]),
+    "cnrma_sparse_conv_prepare_weights_bf16": (c_int, [P, I, I, I, P, P]),
+    "cnrma_sparse_conv_bf16": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_convtr_gen_f16x3": (c_int, [P, P, P, L, P, I, I, P, I, P, P, I, P, P, P, P]),
     "cnrma_sparse_kernel_map_transpose": (c_int, [P, L, P, I, L, P, P]),
     "cnrma_sparse_conv_wgrad_chunks": (c_int, [L, I]),

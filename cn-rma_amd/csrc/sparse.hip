@@ -796,6 +796,20 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
   }
 }
 
+// W fp32 [K][Cin][Cout] -> Wt bf16 [K][Cout_p][Cin], round to nearest (MODE 2)
+__global__ __launch_bounds__(256) void prep_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
+                                                                int Cin, int Cout) {
+  const int Cp = conv_cout_padded(Cout);
+  const int64_t total = (int64_t)K * Cin * Cp;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int cin = (int)(t % Cin);
+    const int64_t q = t / Cin;
+    const int co = (int)(q % Cp);
+    const int k = (int)(q / Cp);
+    wt[t] = (__bf16)(co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] : 0.0f);
+  }
+}
+
 // prefetch registers of the A operand + their staging code, one specialisation per input format (keeps the unused
 // format's registers out of the kernel; plain members instead of lambda-captured arrays so they stay in VGPRs)
 template <bool IN_SPLIT, int N> struct AStageRegs;
@@ -830,13 +844,19 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
         *reinterpret_cast<uint2*>(a0 + o) = h;
         *reinterpret_cast<uint2*>(a1 + o) = m;
         *reinterpret_cast<uint2*>(a2 + o) = l;
-      } else {
+      } else if constexpr (MODE == 1) {
         // a missing neighbour was loaded from row 0 (clamped address): its scale is 0 instead of a select per value
         uint2 h, m;
         split2(v, k ? a_scale : 0.0f, h, m);
         const int o = lds_slot(row, kc >> 1) + (kc & 1) * 4;
         *reinterpret_cast<uint2*>(a0 + o) = h;
         *reinterpret_cast<uint2*>(a1 + o) = m;
+      } else {
+        // plain bf16 (autocast training): one round-to-nearest piece per value
+        const float z = k ? 1.0f : 0.0f;
+        const bf16x4_t q = {(__bf16)(v.x * z), (__bf16)(v.y * z), (__bf16)(v.z * z), (__bf16)(v.w * z)};
+        const int o = lds_slot(row, kc >> 1) + (kc & 1) * 4;
+        *reinterpret_cast<bf16x4_t*>(a0 + o) = q;
       }
     }
   }
@@ -870,11 +890,12 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
   }
 };
 
-// MODE 0 = bf16x6 (3 planes, 6 products), MODE 1 = f16x3 (2 planes, 3 products, power-of-two operand scales)
+// MODE 0 = bf16x6 (3 planes, 6 products), MODE 1 = f16x3 (2 planes, 3 products, power-of-two operand scales),
+// MODE 2 = bf16 (1 plane, 1 product: the autocast training precision -- bf16 operands, fp32 accumulation)
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT, int MODE>
 __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-  constexpr int NP = MODE == 0 ? 3 : 2;
+  constexpr int NP = MODE == 0 ? 3 : (MODE == 1 ? 2 : 1);
   static_assert(MODE == 0 || !IN_SPLIT, "companions exist for bf16x6 only");
   // staging tasks per stage: fp32 input = (row, 4 channels) -> 8 per row; pre-split input = (row, 8 channels) -> 4 per row
   constexpr int ROW_SHIFT = IN_SPLIT ? 2 : 3;
@@ -1016,6 +1037,16 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], c, 0, 0, 0);   // h*h
             acc[a][b] = c;
           }
+      } else if constexpr (MODE == 2) {
+        bf16x8_t af[TM], bf[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const bf16x8_t*>(&As[0][lds_slot(a_row + a * 32, (ks >> 3) + fhalf)]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const bf16x8_t*>(&Bs[0][lds_slot(b_row + b * 32, (ks >> 3) + fhalf)]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
       } else {
         f16x8_t af[TM][2], bf[TN][2];
 #pragma unroll
@@ -1170,6 +1201,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   ConvArgs p{in, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out, no_cap, no_dev, slices, 1, K,
              reinterpret_cast<float*>(workspace), reinterpret_cast<const uint16_t*>(in_split), in_zero_row,
              reinterpret_cast<uint16_t*>(out_split), out_zero_row, in_amax, nullptr, out_amax};
+  if (mode == 2 && (weight_split == nullptr || in_split != nullptr || out_split != nullptr)) return CNRMA_EINVAL;
   if (mode == 1) {
     if (weight_split == nullptr || in_amax == nullptr || in_split != nullptr || out_split != nullptr) return CNRMA_EINVAL;
     p.w_amax = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(weight_split) +
@@ -1185,7 +1217,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     shape = (decltype(shape))sh; bm = bms[sh]; bn = bns[sh];
   };
   if (Cout <= 32) pick(T128x32);
-  else if (six && mode == 1) {
+  else if (six && mode >= 1) {
     if (Cout >= 128) pick(no_cap >= 16384 && no_cap < 40000 ? T128x128 : (no_cap < 1000 && Cout < 256 ? T64x64 : T64x128));
     else pick(no_cap >= 200000 && Cin > 32 ? T128x64 : T64x64);
   }
@@ -1208,7 +1240,11 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     const __bf16* wt = reinterpret_cast<const __bf16*>(weight_split);
 #define CNRMA_CONV6_LAUNCH(WM, WN, TM_, TN_)                                                                       \
   do {                                                                                                             \
-    if (mode == 1 && has_res)                                                                                      \
+    if (mode == 2 && has_res)                                                                                      \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 2>), grid, dim3(256), 0, st, p, wt);  \
+    else if (mode == 2)                                                                                            \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 2>), grid, dim3(256), 0, st, p, wt); \
+    else if (mode == 1 && has_res)                                                                                      \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 1>), grid, dim3(256), 0, st, p, wt);  \
     else if (mode == 1)                                                                                            \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 1>), grid, dim3(256), 0, st, p, wt); \
@@ -1531,7 +1567,9 @@ __global__ __launch_bounds__(256) void kernel_map_transpose_kernel(const int32_t
   if (i >= 0 && i < n_in) nbr_t[(int64_t)i * K + (t % K)] = (int32_t)(t / K);
 }
 
-// one wave per block: a 64 x 64 (Cin x Cout) tile of gradW[k] over one chunk of output rows
+// one wave per block: a 64 x 64 (Cin x Cout) tile of gradW[k] over one chunk of output rows.  A step covers 32 rows: the
+// 32 neighbour indices are fetched by one load, then the 64 operand loads of the step (16 row pairs x 2 x 2 tiles) are all
+// issued before its 64 MFMAs -- the former two-rows-per-iteration loop paid two dependent memory latencies per 4 MFMAs.
 __global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr,
                                                         int K, const float* __restrict__ gout, int Cout, int64_t no_cap,
                                                         const int32_t* __restrict__ no_dev, int rows_per_chunk,
@@ -1550,22 +1588,30 @@ __global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict_
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
   const int64_t r0 = (int64_t)chunk * rows_per_chunk;
   const int64_t r1 = min(n_live, r0 + rows_per_chunk);
-  for (int64_t o0 = r0; o0 < r1; o0 += 2) {
-    const int64_t o = o0 + kk;
-    const bool live = o < r1;
-    int32_t src = -1;
-    if (live) src = nbr ? nbr[o * K + k] : (int32_t)o;
-    float a[2], b[2];
+  const bool ci_ok0 = ci0 + m < Cin, ci_ok1 = ci0 + 32 + m < Cin, co_ok0 = co0 + m < Cout, co_ok1 = co0 + 32 + m < Cout;
+  for (int64_t o0 = r0; o0 < r1; o0 += 32) {
+    int32_t src_l = -1;                                   // lane l < 32: input row of output row o0 + l at this offset
+    if (m + (kk << 5) < 32 && o0 + m < r1) src_l = nbr ? nbr[(o0 + m) * K + k] : (int32_t)(o0 + m);
+    float a0[16], a1[16], b0[16], b1[16];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int ci = ci0 + t * 32 + m, co = co0 + t * 32 + m;
-      a[t] = (src >= 0 && ci < Cin) ? in[(int64_t)src * Cin + ci] : 0.0f;
-      b[t] = (live && co < Cout) ? gout[o * Cout + co] : 0.0f;
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int row = 2 * s2 + kk;
+      const int32_t src = __shfl(src_l, row, 64);
+      const bool live = o0 + row < r1;
+      const float* ap = in + (int64_t)(src < 0 ? 0 : src) * Cin + ci0 + m;
+      const float* gp = gout + (live ? o0 + row : r0) * Cout + co0 + m;
+      const float va0 = ci_ok0 ? ap[0] : 0.0f, va1 = ci_ok1 ? ap[32] : 0.0f;
+      const float vb0 = co_ok0 ? gp[0] : 0.0f, vb1 = co_ok1 ? gp[32] : 0.0f;
+      a0[s2] = src >= 0 ? va0 : 0.0f; a1[s2] = src >= 0 ? va1 : 0.0f;
+      b0[s2] = live ? vb0 : 0.0f; b1[s2] = live ? vb1 : 0.0f;
     }
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    for (int s2 = 0; s2 < 16; ++s2) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s2], b0[s2], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s2], b1[s2], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s2], b0[s2], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s2], b1[s2], acc[1][1], 0, 0, 0);
+    }
   }
   float* dst = slab + ((int64_t)chunk * K + k) * Cin * Cout;
 #pragma unroll
@@ -1781,6 +1827,30 @@ extern "C" int cnrma_sparse_conv_f16x3(const float* in_feats, const float* in_am
   return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
                      workspace, workspace_bytes, as_stream(stream), weight_split, nullptr, 0, nullptr, 0, 1, in_amax,
                      out_amax);
+}
+
+extern "C" size_t cnrma_sparse_conv_bf16_weight_bytes(int K, int Cin, int Cout) {
+  return (size_t)K * Cin * conv_cout_padded(Cout) * sizeof(uint16_t);
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_bf16(const float* weight, int K, int Cin, int Cout, void* weight_bf16,
+                                                      void* stream) {
+  if (K <= 0 || Cin <= 0 || Cout <= 0 || weight_bf16 == nullptr) return CNRMA_EINVAL;
+  int64_t blocks = ceil_div((int64_t)K * Cin * conv_cout_padded(Cout), 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
+                     reinterpret_cast<__bf16*>(weight_bf16), K, Cin, Cout);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const void* weight_bf16,
+                                      int Cout, const float* scale, const float* shift, const float* residual, int act,
+                                      float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (weight_bf16 == nullptr || Cin % 32 != 0 || in_feats == nullptr) return CNRMA_EINVAL;
+  return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
+                     workspace, workspace_bytes, as_stream(stream), weight_bf16, nullptr, 0, nullptr, 0, 2);
 }
 
 extern "C" int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax,

@@ -406,6 +406,36 @@ def split_weights_f16(weight):
     return ws
 
 
+def weights_bf16(weight):
+    """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [K,Cout_p,Cin] (round to nearest) for the "bf16" convolutions;
+    cached on the weight tensor like the other prepared images"""
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    hit = getattr(weight, "_cnrma_bf16", None)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    w = weight.detach().contiguous().float()
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    K, Cin, Cout = w.shape
+    ws = torch.empty(_lib.load().cnrma_sparse_conv_bf16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+    call("cnrma_sparse_conv_prepare_weights_bf16", ptr(w), K, Cin, Cout, ptr(ws), stream())
+    try:
+        weight._cnrma_bf16 = (tag, ws)
+    except AttributeError:
+        pass
+    return ws
+
+
+def _precision(precision=None):
+    """explicit > torch.autocast(bf16) region (the reference's training configuration: bf16 operands, fp32 accumulation,
+    BASELINE configs[4]) > the module default CONV_PRECISION"""
+    if precision:
+        return precision
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return "bf16"
+    return CONV_PRECISION
+
+
 def split_weights(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [3,K,Cout_p,Cin] (hi / mid / lo pieces, Cout padded to 128).  The result is cached ON
     the weight tensor object (so it dies with it) and rebuilt when the tensor is modified in place or moved."""
@@ -449,7 +479,11 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             assert res.shape == out.shape
         ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(out_cs.n, Cout, K)
         ws = _workspace(ws_bytes, x.device) if ws_bytes else None
-        prec = precision or CONV_PRECISION
+        prec = _precision(precision)
+        if prec == "bf16" and Cin % 32 == 0:
+            call("cnrma_sparse_conv_bf16", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(weights_bf16(weight)), Cout, ptr(scale),
+                 ptr(shift), ptr(res), ACT[act], ptr(out), out_cs.n, ptr(out_cs.n_dev), ptr(ws), ws_bytes, stream())
+            return SparseTensor(out, out_cs)
         if prec == "f16x3" and Cin % 32 == 0:
             out_amax = _amax_slot(x.device)
             call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
@@ -483,8 +517,11 @@ def _conv_on_table(feats, n_out, nbr, weight, precision=None):
     ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(n_out, Cout, K)
     ws = _workspace(ws_bytes, feats.device) if ws_bytes else None
     feats = feats.contiguous().float()
-    prec = precision or CONV_PRECISION
-    if prec == "f16x3" and Cin % 32 == 0:
+    prec = _precision(precision)
+    if prec == "bf16" and Cin % 32 == 0:
+        call("cnrma_sparse_conv_bf16", ptr(feats), Cin, ptr(nbr), K, ptr(weights_bf16(weight)), Cout,
+             None, None, None, 0, ptr(out), n_out, None, ptr(ws), ws_bytes, stream())
+    elif prec == "f16x3" and Cin % 32 == 0:
         amax = torch.zeros(_AMAX_WORDS, dtype=torch.float32, device=feats.device)
         call("cnrma_absmax_f32", ptr(feats), feats.shape[0], None, Cin, ptr(amax), stream())
         call("cnrma_sparse_conv_f16x3", ptr(feats), ptr(amax), Cin, ptr(nbr), K, ptr(split_weights_f16(w)), Cout, None, None,
@@ -502,8 +539,9 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, weight, nbr, n_out, precision):
         ctx.save_for_backward(F, weight)
+        precision = _precision(precision)          # resolved here: the backward runs outside the autocast region
         ctx.nbr, ctx.n_out, ctx.precision = nbr, n_out, precision
-        return _conv_on_table(F.detach(), n_out, nbr, weight.detach(), precision)
+        return _conv_on_table(F.detach().float(), n_out, nbr, weight.detach(), precision)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -571,7 +609,7 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
         k = torch.arange(8, device=x.device)
         off = torch.stack((torch.zeros_like(k), k & 1, (k >> 1) & 1, (k >> 2) & 1), dim=1).to(torch.int32) * half
         out_c = (x.C.unsqueeze(0) + off.unsqueeze(1)).reshape(8 * n, 4).contiguous()
-        out_f = torch.einsum("nc,kcd->knd", x.F, weight.float()).reshape(8 * n, weight.shape[2])
+        out_f = torch.einsum("nc,kcd->knd", x.F, weight.float()).reshape(8 * n, weight.shape[2]).float()   # fp32 storage under autocast too
         if scale is not None:
             out_f = out_f * scale
         if shift is not None:

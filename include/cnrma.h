@@ -313,6 +313,16 @@ int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feat
                                   const float* scale, const float* shift, int act, int32_t* out_coords,
                                   float* out_feats, float* out_amax, void* stream);
 
+/* bf16 convolution (one bf16 piece per operand, round to nearest, fp32 accumulation: `v_mfma_f32_32x32x16_bf16`) -- the
+ * precision of the reference's autocast training configuration (BASELINE configs[4]); NOT within the 1e-4 of the
+ * inference path, which stays on f16x3 / f32.  Needs Cin % 32 == 0; weights prepared once:
+ * fp32 [K][Cin][Cout] -> bf16 [K][Cout_p][Cin].  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
+size_t cnrma_sparse_conv_bf16_weight_bytes(int K, int Cin, int Cout);
+int cnrma_sparse_conv_prepare_weights_bf16(const float* weight, int K, int Cin, int Cout, void* weight_bf16, void* stream);
+int cnrma_sparse_conv_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const void* weight_bf16, int Cout,
+                           const float* scale, const float* shift, const float* residual, int act, float* out_feats,
+                           int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward of the sparse convolution (training).
  * cnrma_sparse_kernel_map_transpose: nbr_t[n_in][K] with nbr_t[i][k] = o where nbr[o][k] == i (else -1); the data
  *   gradient is then the forward convolution of grad_out over nbr_t with the per-offset transposed weights.

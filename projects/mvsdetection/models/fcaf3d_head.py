@@ -68,22 +68,25 @@ class _SigmoidBCELoss(nn.Module):
         return self.loss_weight * loss.sum() / (avg_factor if avg_factor is not None else max(loss.numel(), 1))
 
 
-class _AxisAlignedIoU3DLoss(nn.Module):
-    """IoU3DLoss(with_yaw=False) of the FCAF3D code base: (1 - IoU3D) of (cx,cy,cz,w,l,h) boxes, weighted, / avg_factor.
-    The rotated variant (with_yaw=True, ARKit) needs a differentiable rotated IoU and is not provided."""
+class _IoU3DLoss(nn.Module):
+    """IoU3DLoss of the FCAF3D code base: (1 - IoU3D) of (cx, cy, cz, dx, dy, dz[, yaw]) boxes, weighted, / avg_factor.
+    with_yaw=False: axis-aligned boxes (ScanNet); with_yaw=True: rotated about z (ARKit) through core/rotated_iou.py."""
 
     def __init__(self, loss_weight=1.0, with_yaw=False, **_):
         super().__init__()
-        self.loss_weight, self.with_yaw = loss_weight, with_yaw      # building the ARKit config for inference must not fail
+        self.loss_weight, self.with_yaw = loss_weight, with_yaw
 
     def forward(self, pred, target, weight=None, avg_factor=None):
-        if self.with_yaw:
-            raise NotImplementedError("rotated IoU3D loss (with_yaw=True) is not available without mmdet3d")
-        p_lo, p_hi = pred[:, :3] - pred[:, 3:6] / 2, pred[:, :3] + pred[:, 3:6] / 2
-        t_lo, t_hi = target[:, :3] - target[:, 3:6] / 2, target[:, :3] + target[:, 3:6] / 2
-        inter = (torch.min(p_hi, t_hi) - torch.max(p_lo, t_lo)).clamp(min=0).prod(dim=1)
-        union = pred[:, 3:6].prod(dim=1) + target[:, 3:6].prod(dim=1) - inter
-        loss = 1 - inter / union.clamp(min=1e-8)
+        if self.with_yaw and pred.shape[1] >= 7:
+            from ..core.rotated_iou import rotated_iou_3d
+            iou = rotated_iou_3d(pred[:, :7], target[:, :7].to(pred.dtype))
+        else:
+            p_lo, p_hi = pred[:, :3] - pred[:, 3:6] / 2, pred[:, :3] + pred[:, 3:6] / 2
+            t_lo, t_hi = target[:, :3] - target[:, 3:6] / 2, target[:, :3] + target[:, 3:6] / 2
+            inter = (torch.min(p_hi, t_hi) - torch.max(p_lo, t_lo)).clamp(min=0).prod(dim=1)
+            union = pred[:, 3:6].prod(dim=1) + target[:, 3:6].prod(dim=1) - inter
+            iou = inter / union.clamp(min=1e-8)
+        loss = 1 - iou
         if weight is not None:
             loss = loss * weight
         return self.loss_weight * loss.sum() / (avg_factor if avg_factor is not None else max(loss.numel(), 1))
@@ -110,7 +113,7 @@ class FCAF3DHead(nn.Module):
             self.loss_centerness, self.loss_bbox, self.loss_cls = map(build_loss, (loss_centerness, loss_bbox, loss_cls))
         else:   # the three losses the configs name, restated in torch (mmdet / mmdet3d are third-party: unpinned)
             self.loss_centerness = _SigmoidBCELoss(**_without_type(loss_centerness))
-            self.loss_bbox = _AxisAlignedIoU3DLoss(**_without_type(loss_bbox))
+            self.loss_bbox = _IoU3DLoss(**_without_type(loss_bbox))
             self.loss_cls = _SigmoidFocalLoss(**_without_type(loss_cls))
         self.train_cfg = train_cfg
         self.test_cfg = _TestCfg(test_cfg) if isinstance(test_cfg, dict) else test_cfg

@@ -28,8 +28,10 @@ feats = sc["features"][:, 0].to(dev).requires_grad_(True)
 data = dict(features=[feats], projection=[sc["projection"][:, 0].to(dev)], tsdf=sc["tsdf"].to(dev),
             offset=[torch.zeros(3, device=dev)], gt_bboxes_3d=[boxes], gt_labels_3d=[labels])
 opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+AUTOCAST = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 def step():
-    out = model.train_step(dict(data), None)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=AUTOCAST):
+        out = model.train_step(dict(data), None)
     opt.zero_grad(); feats.grad = None
     out["loss"].backward()
     opt.step()
@@ -39,4 +41,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 5
 for _ in range(n): l = step()
 torch.cuda.synchronize()
-print(f"{shape}: {(time.perf_counter() - t0) / n * 1e3:.1f} ms per training step, loss {l:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+print(f"{shape} ({'bf16 autocast' if AUTOCAST else 'fp32'}): {(time.perf_counter() - t0) / n * 1e3:.1f} ms per training step, loss {l:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -1,0 +1,82 @@
+"""Training-side kernels added for BASELINE configs[4] (bf16 autocast): the bf16 convolution against the fp64 oracle on
+bf16-rounded operands, and a detector train_step under torch.autocast(bf16) against the same step in fp32."""
+import os
+import runpy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as SO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_bf16_conv_equals_fp32_accumulation_of_bf16_operands(device, stride):
+    """one bf16 piece per operand (round to nearest), products exact in fp32, fp32 accumulation: the result equals the
+    fp64 oracle on the ROUNDED operands up to accumulation noise -- and differs from the unrounded result by bf16's 2^-8"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(5 + stride)
+    c = np.unique(np.concatenate((np.zeros((9000, 1), dtype=np.int64), rng.randint(-20, 20, size=(9000, 3)) * 2), axis=1), axis=0)
+    f = rng.randn(len(c), 64).astype(np.float32)
+    W = (rng.randn(27, 64, 96) / 20).astype(np.float32)
+    x = S.SparseTensor(torch.from_numpy(f).to(device), S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 2))
+    y = S.conv(x, torch.from_numpy(W).to(device), 3, stride, precision="bf16")
+    oc, exp = SO.conv(c, _bf16_round(f), _bf16_round(W), 3, stride, 2)
+    oc0, exact = SO.conv(c, f, W, 3, stride, 2)
+    got_c = y.C.cpu().numpy().astype(np.int64)
+    o1, o2 = np.lexsort(got_c.T[::-1]), np.lexsort(oc.T[::-1])
+    assert np.array_equal(got_c[o1], oc[o2])
+    got = y.F.cpu().numpy()[o1]
+    np.testing.assert_allclose(got, exp[o2], rtol=1e-5, atol=1e-5)
+    err = np.abs(got - exact[o2]).max() / np.abs(exact).max()
+    assert 1e-4 < err < 2e-2                                   # bf16 operands: visible, bounded
+
+
+def test_train_step_under_bf16_autocast_tracks_the_fp32_step(device, tmp_path):
+    import projects.mvsdetection  # noqa: F401
+    from cnrma_amd import synth
+    from projects.mvsdetection.registry import build_model
+    sc = synth.make_scene("tiny", seed=6)
+    C = 32
+    g = torch.Generator().manual_seed(0)
+    feats0 = torch.randn(sc["features"].shape[0], C, *sc["features"].shape[3:], generator=g)
+    cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_arkit.py"))
+    m = dict(cfg["model"])
+    m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None, save_path=str(tmp_path / "r"),
+             voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None, use_feature_transform=False,
+             detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14))
+    ext = np.array(sc["dims"], dtype=np.float32) * 0.04
+    boxes = torch.tensor([[0.35 * ext[0], 0.4 * ext[1], 0.1 * ext[2], 0.5, 0.4, 0.5, 0.3],
+                          [0.65 * ext[0], 0.6 * ext[1], 0.2 * ext[2], 0.4, 0.6, 0.4, -0.4]], device=device)
+
+    def run(autocast):
+        torch.manual_seed(2)
+        model = build_model(dict(m))
+        model.detection_backbone.init_weights()
+        model.detection_head.init_weights()
+        model = model.to(device).train()
+        feats = feats0.to(device).requires_grad_(True)
+        data = dict(features=[feats], projection=[sc["projection"][:, 0].to(device)], tsdf=sc["tsdf"].to(device),
+                    offset=[torch.zeros(3, device=device)], gt_bboxes_3d=[boxes.clone()],
+                    gt_labels_3d=[torch.tensor([1, 3], device=device)])
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = model.train_step(data, None)
+        out["loss"].backward()
+        grads = torch.cat([p.grad.flatten() for n, p in sorted(model.named_parameters()) if p.grad is not None])
+        return {k: float(v) for k, v in out["log_vars"].items()}, grads, feats.grad.flatten()
+
+    l32, g32, f32 = run(False)
+    l16, g16, f16 = run(True)
+    assert {"loss_centerness", "loss_bbox", "loss_cls"} <= set(l32)            # rotated IoU loss of the ARKit head included
+    for k in l32:
+        assert abs(l16[k] - l32[k]) <= 3e-2 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])
+    cos = torch.nn.functional.cosine_similarity(g16, g32, dim=0)
+    assert torch.isfinite(g16).all() and float(cos) > 0.98, float(cos)
+    assert float(torch.nn.functional.cosine_similarity(f16, f32, dim=0)) > 0.95
