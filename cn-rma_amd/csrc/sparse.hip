@@ -26,6 +26,7 @@ struct UniqueWs {
   uint64_t* key_a; uint64_t* key_b;
   int32_t* val_a; int32_t* val_b;
   void* sort_tmp; size_t sort_tmp_bytes;
+  int32_t* range_err;   // set when a quantised coordinate does not fit the 16-bit fields of coord_key()
 };
 
 size_t sort_temp_bytes(int64_t n) {
@@ -51,6 +52,7 @@ __host__ UniqueWs carve_unique_ws(void* workspace, int64_t n) {
   p = reinterpret_cast<char*>(((uintptr_t)p + 255) & ~(uintptr_t)255);
   w.sort_tmp_bytes = sort_temp_bytes(n);
   w.sort_tmp = p; p += w.sort_tmp_bytes;
+  w.range_err = reinterpret_cast<int32_t*>(p); p += 256;
   w.scan = p;
   return w;
 }
@@ -97,11 +99,19 @@ __global__ __launch_bounds__(256) void uniq_insert_kernel(const void* __restrict
                                                           const int32_t* __restrict__ n_dev, float vs, int new_stride,
                                                           int batch_id, uint64_t* __restrict__ keys,
                                                           int32_t* __restrict__ vals, int64_t cap,
-                                                          int32_t* __restrict__ slot_out) {
+                                                          int32_t* __restrict__ slot_out, int32_t* __restrict__ range_err) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= live_rows(n_cap, n_dev)) return;
   int b, x, y, z;
   quantise<MODE>(src, i, vs, new_stride, batch_id, &b, &x, &y, &z);
+  if (MODE == 0) {
+    // coord_key() packs batch / x / y / z into 16 bits each: a coordinate beyond +-32767 voxels (327 m at 1 cm) or a NaN
+    // would alias another voxel silently -- reported through n_out = -1 instead
+    const float* c = reinterpret_cast<const float*>(src) + i * 3;
+    const float lim = 32767.0f * vs;
+    const bool ok = fabsf(c[0]) < lim && fabsf(c[1]) < lim && fabsf(c[2]) < lim && b >= 0 && b < 65536;   // false for NaN
+    if (!ok) { *range_err = 1; slot_out[i] = -1; return; }
+  }
   int64_t s = hash_insert(keys, cap, coord_key(b, x, y, z));
   slot_out[i] = (int32_t)s;
   if (s >= 0) atomicMin(&vals[s], (int32_t)i);
@@ -198,6 +208,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+__global__ void uniq_range_report_kernel(const int32_t* __restrict__ range_err, int32_t* __restrict__ n_out) {
+  if (*range_err) n_out[0] = -1;
+}
+
 template <int MODE>
 int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, int new_stride, int batch_id,
                uint64_t* keys, int32_t* vals, int64_t cap, int32_t* out_coords, int32_t* out_src, int32_t* n_out,
@@ -210,11 +224,14 @@ int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, i
   e = cnrma_fill_bytes(vals, 0x7F, (size_t)cap * sizeof(int32_t), st);
   if (e != hipSuccess) return -(int)e;
   const unsigned nb = (unsigned)ceil_div(n_cap, 256);
+  e = cnrma_fill_bytes(w.range_err, 0, 4, st);
+  if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL((uniq_insert_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
-                     batch_id, keys, vals, cap, w.slot);
+                     batch_id, keys, vals, cap, w.slot, w.range_err);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3(nb), dim3(256), 0, st, n_cap, n_dev, vals, w.slot, w.flag);
   int rc = cnrma_mask_to_index(w.flag, w.idx, n_out, n_cap, w.scan, st);
   if (rc) return rc;
+  if (MODE == 0) hipLaunchKernelGGL(uniq_range_report_kernel, dim3(1), dim3(1), 0, st, w.range_err, n_out);
   if (!morton) {
     hipLaunchKernelGGL((uniq_write_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
                        batch_id, w.idx, w.slot, vals, out_coords, out_src, out_cap);
@@ -1658,7 +1675,7 @@ extern "C" int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const
 
 extern "C" size_t cnrma_voxelize_workspace_bytes(int64_t M) {
   int64_t n4 = (M + 3) / 4 * 4;
-  return (size_t)(n4 * 33) + sort_temp_bytes(M) + cnrma_scan_workspace_bytes(M) + 1024;
+  return (size_t)(n4 * 33) + sort_temp_bytes(M) + cnrma_scan_workspace_bytes(M) + 1024 + 256;
 }
 
 extern "C" int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, const int32_t* m_dev, int C,

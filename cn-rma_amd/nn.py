@@ -43,6 +43,19 @@ class MinkowskiConvolution(nn.Module):
             return y
         if shift is None and self.bias is not None:
             shift = self.bias.view(-1).contiguous()
+        if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad):
+            # fused epilogue requested while gradients are wanted (eval-mode fine-tuning with frozen BatchNorm, input-gradient
+            # analysis): the fused kernel has no backward -- the same result through the differentiable convolution + torch
+            y = S.conv_autograd(x, self.kernel, self.kernel_size, self.stride).F
+            if scale is not None:
+                y = y * scale.view(1, -1)
+            if shift is not None:
+                y = y + shift.view(1, -1)
+            if residual is not None:
+                y = y + (residual.F if isinstance(residual, S.SparseTensor) else residual)
+            y = torch.relu(y) if act == "relu" else (nn.functional.elu(y) if act == "elu" else y)
+            out_cs = x.cs if self.stride == 1 else x.cs.strided(self.stride)
+            return S.SparseTensor(y, out_cs)
         return S.conv(x, self.kernel, self.kernel_size, self.stride, scale, shift, residual, act)
 
 

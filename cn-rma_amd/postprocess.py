@@ -113,7 +113,7 @@ def indoor_eval(gt_annos, dt_annos, iou_thrs=(0.25, 0.5), n_classes=None, device
                     used = np.zeros(len(gb), dtype=bool)
                     for i in range(len(db)):
                         j = int(np.argmax(iou[i]))
-                        if iou[i, j] >= thr and not used[j]:
+                        if iou[i, j] > thr and not used[j]:      # strict, like mmdet3d's eval_det_cls
                             tp[i] = True
                             used[j] = True
                 scores.append(ds)

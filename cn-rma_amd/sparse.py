@@ -76,6 +76,9 @@ def _count(n_out, bound, lo=0):
     if plan is not None and plan.static:
         return plan.next_cap(bound, n_out, lo), n_out
     n = _lib.read_ints(n_out)[0]
+    if n < 0:
+        raise _lib.CnrmaError("voxelize: a point lies outside the coordinate-key range (|coord / voxel_size| >= 32767, NaN, "
+                              "or batch id >= 65536)")
     if plan is not None:
         plan.record(n)
     return n, None
@@ -505,9 +508,10 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
     return SparseTensor(out, out_cs, out_split)
 
 
+@torch.no_grad()
 def _conv_on_table(feats, n_out, nbr, weight, precision=None):
     """out [n_out, Cout] = sum_k feats[nbr[:, k]] @ weight[k] for an explicit neighbour table (None = identity, K == 1)"""
-    w = weight.contiguous().float()
+    w = weight.detach().contiguous().float()
     if w.dim() == 2:
         w = w.unsqueeze(0)
     K, Cin, Cout = w.shape
@@ -524,7 +528,7 @@ def _conv_on_table(feats, n_out, nbr, weight, precision=None):
     elif prec == "f16x3" and Cin % 32 == 0:
         amax = torch.zeros(_AMAX_WORDS, dtype=torch.float32, device=feats.device)
         call("cnrma_absmax_f32", ptr(feats), feats.shape[0], None, Cin, ptr(amax), stream())
-        call("cnrma_sparse_conv_f16x3", ptr(feats), ptr(amax), Cin, ptr(nbr), K, ptr(split_weights_f16(w)), Cout, None, None,
+        call("cnrma_sparse_conv_f16x3", ptr(feats), ptr(amax), Cin, ptr(nbr), K, ptr(split_weights_f16(weight)), Cout, None, None,
              None, 0, ptr(out), None, n_out, None, ptr(ws), ws_bytes, stream())
     else:
         call("cnrma_sparse_conv_f32", ptr(feats), Cin, ptr(nbr), K, ptr(w), Cout, None, None, None, 0, ptr(out), n_out, None,
@@ -541,7 +545,8 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(F, weight)
         precision = _precision(precision)          # resolved here: the backward runs outside the autocast region
         ctx.nbr, ctx.n_out, ctx.precision = nbr, n_out, precision
-        return _conv_on_table(F.detach().float(), n_out, nbr, weight.detach(), precision)
+        # the Parameter object itself goes down (its prepared image is cached on it until the optimiser changes it)
+        return _conv_on_table(F.detach().float(), n_out, nbr, weight, precision)
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -199,6 +199,8 @@ int cnrma_select_rows_f32(const float* points, int64_t M, int C, const int32_t* 
  * strided level).
  * hash_keys uint64[hash_cap], hash_vals int32[hash_cap]: open-addressing table, hash_cap a power of two >= 2*M;
  * on return it maps voxel key -> output row (reusable as the coordinate map of the level).
+ * A coordinate that does not fit the coordinate key (|coord / voxel_size| >= 32767, NaN, batch id >= 65536) makes the call
+ * report n_out[0] = -1 (the host raises; the static plan's status word flags it) instead of aliasing another voxel.
  * M = capacity of the input, m_dev (may be NULL) = device word with its live row count.  out_cap (0 = M): rows of the
  * output buffers; unique voxels beyond it are dropped and left unmapped (n_out still counts them: n_out > out_cap tells).
  * out_coords int32[Mu][4] (b,x,y,z), out_feats[Mu][C], out_src int32[Mu], n_out[0] = Mu (device).

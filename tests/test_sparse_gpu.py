@@ -550,3 +550,17 @@ def test_fcaf3d_trains_one_step(device):
     opt.step()
     l1, _ = loss_fn()
     assert float(l1.detach()) < float(l0.detach()), (float(l0.detach()), float(l1.detach()))
+
+
+def test_voxelize_reports_out_of_range_coordinates(device):
+    """coordinates beyond the 16-bit fields of the voxel key (or NaN) must not alias other voxels silently"""
+    from cnrma_amd import _lib
+    from cnrma_amd import sparse as S
+    pts = torch.rand(1000, 3, device=device)
+    f = torch.randn(1000, 8, device=device)
+    S.voxelize(pts, f, 0.01)                                   # fine
+    for bad in (400.0, float("nan"), -1e9):
+        p = pts.clone()
+        p[17, 1] = bad
+        with pytest.raises(_lib.CnrmaError):
+            S.voxelize(p, f, 0.01)

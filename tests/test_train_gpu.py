@@ -80,3 +80,24 @@ def test_train_step_under_bf16_autocast_tracks_the_fp32_step(device, tmp_path):
     cos = torch.nn.functional.cosine_similarity(g16, g32, dim=0)
     assert torch.isfinite(g16).all() and float(cos) > 0.98, float(cos)
     assert float(torch.nn.functional.cosine_similarity(f16, f32, dim=0)) > 0.95
+
+
+def test_eval_mode_forward_keeps_gradients_when_asked(device):
+    """eval mode (folded BatchNorm, fused epilogues) with autograd on -- frozen-BN fine-tuning, input-gradient analysis --
+    must not drop gradients silently: the fused convolution falls back to the differentiable one (same values)"""
+    from cnrma_amd import nn as snn
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(3)
+    c = np.unique(np.concatenate((np.zeros((3000, 1), dtype=np.int64), rng.randint(0, 24, size=(3000, 3)) * 2), axis=1), axis=0)
+    f = torch.from_numpy(rng.randn(len(c), 32).astype(np.float32)).to(device)
+    cs = S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 2)
+    blk = snn.BasicBlock(32, 32).to(device).eval()
+    with torch.no_grad():
+        for bn in (blk.norm1.bn, blk.norm2.bn):
+            bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+        ref = blk(S.SparseTensor(f, cs)).F                       # fused path
+    x = f.clone().requires_grad_(True)
+    y = blk(S.SparseTensor(x, cs)).F                            # grad enabled, eval mode
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    y.square().sum().backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) > 0 and blk.conv1.kernel.grad is not None
