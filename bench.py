@@ -37,7 +37,14 @@ MFMA_F16_PEAK_TFLOPS = 2500.0
 # HBM-side traffic of the dominant kernel per launch from the PMC passes committed under profiles/ (separate rocprofv3
 # --pmc runs: FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM" -- + WRITE_SIZE)
 PMC_TRAFFIC = {
-    # (workload, kernel) -> (bytes per launch, source)   -- filled from profiles/r02_* (see profiles/README.md)
+    # (workload, kernel) -> (bytes per launch, source): per-kernel sums of the passes / launches (profiles/README.md)
+    ("NS", "dense"): (83.0e9, "profiles/r02_ns_pmc_FETCH_SIZE.csv (x2) + r02_ns_pmc_WRITE_SIZE.csv: 36.96e6 KB x 2 + 7.14e6 KB "
+                              "per launch; L2<->fabric traffic, i.e. Infinity Cache + HBM (TCC hit rate 22 %, "
+                              "r02_ns_pmc_TCC_HIT_MISS.csv)"),
+    ("NS", "conv"): (318.5e6, "profiles/r02_ns_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches"),
+    ("S", "dense"): (3.15e9, "profiles/r02_s_pmc_FETCH_SIZE.csv (x2) + r02_s_pmc_WRITE_SIZE.csv"),
+    ("S", "conv"): (196.3e6, "profiles/r02_s_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches "
+                             "(10.0 GB per scene, L2<->fabric: the operands are Infinity-Cache resident)"),
 }
 
 
@@ -499,11 +506,13 @@ def profile_block(wl, block, name):
     else:
         tr = PMC_TRAFFIC.get((name, "conv"))
         roof = dict(kernel="sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_f16x3), all launches of one scene",
-                    bound="mfma", achieved=3.0 * F_alg / 1e9 / conv_ms, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=3.0 * F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS, traffic=tr[0] if tr else None,
+                    bound="mfma", achieved=F_alg / 1e9 / conv_ms, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS, traffic=tr[0] if tr else None,
                     traffic_source=tr[1] if tr else None, launch_ms=conv_ms / max(1, len(layers)),
-                    note="achieved = 3 x algorithmic flops (2*pairs*Cin*Cout; 3 fp16 products per fp32 product) / summed launch "
-                         f"time; fp32-equivalent {F_alg / 1e9 / conv_ms:.1f} TFLOP/s")
+                    frac_counting_the_3_fp16_products=3.0 * F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS,
+                    note="achieved = algorithmic flops (2*pairs*Cin*Cout per layer, SURVEY 8d) / summed launch time, priced "
+                         "against the dense fp16 MFMA peak; the f16x3 arithmetic issues 3 fp16 products per fp32 product, "
+                         "so the MFMA pipe itself runs at 3x this fraction")
     return roof
 
 

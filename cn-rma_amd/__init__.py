@@ -1,6 +1,6 @@
 """cn-rma_amd: MI355X-native hot path of CN-RMA (ray-marching aggregation + sparse FCAF3D forward).
 
-Imported as ``cnrma_amd`` through the root-level shim ``cnrma_amd.py``.
+Imported as ``cnrma_amd``: the package ``../cnrma_amd/`` lists this directory in its ``__path__``.
 Layout:
   csrc/        hand-written HIP (gfx950) kernels + the C-ABI (declared in ../include/cnrma.h)
   _lib.py      ctypes loader of csrc/libcnrma_hip.so (fails loudly when missing)
@@ -8,4 +8,4 @@ Layout:
   sparse.py    sparse tensor + operators replacing the MinkowskiEngine surface (a9-a11)
   synth.py     deterministic synthetic scene generator
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
