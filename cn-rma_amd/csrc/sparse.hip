@@ -386,6 +386,9 @@ struct ConvArgs {
   // f16x3: upper bounds of |features| / |weights| (device scalars) that fix the power-of-two operand scales, and the
   // running maximum of |outputs| for the consumers of this layer (atomicMax on the bit pattern; pre-zeroed by the host)
   const float* in_amax; const float* w_amax; float* out_amax;
+  // pair-list mode (cnrma_sparse_conv_pairs_f16x3): the rows are (output, input) pairs grouped by kernel offset in runs
+  // padded to 128 rows; tile_tap[row / 128] = the offset whose weights the run uses, w_taps = offsets in the image
+  const int32_t* tile_tap; int w_taps;
 };
 
 // exact 3-way split by truncation: h = top 8 significant bits of a, m = next 8, l = last 8 (a == h + m + l)
@@ -931,8 +934,9 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   const int zs = blockIdx.z;
   const int Cin = p.Cin, Cout = p.Cout, K = p.K;
   const int Cout_p = conv_cout_padded(Cout);     // prepared images pad Cout with zero rows: no bounds check on B
-  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * K * Cin * Cout_p;
-  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout_p : 0);
+  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * (p.tile_tap ? p.w_taps : K) * Cin * Cout_p;
+  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout_p : 0) +
+                     (p.tile_tap ? (int64_t)p.tile_tap[tile0 >> 7] * Cin * Cout_p : 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid / WAVES_N, wc = wid % WAVES_N;
   float a_scale = 1.0f, out_scale = 1.0f;
@@ -1211,18 +1215,20 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
                 const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
                 int slices, void* workspace, size_t ws_bytes, hipStream_t st, const void* weight_split = nullptr,
                 const void* in_split = nullptr, int64_t in_zero_row = 0, void* out_split = nullptr,
-                int64_t out_zero_row = 0, int mode = 0, const float* in_amax = nullptr, float* out_amax = nullptr) {
+                int64_t out_zero_row = 0, int mode = 0, const float* in_amax = nullptr, float* out_amax = nullptr,
+                const int32_t* tile_tap = nullptr, int w_taps = 0) {
   if (Cin <= 0 || Cout <= 0 || K <= 0 || K > 27 || no_cap <= 0) return CNRMA_EINVAL;
   if (out_split != nullptr && (Cout % 8 != 0 || weight_split == nullptr)) return CNRMA_EINVAL;
   if (in_split != nullptr && (Cin % 32 != 0 || weight_split == nullptr)) return CNRMA_EINVAL;
   ConvArgs p{in, Cin, nbr, K, weight, Cout, scale, shift, residual, act, out, no_cap, no_dev, slices, 1, K,
              reinterpret_cast<float*>(workspace), reinterpret_cast<const uint16_t*>(in_split), in_zero_row,
-             reinterpret_cast<uint16_t*>(out_split), out_zero_row, in_amax, nullptr, out_amax};
+             reinterpret_cast<uint16_t*>(out_split), out_zero_row, in_amax, nullptr, out_amax, tile_tap, w_taps};
   if (mode == 2 && (weight_split == nullptr || in_split != nullptr || out_split != nullptr)) return CNRMA_EINVAL;
   if (mode == 1) {
     if (weight_split == nullptr || in_amax == nullptr || in_split != nullptr || out_split != nullptr) return CNRMA_EINVAL;
     p.w_amax = reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(weight_split) +
-                                              2 * (int64_t)(slices > 1 ? slices : 1) * K * Cin * conv_cout_padded(Cout));
+                                              2 * (int64_t)(slices > 1 ? slices : 1) * (tile_tap ? w_taps : K) * Cin *
+                                                  conv_cout_padded(Cout));
   }
   int bm, bn;
   // tile choice, measured per layer class and precision on MI355X at the ScanNet shape: f16x3 tiles
@@ -1831,6 +1837,198 @@ extern "C" int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K,
   blocks = ceil_div(total, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(prep_weights_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, wt, K, Cin, Cout, amax);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---- pair-list convolution: layers whose kernel map is nearly empty -----------------------------------------------------
+// The output-stationary kernel multiplies a whole 64/128-row tile by W[k] as soon as ONE row of the tile has a neighbour
+// at offset k.  In the stem (stride 2 on a point sample: 1.3-1.5 pairs per output row, 5 % of the 27 x N_out table) every
+// tile has every offset, i.e. 95 % of the matrix work multiplies zero rows.  Here the table is regrouped instead: the
+// valid (output o, offset k) entries become rows of a pair list sorted by k (runs padded to 128 rows with -1), the same
+// MFMA kernel runs over that list as a K = 1 convolution whose weight slice is chosen per 128-row run (tile_tap), and a
+// second kernel adds every output row's pair products in ascending k -- a fixed order, so results are deterministic --
+// and applies the fused epilogue.  Slots inside a run are handed out by atomics: the layout of the list varies from run to
+// run, the values do not (a GEMM row does not depend on its neighbours).
+constexpr int PAIR_HDR = 128;      // ints: cnt[32] | fill[32] | base[33] | n_vrows
+
+constexpr int PAIR_EPT = 32;                    // table entries per thread and chunk (chunk = 8192 entries per block)
+
+// k of flat table index t (t < 2^31: the pair slots are int32)
+__device__ __forceinline__ int tap_of(unsigned t, int K) { return K == 27 ? (int)(t % 27u) : (int)(t % (unsigned)K); }
+
+__global__ __launch_bounds__(256) void pairs_count_kernel(const int32_t* __restrict__ nbr, int64_t no_cap,
+                                                          const int32_t* __restrict__ no_dev, int K, int32_t* __restrict__ hdr) {
+  __shared__ int hist[32];
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned total = (unsigned)(live_rows(no_cap, no_dev) * K);
+  const unsigned base = blockIdx.x * (256u * PAIR_EPT);
+#pragma unroll 8
+  for (int j = 0; j < PAIR_EPT; ++j) {
+    const unsigned t = base + j * 256u + threadIdx.x;
+    if (t < total && nbr[t] >= 0) atomicAdd(&hist[tap_of(t, K)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < K && hist[threadIdx.x]) atomicAdd(&hdr[threadIdx.x], hist[threadIdx.x]);
+}
+
+// one block: run bases (multiples of 128), the tap of every 128-row run, the padded row count; padding rows get -1
+__global__ __launch_bounds__(256) void pairs_plan_kernel(int K, int32_t* __restrict__ hdr, int32_t* __restrict__ tile_tap,
+                                                         int32_t* __restrict__ pair_src, int64_t pair_cap) {
+  __shared__ int base[33];
+  if (threadIdx.x == 0) {
+    int b = 0;
+    for (int k = 0; k < K; ++k) {
+      base[k] = b;
+      b += (hdr[k] + 127) & ~127;
+    }
+    base[K] = b;
+    for (int k = 0; k <= K; ++k) hdr[64 + k] = base[k];
+    hdr[64 + 33] = (int64_t)b <= pair_cap ? b : (int)pair_cap;       // b <= pair_cap by construction of the capacity
+  }
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const int lo = base[k], hi = base[k + 1], live = lo + hdr[k];
+    for (int t = lo / 128 + threadIdx.x; t < hi / 128; t += 256) tile_tap[t] = k;
+    for (int r = live + threadIdx.x; r < hi; r += 256) pair_src[r] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t* __restrict__ nbr, int64_t no_cap,
+                                                         const int32_t* __restrict__ no_dev, int K, int32_t* __restrict__ hdr,
+                                                         int32_t* __restrict__ pair_src, int32_t* __restrict__ pos) {
+  // slot = run base + one global reservation per offset and 8192-entry chunk + rank inside the chunk (LDS atomics):
+  // per-entry global atomics on 27 words serialise at the memory side (3 ms for 660 k entries)
+  __shared__ int hist[32], gbase[32];
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned total = (unsigned)(live_rows(no_cap, no_dev) * K);
+  const unsigned base = blockIdx.x * (256u * PAIR_EPT);
+  int32_t src[PAIR_EPT];
+#pragma unroll
+  for (int j = 0; j < PAIR_EPT; ++j) {
+    const unsigned t = base + j * 256u + threadIdx.x;
+    src[j] = t < total ? nbr[t] : -1;
+    if (src[j] >= 0) atomicAdd(&hist[tap_of(t, K)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int c = hist[threadIdx.x];
+    gbase[threadIdx.x] = c ? hdr[64 + threadIdx.x] + atomicAdd(&hdr[32 + threadIdx.x], c) : 0;
+    hist[threadIdx.x] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PAIR_EPT; ++j) {
+    const unsigned t = base + j * 256u + threadIdx.x;
+    if (t < total) {
+      int32_t slot = -1;
+      if (src[j] >= 0) {
+        const int k = tap_of(t, K);
+        slot = gbase[k] + atomicAdd(&hist[k], 1);
+        pair_src[slot] = src[j];
+      }
+      pos[t] = slot;
+    }
+  }
+}
+
+// out[o] = epilogue(sum over k ascending of prod[pos[o][k]]); 4 columns per thread
+template <int KT>
+__global__ __launch_bounds__(256) void pairs_reduce_kernel(ConvArgs p, const int32_t* __restrict__ pos,
+                                                           const float* __restrict__ prod) {
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int C4 = p.Cout >> 2;
+  const int64_t total = n_live * C4;
+  const int K = KT > 0 ? KT : p.K;
+  float mx = 0.0f;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / C4;
+    const int col = (int)(t % C4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t* po = pos + o * K;
+    if constexpr (KT > 0) {
+      int32_t r[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) r[k] = po[k];            // independent loads first, then the (few) product rows
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+        if (r[k] >= 0) {
+          const float4 q = *reinterpret_cast<const float4*>(prod + (int64_t)r[k] * p.Cout + col);
+          s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const int32_t r = po[k];
+        if (r >= 0) {
+          const float4 q = *reinterpret_cast<const float4*>(prod + (int64_t)r * p.Cout + col);
+          s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+      }
+    }
+    float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j];
+      if (p.scale) x = x * p.scale[col + j];
+      if (p.shift) x = x + p.shift[col + j];
+      if (p.residual) x = x + p.residual[o * p.Cout + col + j];
+      v[j] = apply_act(x, p.act);
+      mx = fmaxf(mx, fabsf(v[j]));
+    }
+    *reinterpret_cast<float4*>(p.out + o * p.Cout + col) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (p.out_amax != nullptr) {
+    __shared__ float sh4[4];
+    block_amax_publish(p.out_amax, mx, sh4);
+  }
+}
+
+static size_t pairs_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t cnrma_sparse_conv_pairs_workspace_bytes(int64_t no_cap, int K, int Cout, int64_t pair_cap) {
+  if (no_cap <= 0 || K <= 0 || Cout <= 0 || pair_cap <= 0) return 0;
+  return pairs_align(PAIR_HDR * 4) + pairs_align((size_t)(pair_cap / 128 + 1) * 4) + pairs_align((size_t)pair_cap * 4) +
+         pairs_align((size_t)no_cap * K * 4) + pairs_align((size_t)pair_cap * Cout * 4);
+}
+
+extern "C" int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float* in_amax, int Cin, const int32_t* nbr, int K,
+                                             const void* weight_split, int Cout, const float* scale, const float* shift,
+                                             const float* residual, int act, float* out_feats, float* out_amax,
+                                             int64_t no_cap, const int32_t* no_dev, int64_t pair_cap, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  if (weight_split == nullptr || Cin % 32 != 0 || Cout % 4 != 0 || in_feats == nullptr || in_amax == nullptr || nbr == nullptr ||
+      K <= 1 || K > 27 || no_cap <= 0 || pair_cap <= 0 || pair_cap % 128 != 0 || pair_cap > 0x7fffff00LL)
+    return CNRMA_EINVAL;
+  if (workspace == nullptr || workspace_bytes < cnrma_sparse_conv_pairs_workspace_bytes(no_cap, K, Cout, pair_cap))
+    return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  char* w = reinterpret_cast<char*>(workspace);
+  int32_t* hdr = reinterpret_cast<int32_t*>(w);        w += pairs_align(PAIR_HDR * 4);
+  int32_t* tile_tap = reinterpret_cast<int32_t*>(w);   w += pairs_align((size_t)(pair_cap / 128 + 1) * 4);
+  int32_t* pair_src = reinterpret_cast<int32_t*>(w);   w += pairs_align((size_t)pair_cap * 4);
+  int32_t* pos = reinterpret_cast<int32_t*>(w);        w += pairs_align((size_t)no_cap * K * 4);
+  float* prod = reinterpret_cast<float*>(w);
+  const hipError_t fe = cnrma_fill_bytes(hdr, 0, PAIR_HDR * 4, st);
+  if (fe != hipSuccess) return -(int)fe;
+  if (no_cap * K >= 0x7fffffffLL) return CNRMA_EINVAL;
+  const int64_t blocks = ceil_div(no_cap * K, 256 * PAIR_EPT);
+  hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr);
+  hipLaunchKernelGGL(pairs_plan_kernel, dim3(1), dim3(256), 0, st, K, hdr, tile_tap, pair_src, pair_cap);
+  hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr, pair_src, pos);
+  CNRMA_LAUNCH_CHECK();
+  const int rc = launch_conv(in_feats, Cin, pair_src, 1, nullptr, Cout, nullptr, nullptr, nullptr, 0, prod, pair_cap, hdr + 64 + 33,
+                             1, nullptr, 0, st, weight_split, nullptr, 0, nullptr, 0, 1, in_amax, nullptr, tile_tap, K);
+  if (rc != 0) return rc;
+  ConvArgs p{};
+  p.K = K; p.Cout = Cout; p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.out = out_feats;
+  p.no_cap = no_cap; p.no_dev = no_dev; p.out_amax = out_amax;
+  int64_t rb = ceil_div(no_cap * (Cout / 4), 256);
+  if (rb > 16384) rb = 16384;
+  if (K == 27) hipLaunchKernelGGL(pairs_reduce_kernel<27>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);
+  else hipLaunchKernelGGL(pairs_reduce_kernel<0>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

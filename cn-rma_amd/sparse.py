@@ -459,6 +459,26 @@ def split_weights(weight):
     return ws
 
 
+PAIR_CONV = True     # pair-list kernel for stride-2 convolutions whose kernel map is nearly empty (the stem)
+# regrouping the table costs ~0.2 ms per 450 k output rows (count, plan, fill, reduce: MI355X); the tile kernel wastes
+# 27 x Cin / 32 stages per tile on empty offsets -- measured break-even between Cin = 32 (tile kernel 0.18 ms, pair list
+# 0.29 ms) and Cin = 256 (1.23 ms vs 0.45 ms)
+PAIR_CONV_MIN_CIN = 128
+
+
+def _nearly_empty_map(in_cs, out_cs):
+    """stride-2 convolution: an input row is a neighbour of <= 2 outputs per axis (27 / 8 on average), so the table is
+    at most 3.4 N_in / (27 N_out) full.  True when that bound is below 20 % -- the coarsening merged almost nothing, i.e.
+    the input is a sparse point sample.  A recorded branch of the size plan (the static trace has capacities, not counts)."""
+    p = P.current()
+    if p is not None and p.static:
+        return bool(p.next_flag())                       # None (calibration scenes disagreed) -> the tile kernel
+    f = 3.375 * in_cs.n < 0.2 * 27 * out_cs.n
+    if p is not None:
+        p.record_flag(f)
+    return f
+
+
 def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=None, act=None, precision=None):
     """MinkowskiConvolution + fused epilogue: out = act((sum_k in[nbr] @ W[k]) * scale + shift + residual).
     weight [K,Cin,Cout] (or [Cin,Cout] when K == 1)."""
@@ -489,6 +509,15 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             return SparseTensor(out, out_cs)
         if prec == "f16x3" and Cin % 32 == 0:
             out_amax = _amax_slot(x.device)
+            if PAIR_CONV and stride == 2 and K == 27 and Cout % 4 == 0 and Cin >= PAIR_CONV_MIN_CIN and _nearly_empty_map(in_cs, out_cs):
+                # pair-list kernel: the kernel map of a stride-2 convolution on a point sample is ~5 % full
+                pair_cap = (min(27 * out_cs.n, 8 * in_cs.n) + 128 * K + 127) // 128 * 128
+                pw_bytes = _lib.load().cnrma_sparse_conv_pairs_workspace_bytes(out_cs.n, K, Cout, pair_cap)
+                pw = _workspace(pw_bytes, x.device)
+                call("cnrma_sparse_conv_pairs_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
+                     ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),
+                     out_cs.n, ptr(out_cs.n_dev), pair_cap, ptr(pw), pw_bytes, stream())
+                return SparseTensor(out, out_cs, None, out_amax)
             call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
                  ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),
                  out_cs.n, ptr(out_cs.n_dev), ptr(ws), ws_bytes, stream())

@@ -290,6 +290,23 @@ int cnrma_sparse_convtr_gen_bf16x6(const int32_t* in_coords, const float* in_fea
                                    const float* scale, const float* shift, int act, int32_t* out_coords,
                                    float* out_feats, void* out_split, void* stream);
 
+/* Pair-list variant of cnrma_sparse_conv_f16x3 for layers whose kernel map is nearly empty (the stem: a stride-2
+ * convolution on a point sample has 1.3-1.5 neighbours per output row, so every row tile of the output-stationary kernel
+ * carries all 27 offsets and 95 % of its matrix work multiplies zero rows).  The valid (output, offset) entries of `nbr`
+ * are regrouped into a list sorted by offset (runs padded to 128 rows), the MFMA kernel runs over that list with the
+ * weight slice chosen per run, and every output row adds its products in ascending offset order (deterministic) before
+ * the fused epilogue.  Same operands, same result contract as cnrma_sparse_conv_f16x3 (replaces the same
+ * ME.MinkowskiConvolution call: fcaf3d_backbone.py:79-80 of the reference).  pair_cap: capacity of the list, a multiple
+ * of 128 and >= (number of valid entries) + 128 * K -- for a stride-2 convolution min(27 * N_out, 8 * N_in) + 128 * K is a
+ * provable bound (an input row is a neighbour of at most 2 outputs per axis).  workspace:
+ * cnrma_sparse_conv_pairs_workspace_bytes(no_cap, K, Cout, pair_cap) bytes. */
+size_t cnrma_sparse_conv_pairs_workspace_bytes(int64_t no_cap, int K, int Cout, int64_t pair_cap);
+int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float* in_amax, int Cin, const int32_t* nbr, int K,
+                                  const void* weight_split, int Cout, const float* scale, const float* shift,
+                                  const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
+                                  const int32_t* no_dev, int64_t pair_cap, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* 22-bit convolution on the fp16 matrix cores ("f16x3"): each operand is scaled by a power of two taken from an upper
  * bound of its tensor's magnitude (so that the largest element sits at 2^13..2^14) and split into two fp16 pieces
  * a 2^s = h + m (round to nearest: |a 2^s - h - m| <= 2^-22 |a 2^s|); the products hh + hm + mh are accumulated in fp32 and

@@ -15,6 +15,9 @@ res = {}
 for rep in range(3):
     for mode in ("0", "1"):
         os.environ[var] = mode
+        if var == "PAIR_CONV":
+            from cnrma_amd import sparse as S
+            S.PAIR_CONV = mode == "1"
         out = pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
         prof = bench.KernelProfile(); prof.install()
         try:
