@@ -1484,10 +1484,15 @@ __global__ __launch_bounds__(256) void union_copy_a_kernel(const int32_t* __rest
                                                            int32_t* __restrict__ out_coords,
                                                            float* __restrict__ out_feats) {
   const int64_t n = live_rows(na_cap, na_dev);
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x)
-    out_feats[t] = a_feats[t];
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * 4; t += (int64_t)gridDim.x * blockDim.x)
-    out_coords[t] = a_coords[t];
+  if ((C & 3) == 0) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * (C >> 2); t += (int64_t)gridDim.x * blockDim.x)
+      reinterpret_cast<float4*>(out_feats)[t] = reinterpret_cast<const float4*>(a_feats)[t];
+  } else {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x)
+      out_feats[t] = a_feats[t];
+  }
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    reinterpret_cast<int4*>(out_coords)[t] = reinterpret_cast<const int4*>(a_coords)[t];
 }
 
 __global__ __launch_bounds__(256) void union_merge_b_kernel(const int32_t* __restrict__ b_coords,
@@ -1504,6 +1509,32 @@ __global__ __launch_bounds__(256) void union_merge_b_kernel(const int32_t* __res
   const int64_t nb = live_rows(nb_cap, nb_dev);
   const int64_t na = live_rows(na_cap, na_dev);
   if (blockIdx.x == 0 && threadIdx.x == 0) n_out[0] = (int32_t)(na + n_new[0]);
+  if ((C & 3) == 0) {                                         // 4 channels per thread
+    const int C4 = C >> 2;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nb * C4; t += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t i = t / C4;
+      const int c = (int)(t - i * C4) * 4;
+      const int32_t m = match[i];
+      const float4 v = *reinterpret_cast<const float4*>(b_feats + i * C + c);
+      if (m >= 0) {
+        float4* d = reinterpret_cast<float4*>(out_feats + (int64_t)m * C + c);     // unique coords in B: one writer per element
+        float4 o = *d;
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        *d = o;
+      } else {
+        const int64_t row = na + idx[i];
+        if (row >= out_cap) continue;                           // over the planned capacity: dropped (n_out tells)
+        *reinterpret_cast<float4*>(out_feats + row * C + c) = v;
+        if (c == 0) {
+          int4 cc = reinterpret_cast<const int4*>(b_coords)[i];
+          reinterpret_cast<int4*>(out_coords)[row] = cc;
+          int64_t s = hash_insert(keys, cap, coord_key(cc.x, cc.y, cc.z, cc.w));
+          if (s >= 0) vals[s] = (int32_t)row;
+        }
+      }
+    }
+    return;
+  }
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nb * C; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / C;
     const int c = (int)(t - i * C);
