@@ -112,14 +112,26 @@ class RayMarching(MultiViewBase):
         self.points_detection = []
         for b in range(B):
             pinv = rma.projection_inverse(projections[:, b].cpu(), self.backbone2d_stride).to(features.device)
+            # point_sampler="device": the max_points selection of switch_pointcloud (:360-405) is drawn on the GPU and fused
+            # into the aggregation -- only the selected rows are emitted (the reference's numpy draw of 500 k out of
+            # ~4 M indices alone costs 45 ms of host time per scene); "numpy" keeps the reference's RNG stream
+            fused = self.point_sampler == "device" and self.max_points is not None and self.ray_marching_type == "neus"
             if torch.is_grad_enabled() and features.requires_grad and self.ray_marching_type == "neus":
                 # training: the gradient of the aggregated features flows back into the 2D feature maps (:793-797)
                 coords, feats = rma.AggregatePoints.apply(features[:, b], pinv, tsdf[b, 0].detach(), self.voxel_dim,
                                                           self.voxel_size, self.origin.view(-1).tolist(), 300,
-                                                          self.neus_threshold, (0.0, 0.0, 0.0), None, "numpy", None)
+                                                          self.neus_threshold, (0.0, 0.0, 0.0),
+                                                          self.max_points if fused else None,
+                                                          "device" if fused else "numpy", None)
                 self.points_detection.append(torch.cat((coords, feats), dim=1))
                 continue
             nhwc = rma.to_nhwc(features[:, b])
+            if fused:
+                coords, feats, _ = rma.aggregate_points(nhwc, pinv, tsdf[b, 0], self.voxel_dim, self.voxel_size,
+                                                        self.origin.view(-1).tolist(), 300, self.neus_threshold, "neus", 0,
+                                                        (0.0, 0.0, 0.0), self.max_points, "device")
+                self.points_detection.append(torch.cat((coords, feats), dim=1))
+                continue
             pts, _ = rma.aggregate_rows(nhwc, pinv, tsdf[b, 0], self.voxel_dim, self.voxel_size,
                                         self.origin.view(-1).tolist(), 300, self.neus_threshold,
                                         self.ray_marching_type, self.depth_points)
@@ -130,7 +142,7 @@ class RayMarching(MultiViewBase):
         coords, feats, new_gt = [], [], []
         for b in range(len(points)):
             mask = None
-            if self.max_points is not None:
+            if self.max_points is not None and points[b].shape[0] > self.max_points:
                 mask = sample_points(points[b], max_points=self.max_points)        # numpy global RNG, like the reference
             off = offsets[b].view(-1).tolist()
             if torch.is_grad_enabled() and points[b].requires_grad:      # training: keep the autograd graph of the features

@@ -14,7 +14,7 @@ cfg = runpy.run_path(os.path.join(root, "projects", "configs", "mvsdetection", "
 m = dict(cfg["model"])
 m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)
 m.update(save_path="/tmp/cnrma_train_probe", voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]),
-         use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34))
+         use_feature_transform=False, point_sampler=os.environ.get("CNRMA_SAMPLER", "device"), detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34))
 torch.manual_seed(0)
 model = build_model(m)
 model.detection_backbone.init_weights(); model.detection_head.init_weights()
@@ -41,4 +41,11 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 5
 for _ in range(n): l = step()
 torch.cuda.synchronize()
+if os.environ.get("CNRMA_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(3): step()
+    torch.cuda.synchronize(); pr.disable()
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+    st.sort_stats("cumulative").print_stats(45)
 print(f"{shape} ({'bf16 autocast' if AUTOCAST else 'fp32'}): {(time.perf_counter() - t0) / n * 1e3:.1f} ms per training step, loss {l:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")

@@ -121,8 +121,10 @@ def test_raymarching_with_atlas3d_predicts_its_own_tsdf(device, tmp_path):
     assert os.path.exists(tmp_path / "r" / "s" / "s_bbox_raw.npz")
 
 
-def test_raymarching_train_step(device, tmp_path):
-    """SURVEY.md 8f rank 3 end to end: train_step of the registered detector on a synthetic scene with ground-truth boxes --
+@pytest.mark.parametrize("sampler,max_points", [("numpy", None), ("device", 3000), ("numpy", 3000)])
+def test_raymarching_train_step(device, tmp_path, sampler, max_points):
+    """(point_sampler="device": the max_points selection is drawn on the GPU and fused into the aggregation)
+    SURVEY.md 8f rank 3 end to end: train_step of the registered detector on a synthetic scene with ground-truth boxes --
     differentiable aggregation (gradient reaches the 2D feature maps), sparse network on the dgrad / wgrad kernels, FCAF3D
     assignment + centerness / IoU / focal losses; a few SGD steps on the same scene lower the loss"""
     import projects.mvsdetection  # noqa: F401
@@ -133,9 +135,10 @@ def test_raymarching_train_step(device, tmp_path):
     cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
     m = dict(cfg["model"])
     m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None)      # hot path only: features / TSDF come in
-    m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=None,
-             use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14))
+    m.update(save_path=str(tmp_path / "r"), voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), max_points=max_points,
+             point_sampler=sampler, use_feature_transform=False, detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=14))
     torch.manual_seed(2)
+    np.random.seed(3)
     model = build_model(m)
     model.detection_backbone.init_weights()
     model.detection_head.init_weights()
@@ -155,6 +158,8 @@ def test_raymarching_train_step(device, tmp_path):
         if feats.grad is not None:
             feats.grad = None
         out["loss"].backward()
+        if max_points is not None:
+            assert model.points_detection[0].shape[0] <= max(max_points, 0) or sampler == "numpy"
         if it == 0:
             assert feats.grad is not None and torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
             assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
