@@ -69,6 +69,7 @@ SIGNATURES = {
     "cnrma_sparse_kernel_map_transpose": (c_int, [P, L, P, I, L, P, P]),
     "cnrma_sparse_conv_wgrad_chunks": (c_int, [L, I]),
     "cnrma_sparse_conv_wgrad_f32": (c_int, [P, I, P, I, P, I, L, P, I, P, P]),
+    "cnrma_sparse_conv_wgrad_bf16": (c_int, [P, I, P, I, P, I, L, P, I, P, P]),
     "cnrma_sparse_convtr_gen_f32": (c_int, [P, P, L, P, I, I, P, I, P, P, I, P, P, P]),
     "cnrma_sparse_maxpool_f32": (c_int, [P, I, P, I, P, L, P, P]),
     "cnrma_instnorm_workspace_bytes": (c_size_t, [I]),

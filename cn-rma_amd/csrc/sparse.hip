@@ -1681,6 +1681,78 @@ __global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict_
     }
 }
 
+// the same tile in bf16 (autocast training): operands rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16 --
+// 16 rows per MFMA instead of 2, so the matrix pipe is no longer the limiter (the gathers are).  Lane (m, kh) holds rows
+// 8 kh .. 8 kh + 7 of a 16-row step for channel m: A[m][k] = in[src(row k)][ci0 + m], B[k][n] = gout[row k][co0 + n].
+__global__ __launch_bounds__(64) void conv_wgrad_bf16_kernel(const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr,
+                                                             int K, const float* __restrict__ gout, int Cout, int64_t no_cap,
+                                                             const int32_t* __restrict__ no_dev, int rows_per_chunk,
+                                                             float* __restrict__ slab) {
+  const int64_t n_live = live_rows(no_cap, no_dev);
+  const int chunk = blockIdx.x, k = blockIdx.y;
+  const int tiles_co = (Cout + 63) / 64;
+  const int ci0 = (blockIdx.z / tiles_co) * 64, co0 = (blockIdx.z % tiles_co) * 64;
+  const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  const int64_t r1 = min(n_live, r0 + rows_per_chunk);
+  // out-of-range channels / missing rows load from a clamped (valid) address and are zeroed AFTER all loads of the step
+  // are in flight: a select right behind each load makes the compiler wait for every load in turn
+  const bool ci_ok0 = ci0 + m < Cin, ci_ok1 = ci0 + 32 + m < Cin, co_ok0 = co0 + m < Cout, co_ok1 = co0 + 32 + m < Cout;
+  const int ca0 = ci_ok0 ? ci0 + m : 0, ca1 = ci_ok1 ? ci0 + 32 + m : 0, cb0 = co_ok0 ? co0 + m : 0, cb1 = co_ok1 ? co0 + 32 + m : 0;
+  for (int64_t o0 = r0; o0 < r1; o0 += 32) {
+    int32_t src_l = -1;                                   // lane l < 32: input row of output row o0 + l at this offset
+    if (lane < 32 && o0 + lane < r1) src_l = nbr ? nbr[(o0 + lane) * K + k] : (int32_t)(o0 + lane);
+    float a0[16], a1[16], b0[16], b1[16];                 // [q]: row 16 (q >> 3) + 8 kh + (q & 7)
+    unsigned ok_a = 0, ok_b = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = 16 * (q >> 3) + 8 * kh + (q & 7);
+      const int32_t src = __shfl(src_l, row, 64);
+      const bool live = o0 + row < r1;
+      const float* ap = in + (int64_t)(src < 0 ? 0 : src) * Cin;
+      const float* gp = gout + (live ? o0 + row : r0) * Cout;
+      a0[q] = ap[ca0]; a1[q] = ap[ca1];
+      b0[q] = gp[cb0]; b1[q] = gp[cb1];
+      ok_a |= (src >= 0 ? 1u : 0u) << q;
+      ok_b |= (live ? 1u : 0u) << q;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8_t fa0, fa1, fb0, fb1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = 8 * t + j;
+        const bool oa = (ok_a >> q) & 1u, ob = (ok_b >> q) & 1u;
+        fa0[j] = (__bf16)(oa && ci_ok0 ? a0[q] : 0.0f); fa1[j] = (__bf16)(oa && ci_ok1 ? a1[q] : 0.0f);
+        fb0[j] = (__bf16)(ob && co_ok0 ? b0[q] : 0.0f); fb1[j] = (__bf16)(ob && co_ok1 ? b1[q] : 0.0f);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+  }
+  float* dst = slab + ((int64_t)chunk * K + k) * Cin * Cout;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int co = co0 + y * 32 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[x][y][i];
+      }
+    }
+}
+
 extern "C" int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K,
                                                  int64_t n_in, int32_t* nbr_t, void* stream) {
   if (no_cap <= 0 || K <= 0 || n_in <= 0 || nbr == nullptr || nbr_t == nullptr) return CNRMA_EINVAL;
@@ -1706,6 +1778,19 @@ extern "C" int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const
   const unsigned tiles = (unsigned)(ceil_div(Cin, 64) * ceil_div(Cout, 64));
   hipLaunchKernelGGL(conv_wgrad_kernel, dim3(chunks, (unsigned)K, tiles), dim3(64), 0, as_stream(stream), in_feats, Cin, nbr,
                      K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out,
+                                            int Cout, int64_t no_cap, const int32_t* no_dev, int rows_per_chunk,
+                                            float* slabs, void* stream) {
+  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0 || rows_per_chunk <= 0 || (rows_per_chunk & 1) || slabs == nullptr)
+    return CNRMA_EINVAL;
+  const unsigned chunks = (unsigned)ceil_div(no_cap, rows_per_chunk);
+  const unsigned tiles = (unsigned)(ceil_div(Cin, 64) * ceil_div(Cout, 64));
+  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(chunks, (unsigned)K, tiles), dim3(64), 0, as_stream(stream), in_feats, Cin,
+                     nbr, K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

@@ -606,8 +606,9 @@ class _ConvFn(torch.autograd.Function):
             chunks = _lib.load().cnrma_sparse_conv_wgrad_chunks(max(n_out, 1), rows)
             slabs = torch.zeros((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
             if n_out:
-                call("cnrma_sparse_conv_wgrad_f32", ptr(F.detach().contiguous().float()), Cin, ptr(nbr), K, ptr(g), Cout,
-                     n_out, None, rows, ptr(slabs), stream())
+                # under autocast(bf16) the weight gradient is a bf16 x bf16 -> fp32 reduction too (what AMP computes)
+                call("cnrma_sparse_conv_wgrad_bf16" if ctx.precision == "bf16" else "cnrma_sparse_conv_wgrad_f32",
+                     ptr(F.detach().contiguous().float()), Cin, ptr(nbr), K, ptr(g), Cout, n_out, None, rows, ptr(slabs), stream())
             grad_W = slabs.sum(dim=0).view(weight.shape)
         return grad_F, grad_W, None, None, None
 

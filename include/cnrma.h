@@ -353,6 +353,10 @@ int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_cap, const 
 int cnrma_sparse_conv_wgrad_chunks(int64_t no_cap, int rows_per_chunk);
 int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out, int Cout,
                                 int64_t no_cap, const int32_t* no_dev, int rows_per_chunk, float* slabs, void* stream);
+/* the same reduction with both operands rounded to bf16 (fp32 accumulation, v_mfma_f32_32x32x16_bf16): the weight
+ * gradient of a torch.autocast(bfloat16) training step, as AMP computes it */
+int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out, int Cout,
+                                 int64_t no_cap, const int32_t* no_dev, int rows_per_chunk, float* slabs, void* stream);
 
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */

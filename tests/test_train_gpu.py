@@ -39,6 +39,37 @@ def test_bf16_conv_equals_fp32_accumulation_of_bf16_operands(device, stride):
     assert 1e-4 < err < 2e-2                                   # bf16 operands: visible, bounded
 
 
+@pytest.mark.parametrize("cin,cout,stride", [(64, 96, 1), (32, 64, 2), (40, 24, 1)])
+def test_bf16_weight_gradient_equals_fp32_accumulation_of_bf16_operands(device, cin, cout, stride):
+    """wgrad of the autocast mode (cnrma_sparse_conv_wgrad_bf16): features and output gradients rounded to bf16, fp32
+    accumulation -> equals the fp64 oracle on the ROUNDED operands up to accumulation noise"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + stride)
+    c = np.unique(np.concatenate((np.zeros((7000, 1), dtype=np.int64), rng.randint(-16, 16, size=(7000, 3)) * 2), axis=1), axis=0)
+    f = rng.randn(len(c), cin).astype(np.float32)
+    W = (rng.randn(27, cin, cout) / 20).astype(np.float32)
+    x = S.SparseTensor(torch.from_numpy(f).to(device).requires_grad_(True), S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 2))
+    Wd = torch.from_numpy(W).to(device).requires_grad_(True)
+    y = S.conv_autograd(x, Wd, 3, stride, precision="bf16")
+    g = rng.randn(*y.F.shape).astype(np.float32)
+    calls = []
+    orig = S.call
+    S.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        y.F.backward(torch.from_numpy(g).to(device))
+    finally:
+        S.call = orig
+    assert "cnrma_sparse_conv_wgrad_bf16" in calls and "cnrma_sparse_conv_wgrad_f32" not in calls
+    # the oracle's output rows in the engine's row order
+    oc = y.C.cpu().numpy().astype(np.int64)
+    _, gW = SO.conv_backward(c, _bf16_round(f), W, _bf16_round(g), 3, stride, 2, out_coords=oc)
+    _, gW_exact = SO.conv_backward(c, f, W, g, 3, stride, 2, out_coords=oc)
+    got = Wd.grad.cpu().numpy()
+    np.testing.assert_allclose(got, gW, rtol=2e-5, atol=2e-5 * np.abs(gW).max())
+    err = np.abs(got - gW_exact).max() / np.abs(gW_exact).max()
+    assert 1e-5 < err < 2e-2                                   # bf16 operands: visible, bounded
+
+
 def test_train_step_under_bf16_autocast_tracks_the_fp32_step(device, tmp_path):
     import projects.mvsdetection  # noqa: F401
     from cnrma_amd import synth
