@@ -120,6 +120,9 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_contiguous(), "C-ABI buffers must be contiguous"
+    if not t.is_cuda:                    # a host pointer handed to a kernel is a GPU memory fault, not an exception
+        raise CnrmaError(f"C-ABI buffers must live on the GPU (got a {t.device} tensor of shape {tuple(t.shape)}): "
+                         "move the module / tensor with .to(device) first")
     return t.data_ptr()
 
 

@@ -204,3 +204,12 @@ def test_save_middle_result_writes_the_pretraining_points(tmp_path):
     assert np.all(np.diff(rows) > 0)                 # order preserved
     np.testing.assert_allclose(out[:, :3], pts.numpy()[rows.astype(int), :3] + [1, 2, 3])
     assert (tmp_path / "vis" / "sceneX" / "sceneX_points.ply").exists()
+
+
+def test_host_tensors_are_rejected_before_they_reach_a_kernel():
+    """a CPU tensor's address handed to a HIP kernel is a GPU memory fault; the binding refuses it instead"""
+    import torch
+    from cnrma_amd import _lib
+    with pytest.raises(_lib.CnrmaError, match="must live on the GPU"):
+        _lib.ptr(torch.zeros(4))
+    assert _lib.ptr(None) is None
