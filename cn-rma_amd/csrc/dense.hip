@@ -30,6 +30,31 @@ __device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, flo
   *wz = (float)z * p.vs + p.oz;
 }
 
+// Brick order of the voxels (cooperative kernel).  Voxels that share a pixel lie on one camera ray, 8-64 voxels apart;
+// a gathered pixel line is re-used only if two of them are processed by the SAME XCD (private 4 MB L2) at about the same
+// time.  With the plain z-fastest order the voxels in flight on an XCD are a pile of thin vertical columns that a ray
+// crosses once (TCC hit rate 22 %).  Here the grid is cut into bricks of st x st columns x zt layers (default 16 x 16 x 32
+// = 8192 voxels = 32 workgroups), z fastest inside a column, columns in tt x tt tiles; every brick is a chunk that one XCD
+// group owns (chunks c, c + 8, ... as before), so the ~8 bricks an XCD has in flight are compact 0.64 x 0.64 x 1.28 m
+// boxes in which a ray meets several of its voxels.  Measured at the north-star shape (scripts/dense_ab.py, results
+// bit-identical): 13.3 -> 10.7 ms; 64 x 64 x 16 slabs 12.8, 32 x 32 x 16 11.5, 16 x 16 x 64 10.8, 8 x 8 x 32 11.5,
+// 128 x 128 x 16 19.0 ms.  Stores stay 32-byte runs along z per lane group, merged in L2 (zt >= 16).
+struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt; };      // zt: z-layers per slab, st: supertile side, tt: tile side (columns)
+
+__device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrder& o, int64_t gv, int* x, int* y, int* z) {
+  const int64_t per = (int64_t)o.st * o.st * o.zt;
+  const int64_t sv = gv / per;
+  const int r = (int)(gv - sv * per);
+  if (sv >= (int64_t)o.nsx * o.nsy * o.nsz) return false;
+  const int sy = (int)(sv % o.nsy), sx = (int)((sv / o.nsy) % o.nsx), sz = (int)(sv / ((int64_t)o.nsy * o.nsx));
+  const int zl = r % o.zt, col = r / o.zt;                 // st^2 columns: (st/tt)^2 tiles of tt x tt columns
+  const int tpr = o.st / o.tt, tile = col / (o.tt * o.tt), in = col % (o.tt * o.tt);
+  *x = sx * o.st + (tile / tpr) * o.tt + in / o.tt;
+  *y = sy * o.st + (tile % tpr) * o.tt + in % o.tt;
+  *z = sz * o.zt + zl;
+  return *x < p.X && *y < p.Y && *z < p.Z;
+}
+
 // project one voxel into one view: returns validity, pixel in (*px,*py) (ray_marching.py:51-58)
 __device__ __forceinline__ bool project(const float* __restrict__ P, float wx, float wy, float wz, int H, int W,
                                         float* rx, float* ry) {
@@ -100,7 +125,7 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
                                                                      const float* __restrict__ proj,
                                                                      float* __restrict__ volume,
                                                                      int32_t* __restrict__ count, int chunk_blocks,
-                                                                     int64_t n_phys) {
+                                                                     int64_t n_phys, SlabOrder ord) {
   constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   const int lane = threadIdx.x & 63;
@@ -121,12 +146,24 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
     lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
   }
   const int64_t wave_base = (lb * blockDim.x + threadIdx.x) - lane;
-  if (wave_base >= G) continue;
   const int64_t g = wave_base + lane;
   const int c0 = blockIdx.y * (4 * LPV);
   float wx = 0.f, wy = 0.f, wz = 0.f;
-  const bool in_grid = g < G;
-  if (in_grid) voxel_world(p, g, &wx, &wy, &wz);
+  bool in_grid;
+  int64_t lin = -1;                               // this lane's voxel as an index into [X][Y][Z] (-1: none)
+  if (ord.on) {
+    int x = 0, y = 0, z = 0;
+    in_grid = slab_decode(p, ord, g, &x, &y, &z);
+    if (__ballot(in_grid) == 0ull) continue;
+    if (in_grid) {
+      lin = ((int64_t)x * p.Y + y) * p.Z + z;
+      wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;      // as voxel_world()
+    }
+  } else {
+    if (wave_base >= G) continue;
+    in_grid = g < G;
+    if (in_grid) { voxel_world(p, g, &wx, &wy, &wz); lin = g; }
+  }
   float4 acc[LPV];
 #pragma unroll
   for (int i = 0; i < LPV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -155,8 +192,9 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
 #pragma unroll
   for (int grp = 0; grp < LPV; ++grp) {
     const int cv = __shfl(cnt, grp * VPG + vsel, 64);
-    const int64_t gv = wave_base + grp * VPG + vsel;
-    if (gv < G) {
+    const int lo = __shfl((int)(lin & 0xffffffffLL), grp * VPG + vsel, 64), hi = __shfl((int)(lin >> 32), grp * VPG + vsel, 64);
+    const int64_t gv = ((int64_t)hi << 32) | (uint32_t)lo;
+    if (gv >= 0) {
       const float denom = (float)cv;
       const float4 a = acc[grp];
       const int c = c0 + 4 * sub;
@@ -166,7 +204,7 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
       volume[(int64_t)(c + 3) * G + gv] = cv > 0 ? a.w / denom : 0.0f;
     }
   }
-  if (blockIdx.y == 0 && in_grid) count[g] = cnt;
+  if (blockIdx.y == 0 && in_grid) count[lin] = cnt;
   }
 }
 
@@ -174,21 +212,34 @@ template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
                       hipStream_t st) {
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  const int64_t nb = ceil_div(G, 256);
+  int64_t nb = ceil_div(G, 256);
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
   int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
   if (cb < 32) cb = 32;
+  SlabOrder ord{0, 0, 0, 0, 32, 16, 8};
+  const char* so = getenv("CNRMA_DENSE_SLAB");             // tuning / A-B aid: 0 = z-fastest linear order (x-plane chunks)
+  if (so != nullptr ? so[0] == '1' : G < ((int64_t)1 << 40)) {
+    ord.on = 1;
+    const char* e;
+    if ((e = getenv("CNRMA_SLAB_Z")) != nullptr) ord.zt = atoi(e);
+    if ((e = getenv("CNRMA_SLAB_S")) != nullptr) ord.st = atoi(e);
+    if ((e = getenv("CNRMA_SLAB_T")) != nullptr) ord.tt = atoi(e);
+    if (ord.zt < 1 || ord.tt < 1 || ord.st < ord.tt || ord.st % ord.tt != 0 || ((int64_t)ord.st * ord.st * ord.zt) % 256 != 0) return CNRMA_EINVAL;
+    ord.nsx = (int)ceil_div(p.X, ord.st); ord.nsy = (int)ceil_div(p.Y, ord.st); ord.nsz = (int)ceil_div(p.Z, ord.zt);
+    cb = (int64_t)ord.st * ord.st * ord.zt / 256;          // one supertile per chunk
+    nb = (int64_t)ord.nsx * ord.nsy * ord.nsz * cb;
+  }
   const char* env = getenv("CNRMA_DENSE_CHUNK");           // tuning / A-B aid: 0 = plain round-robin order
   if (env != nullptr) cb = atoll(env);
   int64_t gx = nb;
-  if (cb > 0 && nb >= 16 * cb) gx = ceil_div(ceil_div(nb, cb), 8) * 8 * cb;      // whole chunks for every XCD group
+  if (cb > 0 && (nb >= 16 * cb || ord.on)) gx = ceil_div(ceil_div(nb, cb), 8) * 8 * cb;      // whole chunks for every XCD group
   else cb = 0;
   int64_t launch_x = gx;
   const char* pe = getenv("CNRMA_DENSE_PERSIST");          // tuning aid: workgroups per CU and channel sweep of a persistent grid
   const int per_cu = pe != nullptr ? atoi(pe) : 0;
   if (per_cu > 0 && gx > (int64_t)256 * per_cu) launch_x = (int64_t)256 * per_cu;     // a multiple of 8
   dim3 grid((unsigned)launch_x, (unsigned)ceil_div(p.C, 4 * LPV));
-  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb, gx);
+  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb, gx, ord);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
