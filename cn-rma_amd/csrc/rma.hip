@@ -11,6 +11,8 @@
 // Appendix B.4) and stops as soon as the transmittance drops below the weight threshold (w = T*alpha <= T).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct MarchParams {
@@ -232,8 +234,20 @@ __device__ __forceinline__ TabSample fetch_step(const Ray& r, int n, const March
 __global__ __launch_bounds__(256) void neus_march_kernel(MarchParams p, const float* __restrict__ proj_inv,
                                                          const float* __restrict__ tab, int32_t* __restrict__ count,
                                                          double* __restrict__ wsum, int2* __restrict__ kept, int cap,
-                                                         int32_t* __restrict__ overflow) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                         int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view) {
+  // thread -> ray: a wave marches an 8 x 8 pixel tile (a block a 16 x 16 tile) instead of 64 consecutive pixels of an image
+  // row: the bundle stays a compact patch of voxels at every step, so one table line serves more lanes
+  int64_t r;
+  if (tiles_x > 0) {
+    const int view_t = blockIdx.x / tiles_per_view, tile = blockIdx.x - view_t * tiles_per_view;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int u = tx * 16 + (w & 1) * 8 + (l & 7), v = ty * 16 + (w >> 1) * 8 + (l >> 3);
+    if (u >= p.W || v >= p.H) return;
+    r = ((int64_t)view_t * p.H + v) * p.W + u;
+  } else {
+    r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  }
   Ray ray; int view, pix;
   if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
   const float s_out = sigmoid_neg(1.0f);
@@ -566,8 +580,12 @@ extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf
   hipError_t e = cnrma_fill_bytes(overflow, 0, sizeof(int32_t), as_stream(stream));
   if (e != hipSuccess) return -(int)e;
   if (sig_table != nullptr && (int64_t)X * Y * Z < ((int64_t)1 << 31)) {
-    hipLaunchKernelGGL(neus_march_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p, proj_inv,
-                       sig_table, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
+    const char* te = getenv("CNRMA_MARCH_TILE");           // tuning / A-B aid: 0 = one image-row segment per wave
+    const bool tiled = te == nullptr || te[0] != '0';
+    const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, 16);
+    const unsigned blocks = tiled ? (unsigned)((int64_t)V * tx * ty) : (unsigned)ceil_div(R, 256);
+    hipLaunchKernelGGL(neus_march_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, proj_inv, sig_table, count, wsum,
+                       reinterpret_cast<int2*>(kept), cap, overflow, tiled ? tx : 0, tx * ty);
   } else {
     if (tsdf == nullptr) return CNRMA_EINVAL;
     hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
