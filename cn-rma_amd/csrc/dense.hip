@@ -39,7 +39,7 @@ __device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, flo
 // boxes in which a ray meets several of its voxels.  Measured at the north-star shape (scripts/dense_ab.py, results
 // bit-identical): 13.3 -> 10.7 ms; 64 x 64 x 16 slabs 12.8, 32 x 32 x 16 11.5, 16 x 16 x 64 10.8, 8 x 8 x 32 11.5,
 // 128 x 128 x 16 19.0 ms.  Stores stay 32-byte runs along z per lane group, merged in L2 (zt >= 16).
-struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt; };      // zt: z-layers per slab, st: supertile side, tt: tile side (columns)
+struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
 
 __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrder& o, int64_t gv, int* x, int* y, int* z) {
   const int64_t per = (int64_t)o.st * o.st * o.zt;
@@ -47,8 +47,13 @@ __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrde
   const int r = (int)(gv - sv * per);
   if (sv >= (int64_t)o.nsx * o.nsy * o.nsz) return false;
   const int sy = (int)(sv % o.nsy), sx = (int)((sv / o.nsy) % o.nsx), sz = (int)(sv / ((int64_t)o.nsy * o.nsx));
-  const int zl = r % o.zt, col = r / o.zt;                 // st^2 columns: (st/tt)^2 tiles of tt x tt columns
-  const int tpr = o.st / o.tt, tile = col / (o.tt * o.tt), in = col % (o.tt * o.tt);
+  // order inside a brick: [tile of tt x tt columns][outer z][column in tile][inner z run of zi]
+  const int tcols = o.tt * o.tt, zo_n = o.zt / o.zi;
+  const int zin = r % o.zi, q = r / o.zi;
+  const int in = q % tcols, q2 = q / tcols;
+  const int zo = q2 % zo_n, tile = q2 / zo_n;
+  const int zl = zo * o.zi + zin;
+  const int tpr = o.st / o.tt;
   *x = sx * o.st + (tile / tpr) * o.tt + in / o.tt;
   *y = sy * o.st + (tile % tpr) * o.tt + in % o.tt;
   *z = sz * o.zt + zl;
@@ -216,7 +221,7 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
   int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
   if (cb < 32) cb = 32;
-  SlabOrder ord{0, 0, 0, 0, 32, 16, 8};
+  SlabOrder ord{0, 0, 0, 0, 32, 16, 8, 32};
   const char* so = getenv("CNRMA_DENSE_SLAB");             // tuning / A-B aid: 0 = z-fastest linear order (x-plane chunks)
   if (so != nullptr ? so[0] == '1' : G < ((int64_t)1 << 40)) {
     ord.on = 1;
@@ -224,6 +229,9 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
     if ((e = getenv("CNRMA_SLAB_Z")) != nullptr) ord.zt = atoi(e);
     if ((e = getenv("CNRMA_SLAB_S")) != nullptr) ord.st = atoi(e);
     if ((e = getenv("CNRMA_SLAB_T")) != nullptr) ord.tt = atoi(e);
+    ord.zi = ord.zt;
+    if ((e = getenv("CNRMA_SLAB_ZI")) != nullptr) ord.zi = atoi(e);
+    if (ord.zi < 1 || ord.zt % ord.zi != 0) return CNRMA_EINVAL;
     if (ord.zt < 1 || ord.tt < 1 || ord.st < ord.tt || ord.st % ord.tt != 0 || ((int64_t)ord.st * ord.st * ord.zt) % 256 != 0) return CNRMA_EINVAL;
     ord.nsx = (int)ceil_div(p.X, ord.st); ord.nsy = (int)ceil_div(p.Y, ord.st); ord.nsz = (int)ceil_div(p.Z, ord.zt);
     cb = (int64_t)ord.st * ord.st * ord.zt / 256;          // one supertile per chunk

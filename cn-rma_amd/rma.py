@@ -41,8 +41,13 @@ def scale_projection(projection, stride):
 
 
 def to_nhwc(features, out=None):
-    """features [V,C,H,W] (reference layout) -> channels-last [V,H,W,C] on the device (one HIP pass)."""
+    """features [V,C,H,W] (reference layout) -> channels-last [V,H,W,C] on the device (one HIP pass).
+    A tensor whose MEMORY is already channels-last (torch.channels_last: what a 2D network run in that memory format
+    writes) is returned as a view -- no pass at all (25 GB of traffic at the north-star shape)."""
     _lib.require_gpu()
+    if (out is None and features.dim() == 4 and features.dtype == torch.float32 and features.is_cuda
+            and features.permute(0, 2, 3, 1).is_contiguous()):
+        return features.permute(0, 2, 3, 1)
     features = _f32(features)
     V, C, H, W = features.shape
     if out is None:

@@ -18,7 +18,7 @@ for chunk in sys.argv[2:]:
     elif chunk == "default":
         os.environ.pop("CNRMA_DENSE_CHUNK", None)
         os.environ.pop("CNRMA_DENSE_SLAB", None)
-        for k in ("CNRMA_SLAB_Z", "CNRMA_SLAB_S", "CNRMA_SLAB_T"):
+        for k in ("CNRMA_SLAB_Z", "CNRMA_SLAB_S", "CNRMA_SLAB_T", "CNRMA_SLAB_ZI"):
             os.environ.pop(k, None)
     elif chunk == "linear":
         os.environ.pop("CNRMA_DENSE_CHUNK", None)
@@ -27,7 +27,8 @@ for chunk in sys.argv[2:]:
         os.environ.pop("CNRMA_DENSE_CHUNK", None)
         os.environ["CNRMA_DENSE_SLAB"] = "1"
         parts = chunk.split(":")[1:]
-        for name, val in zip(("CNRMA_SLAB_Z", "CNRMA_SLAB_S", "CNRMA_SLAB_T"), parts):
+        os.environ.pop("CNRMA_SLAB_ZI", None)
+        for name, val in zip(("CNRMA_SLAB_Z", "CNRMA_SLAB_S", "CNRMA_SLAB_T", "CNRMA_SLAB_ZI"), parts):
             os.environ[name] = val
     else:
         os.environ["CNRMA_DENSE_CHUNK"] = chunk

@@ -323,3 +323,14 @@ def test_division_by_voxel_size_is_exact(device, vs):
     qf, qr = torch.empty_like(a), torch.empty_like(a)
     call("cnrma_debug_div_by_voxel_size_f32", ptr(a), a.numel(), float(vs), ptr(qf), ptr(qr), stream())
     assert torch.equal(qf.view(torch.int32), qr.view(torch.int32))
+
+
+def test_channels_last_features_need_no_layout_pass(device):
+    """a feature tensor in torch.channels_last memory format is used in place (zero-copy view), same results"""
+    from cnrma_amd import rma
+    g = torch.Generator().manual_seed(3)
+    f = torch.randn(3, 8, 12, 16, generator=g).to(device)
+    a = rma.to_nhwc(f)
+    fcl = f.contiguous(memory_format=torch.channels_last)
+    b = rma.to_nhwc(fcl)
+    assert b.data_ptr() == fcl.data_ptr() and b.is_contiguous() and torch.equal(a, b)
