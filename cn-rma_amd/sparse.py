@@ -910,6 +910,28 @@ def topk_mask(scores, k, n_dev=None):
 _NDEV = {}
 
 
+def topk_indices(scores, k, n_dev=None):
+    """int64 [k] row indices of the k largest scores in descending score order (ties -> smaller index): what
+    torch.topk(scores, k)[1] returns, built from the radix-select keep-mask + a compaction + a sort of only the k survivors
+    (torch.topk's single-workgroup select takes 0.2-0.7 ms on ~500 k scores and sits on the critical path of a scene).
+    With fewer than k live rows (n_dev) the live rows come first, in score order; the remaining slots repeat row 0."""
+    scores = scores.contiguous().view(-1).float()
+    n = scores.numel()
+    mask = topk_mask(scores, k, n_dev)
+    sel = torch.empty(n, dtype=torch.int32, device=scores.device)
+    n_sel = torch.empty(1, dtype=torch.int32, device=scores.device)
+    ws = torch.empty(_lib.load().cnrma_scan_workspace_bytes(n), dtype=torch.uint8, device=scores.device)
+    call("cnrma_mask_to_index", ptr(mask), ptr(sel), ptr(n_sel), n, ptr(ws), stream())     # sel[row] = output slot or -1
+    rows = torch.zeros(k + 1, dtype=torch.int64, device=scores.device)                      # slot -> row (slot k: dump)
+    rows.scatter_(0, torch.where(sel >= 0, sel, torch.full_like(sel, k)).long().clamp_(max=k),
+                  torch.arange(n, device=scores.device, dtype=torch.int64))
+    slot_ok = torch.arange(k, device=scores.device, dtype=torch.int32) < n_sel
+    idx = torch.where(slot_ok, rows[:k], torch.zeros_like(rows[:k]))
+    vals = torch.where(slot_ok, scores[idx], torch.full((k,), float("-inf"), device=scores.device))
+    order = torch.sort(vals, descending=True, stable=True)[1]
+    return idx[order]
+
+
 def row_max(feats):
     n, C = feats.shape
     out = torch.empty((n, 1), dtype=torch.float32, device=feats.device)

@@ -289,7 +289,7 @@ class FCAF3DHead(nn.Module):
                 plan.record_flag(len(cls_score) > nms_pre > 0)
             if len(cls_score) > nms_pre > 0:
                 max_scores = S.max_scores(cls_score, centerness)                            # :249-250 (ranking key only)
-                _, ids = max_scores.topk(nms_pre)                                           # :252-256
+                ids = S.topk_indices(max_scores, nms_pre)                                   # :252-256
             boxes, scores = S.select_decode(ids, cls_score, centerness, bbox_pred, point, self.yaw_parametrization)
             mlvl_bboxes.append(boxes)
             mlvl_scores.append(scores)
@@ -327,9 +327,7 @@ class FCAF3DHead(nn.Module):
                 # there are fewer than nms_pre, then in score order instead of row order)
                 assert cap > nms_pre
                 plan.watch(n_dev, nms_pre + 1 if flag else 0, cap)
-                ms = S.max_scores(cls, cen)
-                live = torch.arange(cap, device=ms.device, dtype=torch.int32) < n_dev
-                ids = torch.where(live, ms, torch.full_like(ms, float("-inf"))).topk(nms_pre)[1]
+                ids = S.topk_indices(S.max_scores(cls, cen), nms_pre, n_dev)
                 k = nms_pre
                 valid.append(torch.clamp(n_dev.view(1), max=nms_pre).to(torch.int32))
             else:
@@ -354,7 +352,7 @@ class FCAF3DHead(nn.Module):
             if n_scenes == 1:
                 ids = None
                 if len(cls) > nms_pre > 0:
-                    ids = S.max_scores(cls, cen).topk(nms_pre)[1]
+                    ids = S.topk_indices(S.max_scores(cls, cen), nms_pre)
                 groups = [ids]
             else:
                 # ONE stable sort per level on the key (scene, descending score): every scene's rows become a contiguous

@@ -477,6 +477,23 @@ def test_f16x3_all_zero_and_empty_inputs(device):
     assert float((y.F - 0.5).abs().max()) == 0.0 and _amax(y) == 0.5
 
 
+@pytest.mark.parametrize("n,k,live", [(5000, 100, None), (300000, 1000, None), (2000, 500, 320), (64, 64, None)])
+def test_topk_indices_match_torch_topk(device, n, k, live):
+    """decode's nms_pre cut: same rows, same order as torch.topk (ties -> smaller index); with fewer live rows than k the
+    live rows come first in score order"""
+    from cnrma_amd import sparse as S
+    g = torch.Generator().manual_seed(n + k)
+    s = torch.rand(n, generator=g).to(device)
+    s[::7] = s[3]                                           # ties
+    n_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=device)
+    ids = S.topk_indices(s, k, n_dev)
+    assert ids.dtype == torch.int64 and ids.shape == (k,)
+    m = n if live is None else live
+    ref = torch.sort(s[:m], descending=True, stable=True)[1][:k]
+    assert torch.equal(ids[:min(k, m)], ref[:min(k, m)])
+    assert bool((ids[min(k, m):] == 0).all())
+
+
 def test_topk_mask_is_exact_under_heavy_ties(device):
     """thousands of exactly equal scores at the threshold: exactly k rows, the tied ones by smallest index
     (the row set of a stable descending sort)"""
