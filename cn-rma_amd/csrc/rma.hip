@@ -727,22 +727,30 @@ extern "C" int cnrma_rma_depth_emit_f32(const float* proj_inv, const float* tsdf
 
 // Reference quirk (ray_marching.py:781-782, :282-287): a view that keeps exactly ONE sample is dropped entirely
 // (torch.squeeze() makes the index 0-dim, len() raises and the bare except skips the view).  One block per view.
-__global__ __launch_bounds__(256) void drop_single_sample_views_kernel(int32_t* __restrict__ count, double* __restrict__ wsum,
-                                                                       int64_t rays_per_view) {
-  __shared__ int smem[256 / 64 + 1];
+__global__ __launch_bounds__(1024) void drop_single_sample_views_kernel(int32_t* __restrict__ count, double* __restrict__ wsum,
+                                                                        int64_t rays_per_view) {
+  __shared__ int smem[1024 / 64 + 1];
   int32_t* c = count + (int64_t)blockIdx.x * rays_per_view;
   double* w = wsum + (int64_t)blockIdx.x * rays_per_view;
   int local = 0;
-  for (int64_t i = threadIdx.x; i < rays_per_view; i += 256) local += c[i];
+  int64_t i = threadIdx.x * 4;
+  if ((rays_per_view & 3) == 0 && ((reinterpret_cast<uintptr_t>(c) & 15) == 0)) {
+    for (; i + 3 < rays_per_view; i += 4096) {
+      const int4 q = *reinterpret_cast<const int4*>(c + i);
+      local += q.x + q.y + q.z + q.w;
+    }
+  } else {
+    for (int64_t j = threadIdx.x; j < rays_per_view; j += 1024) local += c[j];
+  }
   int total;
-  (void)block_excl_scan<256>(local, smem, &total);
+  (void)block_excl_scan<1024>(local, smem, &total);
   if (total != 1) return;
-  for (int64_t i = threadIdx.x; i < rays_per_view; i += 256) { c[i] = 0; w[i] = 0.0; }
+  for (int64_t j = threadIdx.x; j < rays_per_view; j += 1024) { c[j] = 0; w[j] = 0.0; }
 }
 
 extern "C" int cnrma_rma_drop_single_sample_views(int32_t* count, double* wsum, int V, int64_t rays_per_view, void* stream) {
   if (V <= 0 || rays_per_view <= 0 || count == nullptr || wsum == nullptr) return CNRMA_EINVAL;
-  hipLaunchKernelGGL(drop_single_sample_views_kernel, dim3((unsigned)V), dim3(256), 0, as_stream(stream), count, wsum,
+  hipLaunchKernelGGL(drop_single_sample_views_kernel, dim3((unsigned)V), dim3(1024), 0, as_stream(stream), count, wsum,
                      rays_per_view);
   CNRMA_LAUNCH_CHECK();
   return 0;
