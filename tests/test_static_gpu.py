@@ -122,3 +122,33 @@ def test_static_equals_eager_scannet_shape(device):
     # 35 layers deep; rows with near-equal scores can swap ranks at the nms_pre cut: compare the bulk
     close = np.isclose(b1, b0, rtol=5e-4, atol=5e-4).all(axis=1)
     assert close.mean() > 0.99
+
+
+def test_static_trace_takes_the_pair_list_stem(device):
+    """128 input channels: the stem's nearly empty kernel map goes through cnrma_sparse_conv_pairs_f16x3 -- a recorded
+    branch of the size plan -- in the calibration run, in the static trace and in the captured graph"""
+    from cnrma_amd import pipeline, synth
+    from cnrma_amd import sparse as S
+    sc = synth.make_scene((3, 128, 30, 40, (48, 48, 20), 4), seed=2)
+    feat, proj, tsdf = sc["features"][:, 0].to(device), sc["projection"][:, 0], sc["tsdf"][0, 0].to(device)
+    backbone, head = _model(128, device)
+    cfg = pipeline.SceneConfig(sc["dims"], stride=sc["stride"], max_points=1500, sample_seed=5)
+    calls = []
+    orig = S.call
+    S.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+    try:
+        st = pipeline.StaticScene(cfg, backbone, head, device)
+        eager = st.build(feat, proj, tsdf)
+    finally:
+        S.call = orig
+    assert calls.count("cnrma_sparse_conv_pairs_f16x3") == 3          # calibration, static trace, capture
+    assert True in st.plan.flags
+    st.seed_dev.zero_()
+    out = st.run(feat, proj, tsdf)
+    torch.cuda.synchronize()
+    b, s, info = pipeline.StaticScene.detections(out)
+    assert info["M_unique"] == eager["M_unique"] and info["level_rows"] == eager["level_rows"]
+    b0, s0 = _sorted(eager["bboxes"].cpu().numpy(), eager["scores"].cpu().numpy())
+    b1, s1 = _sorted(b.cpu().numpy(), s.cpu().numpy())
+    np.testing.assert_allclose(b1, b0, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)
