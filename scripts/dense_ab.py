@@ -12,7 +12,9 @@ del sc["features"]
 proj = rma.scale_projection(sc["projection"][:, 0], stride).to(dev)
 ref = None
 for chunk in sys.argv[2:]:
-    if chunk.startswith("lpv"):
+    if chunk.startswith("persist"):
+        os.environ["CNRMA_DENSE_PERSIST"] = chunk[7:]
+    elif chunk.startswith("lpv"):
         os.environ["CNRMA_DENSE_LPV"] = chunk[3:]
         os.environ.pop("CNRMA_DENSE_CHUNK", None)
     elif chunk == "default":
