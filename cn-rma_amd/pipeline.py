@@ -265,6 +265,26 @@ class StaticScene:
                     head_rows=counts[3 + nl:3 + 2 * nl])
         return out["bboxes"].index_select(0, rows), out["scores"].index_select(0, rows), info
 
+    def detect(self, features_nchw, projections, tsdf):
+        """run() + detections() with the fallback a server wants: a scene that outgrows the size plan (status != 0) is
+        re-run through the eager path (sizes read back from the device), and its sizes are merged into the plan for
+        the next build().  Returns (bboxes, scores, info); info["static"] tells which path produced them."""
+        out = self.run(features_nchw, projections, tsdf)
+        try:
+            with torch.cuda.stream(self.stream):          # the read-back waits on the stream the graph runs on
+                b, s, info = self.detections(out)
+            info["static"] = True
+            return b, s, info
+        except _lib.CnrmaError:
+            with torch.cuda.stream(self.stream):
+                grown = P.Plan(self.margin)
+                with P.using(grown):
+                    e = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense)
+            self.outgrown = grown if getattr(self, "outgrown", None) is None else self.outgrown.merge(grown)
+            info = {k: e[k] for k in ("M", "M_selected", "M_unique", "level_rows", "head_rows")}
+            info["static"] = False
+            return e["bboxes"], e["scores"], info
+
 
 def gather_padded_detections(det, valid, det_all=None, valid_all=None):
     """ONE fixed-size exchange of a step's detections: det [S, K, W] = the padded raw boxes + scores of the

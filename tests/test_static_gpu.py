@@ -100,6 +100,13 @@ def test_static_flags_a_scene_that_outgrows_the_plan(device):
     out = st.run(feat, proj, tsdf)
     torch.cuda.synchronize()
     pipeline.StaticScene.detections(out)
+    # detect(): the serving call -- falls back to the eager path for the scene that does not fit, static otherwise
+    b, s, info = st.detect(feat2, proj2, tsdf2)
+    if eager["M"] > st.plan.sizes[0] + 320:
+        assert info["static"] is False and st.outgrown is not None
+    assert b.shape == eager["bboxes"].shape and info["M"] == eager["M"]
+    b, s, info = st.detect(feat, proj, tsdf)
+    assert info["static"] is True
 
 
 def test_static_equals_eager_scannet_shape(device):
