@@ -12,8 +12,9 @@ feat, proj, tsdf = sc["features"][:, 0].to(dev), sc["projection"][:, 0], sc["tsd
 backbone, head = bench.build_model(C, dev)
 cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device", sample_seed=0)
 res = {}
+modes = ("0", "1") if len(sys.argv) <= 3 else tuple(sys.argv[3:])
 for rep in range(3):
-    for mode in ("0", "1"):
+    for mode in modes:
         os.environ[var] = mode
         if var == "PAIR_CONV":
             from cnrma_amd import sparse as S
@@ -27,11 +28,11 @@ for rep in range(3):
         kern, layers = prof.summary(1)
         res.setdefault(mode, []).append(layers)
         res[("out", mode)] = out
-for mode in ("0", "1"):
+for mode in modes:
     print(var, mode, "conv total ms per rep:", [round(sum(L["ms"] for L in layers), 3) for layers in res[mode]])
-a, b = res["0"][-1], res["1"][-1]
+a, b = res[modes[0]][-1], res[modes[-1]][-1]
 for La, Lb in zip(a, b):
     if La["ms"] > 0.05:
         print(f"rows={La['n_out']:7d} Cin={La['Cin']:4d} Cout={La['Cout']:4d} K={La['K']:2d}  {La['ms']:.4f} -> {Lb['ms']:.4f} ms  ({Lb['ms'] / La['ms']:.2f}x)")
-oa, ob = res[("out", "0")], res[("out", "1")]
+oa, ob = res[("out", modes[0])], res[("out", modes[-1])]
 print("detections bit-identical:", torch.equal(oa["bboxes"], ob["bboxes"]) and torch.equal(oa["scores"], ob["scores"]))
