@@ -136,8 +136,9 @@ def _header_functions():
 
 def test_library_exports_every_declared_symbol():
     from cnrma_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):
-        pytest.fail("libcnrma_hip.so is not built: run `python __graft_entry__.py build`")
+    if not os.path.exists(_lib.LIB_PATH):                  # fresh checkout: hipcc cross-compiles without a GPU (~1-2 min)
+        import subprocess
+        subprocess.run(["make", "-C", os.path.dirname(_lib.LIB_PATH), "-j8", "libcnrma_hip.so"], check=True)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     decl = _header_functions()
     assert len(decl) >= 30
