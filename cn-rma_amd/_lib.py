@@ -16,7 +16,8 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "cnrma_abi_version": (c_int, []),
     "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
-    "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P]),
+    "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
+    "cnrma_debug_dense_tuning": (c_int, [P, I]),
     "cnrma_backproject_backward_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, P, P]),
     "cnrma_backproject_index_f32": (c_int, [P, I, I, I, I, I, F, F, F, F, P, P, P, P]),
     "cnrma_ray_params_f32": (c_int, [P, I, I, I, P, P, P]),
@@ -89,7 +90,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class CnrmaError(RuntimeError):

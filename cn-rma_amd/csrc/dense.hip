@@ -11,9 +11,10 @@
 // sum in view order; mean = sum / (float)count.  Compiled with -ffp-contract=off.
 #include "common.h"
 
-#include <stdlib.h>
 
 namespace {
+
+static __device__ __forceinline__ int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 struct DenseParams {
   int V, C, H, W, X, Y, Z;
@@ -39,7 +40,7 @@ __device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, flo
 // boxes in which a ray meets several of its voxels.  Measured at the north-star shape (scripts/dense_ab.py, results
 // bit-identical): 13.3 -> 10.7 ms; 64 x 64 x 16 slabs 12.8, 32 x 32 x 16 11.5, 16 x 16 x 64 10.8, 8 x 8 x 32 11.5,
 // 128 x 128 x 16 19.0 ms.  Stores stay 32-byte runs along z per lane group, merged in L2 (zt >= 16).
-struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
+struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
 
 __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrder& o, int64_t gv, int* x, int* y, int* z) {
   const int64_t per = (int64_t)o.st * o.st * o.zt;
@@ -57,6 +58,23 @@ __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrde
   *x = sx * o.st + (tile / tpr) * o.tt + in / o.tt;
   *y = sy * o.st + (tile % tpr) * o.tt + in % o.tt;
   *z = sz * o.zt + zl;
+  return *x < p.X && *y < p.Y && *z < p.Z;
+}
+
+// Lattice assignment of a brick's z-columns to its workgroups (lockstep schedule; zt == 32, st % 8 == 0): workgroup w of
+// the st*st/8 takes 8 whole columns on a (2 x 4) lattice with pitch (st/2, st/4) -- column j at
+// (w / (st/4) + (st/2) * (j / 4),  w % (st/4) + (st/4) * (j % 4)) --, so every workgroup samples the whole brick and meets
+// each view's frustum boundary in the same proportion as its neighbours: equal work per view, the precondition for staying in
+// phase.  A wave still owns 2 columns x 32 consecutive z (full 128-byte store runs per channel plane).
+__device__ __forceinline__ bool lattice_decode(const DenseParams& p, const SlabOrder& o, int64_t lb, int* x, int* y, int* z) {
+  const int cb = o.st * o.st / 8;
+  const int64_t sv = lb / cb;
+  if (sv >= (int64_t)o.nsx * o.nsy * o.nsz) return false;
+  const int w = (int)(lb - sv * cb), j = (int)(threadIdx.x >> 5), q4 = o.st / 4;
+  const int sy = (int)(sv % o.nsy), sx = (int)((sv / o.nsy) % o.nsx), sz = (int)(sv / ((int64_t)o.nsy * o.nsx));
+  *x = sx * o.st + w / q4 + (o.st / 2) * (j >> 2);
+  *y = sy * o.st + w % q4 + q4 * (j & 3);
+  *z = sz * 32 + (int)(threadIdx.x & 31);
   return *x < p.X && *y < p.Y && *z < p.Z;
 }
 
@@ -213,41 +231,415 @@ __global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams
   }
 }
 
+// ---- pipelined cooperative-gather kernel (round 3; the product kernel) ------------------------------------------------
+// Same lane <-> voxel / channel mapping and the same arithmetic as backproject_accum_coop_kernel (results bit-identical),
+// but built for memory-level parallelism.  The round-2 loop put every gather inside its own conditional block, and the
+// compiler closed each with `s_waitcnt vmcnt(0)`: ONE 1-KB gather in flight per wave, 24 KB per CU -- the kernel was bound
+// by the latency of a single L2 / Infinity-Cache / HBM round trip (its run time scaled 1:1 with the number of resident
+// waves), not by bandwidth.  Here all LPV gathers of a view are issued back to back (exec-masked loads,
+// no branch in between), the projection of the NEXT view is computed while they fly, and only then are they added; with
+// PIPE = 2 the gathers of view v + 1 are issued before the sums of view v.
+//
+// Schedule (SlabOrder + lockstep): the grid is cut into bricks; a brick is the unit one XCD group works on.  In lockstep
+// mode the launch is a persistent grid of 8 x `bpc` workgroups (bpc = workgroups per brick, all resident): group g =
+// blockIdx.x % 8 walks bricks g, g + 8, ... and meets at a group-local barrier after every brick, so that the workgroups
+// sharing an L2 are in the same 32^3 box AND at about the same view at the same time -- the condition under which a
+// pixel line fetched for one voxel is still in L2 when the next voxel on that camera ray asks for it
+// (scripts/dense_l2sim.cpp: read hit rate 34 % -> 54 %, fabric reads 51 -> 35 GB per launch at the north-star shape).
+// The barrier spins a bounded number of times: placement (b % 8 = XCD) and co-residency are performance assumptions,
+// never correctness ones.
+// Group-local barrier on ONE monotonic arrival counter (never reset, so a call that timed out leaves nothing to clean up):
+// the k-th arrival waits until the counter reaches the next multiple of n.  Bounded spin: if the workgroups of a group
+// are not all resident (another kernel holds CUs) the wait gives up after ~1 ms and the kernel merely loses its phase lock.
+__device__ __forceinline__ void group_barrier(unsigned int* w, unsigned int n) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int old = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int goal = (old / n + 1u) * n;
+    for (int spin = 0; spin < 4096; ++spin) {
+      if ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - goal) >= 0) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  __syncthreads();
+}
+
+template <int LPV, int PIPE, int EPI>
+__device__ __forceinline__ void accum_block(const DenseParams& p, const float* __restrict__ feat,
+                                            const float* __restrict__ proj, float* __restrict__ volume,
+                                            int32_t* __restrict__ count, int64_t lb, int c0, bool write_count,
+                                            const SlabOrder& ord, float* __restrict__ lds_wave) {
+  constexpr int VPG = 64 / LPV;
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  const int lane = threadIdx.x & 63;
+  const int64_t g = lb * blockDim.x + threadIdx.x;
+  float wx = 0.f, wy = 0.f, wz = 0.f;
+  bool in_grid;
+  int64_t lin = -1;
+  if (ord.on) {
+    int x = 0, y = 0, z = 0;
+    in_grid = ord.on == 2 ? lattice_decode(p, ord, lb, &x, &y, &z) : slab_decode(p, ord, g, &x, &y, &z);
+    if (in_grid) {
+      lin = ((int64_t)x * p.Y + y) * p.Z + z;
+      wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;      // as voxel_world()
+    }
+  } else {
+    in_grid = g < G;
+    if (in_grid) { voxel_world(p, g, &wx, &wy, &wz); lin = g; }
+  }
+  if (__ballot(in_grid) == 0ull) return;
+  float4 acc[LPV];
+#pragma unroll
+  for (int i = 0; i < LPV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;
+  const int sub = lane % LPV, vsel = lane / LPV;
+  const int64_t plane = (int64_t)p.H * p.W * p.C;
+  const float* fbase = feat + c0 + 4 * sub;
+
+  auto pixel_of = [&](int v) -> int {
+    float rx, ry;
+    const bool ok = in_grid && project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry);
+    return ok ? ((int)ry * p.W + (int)rx) : -1;
+  };
+  auto gather = [&](int v, int pix, float4* q) {
+    const float* fv = fbase + v * plane;
+#pragma unroll
+    for (int grp = 0; grp < LPV; ++grp) {
+      const int pq = __shfl(pix, grp * VPG + vsel, 64);
+      q[grp] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pq >= 0) q[grp] = *reinterpret_cast<const float4*>(fv + (int64_t)pq * p.C);
+    }
+  };
+  auto add = [&](const float4* q) {
+#pragma unroll
+    for (int grp = 0; grp < LPV; ++grp) {
+      acc[grp].x += q[grp].x; acc[grp].y += q[grp].y; acc[grp].z += q[grp].z; acc[grp].w += q[grp].w;
+    }
+  };
+
+  if constexpr (PIPE == 1) {
+    int pix_n = pixel_of(0);
+    for (int v = 0; v < p.V; ++v) {
+      const int pix = pix_n;
+      const bool any = __ballot(pix >= 0) != 0ull;
+      float4 q[LPV];
+      if (any) gather(v, pix, q);
+      cnt += pix >= 0 ? 1 : 0;
+      pix_n = (v + 1 < p.V) ? pixel_of(v + 1) : -1;        // overlaps with the gathers in flight
+      if (any) add(q);
+    }
+  } else {
+    // two views in flight: q0 holds view v (issued one iteration ago), q1 is issued for view v + 1 before q0 is consumed
+    float4 q0[LPV], q1[LPV];
+    int pix0 = pixel_of(0);
+    bool any0 = __ballot(pix0 >= 0) != 0ull;
+    if (any0) gather(0, pix0, q0);
+    cnt += pix0 >= 0 ? 1 : 0;
+    for (int v = 0; v < p.V; ++v) {
+      bool any1 = false;
+      if (v + 1 < p.V) {
+        const int pix1 = pixel_of(v + 1);
+        any1 = __ballot(pix1 >= 0) != 0ull;
+        if (any1) gather(v + 1, pix1, q1);
+        cnt += pix1 >= 0 ? 1 : 0;
+      }
+      if (any0) add(q0);
+      any0 = any1;
+#pragma unroll
+      for (int grp = 0; grp < LPV; ++grp) q0[grp] = q1[grp];
+    }
+  }
+
+  // means.  The count of the voxel a lane accumulates for (group grp) lives in lane grp*VPG + vsel.
+  if constexpr (EPI == 0) {
+#pragma unroll
+    for (int grp = 0; grp < LPV; ++grp) {
+      const int cv = __shfl(cnt, grp * VPG + vsel, 64);
+      const int lo = __shfl((int)(lin & 0xffffffffLL), grp * VPG + vsel, 64), hi = __shfl((int)(lin >> 32), grp * VPG + vsel, 64);
+      const int64_t gv = ((int64_t)hi << 32) | (uint32_t)lo;
+      if (gv >= 0) {
+        const float denom = (float)cv;
+        const float4 a = acc[grp];
+        const int c = c0 + 4 * sub;
+        const float m0 = cv > 0 ? a.x / denom : 0.0f, m1 = cv > 0 ? a.y / denom : 0.0f, m2 = cv > 0 ? a.z / denom : 0.0f,
+                    m3 = cv > 0 ? a.w / denom : 0.0f;
+        float* o = volume + (int64_t)c * G + gv;
+        if (ord.nt) {                           // streaming stores: the volume is written once and not read here
+          __builtin_nontemporal_store(m0, o); __builtin_nontemporal_store(m1, o + G);
+          __builtin_nontemporal_store(m2, o + 2 * G); __builtin_nontemporal_store(m3, o + 3 * G);
+        } else { o[0] = m0; o[G] = m1; o[2 * G] = m2; o[3 * G] = m3; }
+      }
+    }
+  } else {
+    // transpose through the wave's own LDS tile [4*LPV channels][64 voxels (+1 pad)] so that every store instruction
+    // writes ONE channel plane for the wave's 64 voxels (two full 128-B lines in brick order) instead of 8 planes x 32 B
+    constexpr int LD = 65;
+#pragma unroll
+    for (int grp = 0; grp < LPV; ++grp) {
+      const int cv = __shfl(cnt, grp * VPG + vsel, 64);
+      const float denom = (float)cv;
+      const float4 a = acc[grp];
+      float* t = lds_wave + (4 * sub) * LD + grp * VPG + vsel;
+      t[0 * LD] = cv > 0 ? a.x / denom : 0.0f;
+      t[1 * LD] = cv > 0 ? a.y / denom : 0.0f;
+      t[2 * LD] = cv > 0 ? a.z / denom : 0.0f;
+      t[3 * LD] = cv > 0 ? a.w / denom : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (in_grid) {
+      float* o = volume + (int64_t)c0 * G + lin;
+#pragma unroll
+      for (int c = 0; c < 4 * LPV; ++c) o[(int64_t)c * G] = lds_wave[c * LD + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (write_count && in_grid) count[lin] = cnt;
+}
+
+template <int LPV, int PIPE, int EPI, int LOCK>
+__global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe_kernel(DenseParams p, const float* __restrict__ feat,
+                                                                     const float* __restrict__ proj,
+                                                                     float* __restrict__ volume,
+                                                                     int32_t* __restrict__ count, int chunk_blocks,
+                                                                     int64_t n_phys, SlabOrder ord,
+                                                                     unsigned int* __restrict__ bar) {
+  __shared__ float lds[EPI ? 4 * (4 * LPV) * 65 : 1];
+  float* lds_wave = lds + (EPI ? (threadIdx.x >> 6) * (4 * LPV) * 65 : 0);
+  if constexpr (LOCK != 0) {
+    // persistent grid: gridDim.x = 8 * chunk_blocks; group = blockIdx.x & 7 walks chunks group, group + 8, ...; all channel
+    // sweeps inside (blockIdx.y unused)
+    const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int64_t n_chunks = n_phys / chunk_blocks;
+    const int n_sweeps = (int)ceil_div_dev(p.C, 4 * LPV);
+    for (int sw = 0; sw < n_sweeps; ++sw)
+      for (int64_t ch = grp; ch < n_chunks; ch += 8) {
+        accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, ch * chunk_blocks + slot, sw * 4 * LPV, sw == 0, ord, lds_wave);
+        group_barrier(bar + grp * 32, (unsigned)chunk_blocks);
+      }
+  } else {
+    int64_t lb = blockIdx.x;
+    if (chunk_blocks > 0) {
+      const int64_t grp = lb & 7, k = lb >> 3;
+      lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
+    }
+    accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, lb, blockIdx.y * (4 * LPV), blockIdx.y == 0, ord, lds_wave);
+  }
+}
+
+// ---- hoisted kernel (variant 2) ------------------------------------------------------------------------------------------
+// Measured on the pipelined kernel: with feature maps small enough to sit in L2 it still needs 6.4 ms at the north-star
+// grid -- the loop body is VALU-bound (the projection, two IEEE divisions per voxel and view, is repeated in each of the 8
+// channel sweeps, for the 73 % of (voxel, view) pairs that are out of the frustum as well).  Here a workgroup handles ALL
+// channel sweeps of its 256 voxels: phase A projects every view once, keeps the pixel index of each (voxel, view) in LDS
+// ([wave][V][64] int32) and a wave-uniform bit mask of the views that see any of the wave's voxels; phase B runs the sweeps
+// over the SET bits only -- no projection, no work at all for views the wave is outside of -- with the gathers of the next
+// active view in flight while the current one is added (software pipeline of depth 2).
+// Lockstep form: bricks of st x st x 32; a workgroup takes 8 z-columns on a (st/2 x st/4) lattice over the brick instead of
+// a compact tile, so that all workgroups of a brick meet every view's frustum boundary in the same proportion and stay
+// in phase without waiting for each other (the compact assignment made the lockstep grid 2x slower: 20.8 vs 9.8 ms).
+template <int LPV, int LOCK>
+__global__ __launch_bounds__(256, 4) void backproject_accum_hoist_kernel(DenseParams p, const float* __restrict__ feat,
+                                                                         const float* __restrict__ proj,
+                                                                         float* __restrict__ volume,
+                                                                         int32_t* __restrict__ count, int chunk_blocks,
+                                                                         int64_t n_phys, SlabOrder ord,
+                                                                         unsigned int* __restrict__ bar, int use_barrier) {
+  extern __shared__ int32_t lds_pix[];                       // [4 waves][V][64]
+  constexpr int VPG = 64 / LPV;
+  const int64_t G = (int64_t)p.X * p.Y * p.Z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t* wp = lds_pix + (size_t)wave * p.V * 64 + lane;
+  const int sub = lane % LPV, vsel = lane / LPV;
+  const int n_sweeps = (int)ceil_div_dev(p.C, 4 * LPV);
+  const uint32_t row_bytes = (uint32_t)p.C * 4u;
+  const int64_t plane = (int64_t)p.H * p.W * p.C;
+
+  const int grp_id = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t n_chunks = chunk_blocks > 0 ? n_phys / chunk_blocks : 0;
+  for (int64_t it = 0;; ++it) {
+    int64_t lb;
+    if constexpr (LOCK != 0) {
+      const int64_t ch = grp_id + 8 * it;
+      if (ch >= n_chunks) break;
+      lb = ch * chunk_blocks + slot;
+    } else {
+      if (it > 0) break;
+      lb = blockIdx.x;
+      if (chunk_blocks > 0) {
+        const int64_t g8 = lb & 7, k = lb >> 3;
+        lb = (g8 + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
+      }
+    }
+    // ---- this lane's voxel
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    bool in_grid = false;
+    int64_t lin = -1;
+    if (LOCK != 0) {
+      int x = 0, y = 0, z = 0;
+      in_grid = lattice_decode(p, ord, lb, &x, &y, &z);
+      if (in_grid) {
+        lin = ((int64_t)x * p.Y + y) * p.Z + z;
+        wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;
+      }
+    } else if (ord.on) {
+      int x = 0, y = 0, z = 0;
+      in_grid = slab_decode(p, ord, lb * 256 + threadIdx.x, &x, &y, &z);
+      if (in_grid) {
+        lin = ((int64_t)x * p.Y + y) * p.Z + z;
+        wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;      // as voxel_world()
+      }
+    } else {
+      const int64_t g = lb * 256 + threadIdx.x;
+      in_grid = g < G;
+      if (in_grid) { voxel_world(p, g, &wx, &wy, &wz); lin = g; }
+    }
+    if (__ballot(in_grid) != 0ull) {
+      // ---- phase A: every projection once
+      unsigned long long active = 0ull;
+      int cnt = 0;
+      for (int v = 0; v < p.V; ++v) {
+        float rx, ry;
+        const bool ok = in_grid && project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry);
+        wp[v * 64] = ok ? (int)(((uint32_t)(int)ry * (uint32_t)p.W + (uint32_t)(int)rx) * row_bytes) : -1;   // byte offset of the pixel row
+        cnt += ok ? 1 : 0;
+        if (__ballot(ok) != 0ull) active |= 1ull << v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (in_grid) count[lin] = cnt;
+      // who writes which voxel: the count / linear index of the voxel a lane accumulates for (group grp) live in lane grp*VPG + vsel
+      // ---- phase B: the channel sweeps over the active views
+      for (int sw = 0; sw < n_sweeps; ++sw) {
+        const char* fbase = reinterpret_cast<const char*>(feat + sw * (4 * LPV) + 4 * sub);
+        float4 acc[LPV];
+#pragma unroll
+        for (int i = 0; i < LPV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto gather = [&](int v, float4* q) {
+          const int off = wp[v * 64];
+          const char* fv = fbase + (int64_t)v * plane * 4;
+#pragma unroll
+          for (int grp = 0; grp < LPV; ++grp) {
+            const int oq = __shfl(off, grp * VPG + vsel, 64);
+            q[grp] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oq >= 0) q[grp] = *reinterpret_cast<const float4*>(fv + (uint32_t)oq);
+          }
+        };
+        auto add = [&](const float4* q) {
+#pragma unroll
+          for (int grp = 0; grp < LPV; ++grp) {
+            acc[grp].x += q[grp].x; acc[grp].y += q[grp].y; acc[grp].z += q[grp].z; acc[grp].w += q[grp].w;
+          }
+        };
+        unsigned long long m = active;
+        float4 qa[LPV], qb[LPV];
+        bool has = m != 0ull;
+        if (has) { const int v = __builtin_ctzll(m); m &= m - 1; gather(v, qa); }
+        while (has) {
+          const bool hasb = m != 0ull;
+          if (hasb) { const int v = __builtin_ctzll(m); m &= m - 1; gather(v, qb); }
+          add(qa);
+          if (!hasb) break;
+          has = m != 0ull;
+          if (has) { const int v = __builtin_ctzll(m); m &= m - 1; gather(v, qa); }
+          add(qb);
+        }
+        const int c = sw * (4 * LPV) + 4 * sub;
+#pragma unroll
+        for (int grp = 0; grp < LPV; ++grp) {
+          const int cv = __shfl(cnt, grp * VPG + vsel, 64);
+          const int lo = __shfl((int)(lin & 0xffffffffLL), grp * VPG + vsel, 64), hi = __shfl((int)(lin >> 32), grp * VPG + vsel, 64);
+          const int64_t gv = ((int64_t)hi << 32) | (uint32_t)lo;
+          if (gv >= 0) {
+            const float denom = (float)cv;
+            const float4 a = acc[grp];
+            volume[(int64_t)(c + 0) * G + gv] = cv > 0 ? a.x / denom : 0.0f;
+            volume[(int64_t)(c + 1) * G + gv] = cv > 0 ? a.y / denom : 0.0f;
+            volume[(int64_t)(c + 2) * G + gv] = cv > 0 ? a.z / denom : 0.0f;
+            volume[(int64_t)(c + 3) * G + gv] = cv > 0 ? a.w / denom : 0.0f;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (LOCK != 0) {
+      if (use_barrier) group_barrier(bar + grp_id * 32, (unsigned)chunk_blocks);
+    }
+  }
+}
+
+// Debug / A-B switches of the dense kernel.  Product code never reads the environment: the defaults below ARE the shipped
+// configuration, and only cnrma_debug_dense_tuning() (scripts/dense_ab.py, tests of the alternative orders) changes them.
+struct DenseTune {
+  int variant = 1;      // 0: round-2 kernel (one gather in flight per wave)   1: pipelined kernel   2: hoisted kernel
+  int slab = 1;         // 1: brick order, 0: z-fastest linear order with x-plane chunks
+  int st = 16, zt = 32, tt = 8, zi = 32;   // brick side (columns), brick layers, tile side, inner z run
+  int chunk = -1;       // blocks per XCD chunk in linear order (-1: one x-plane, 0: plain round-robin)
+  int persist = 0;      // variant 0 only: workgroups per CU of its persistent form
+  int lpv = 0;          // 0: by channel count; 4 / 8 / 16 / 32 lanes (x 4 channels) per voxel
+  int pipe = 1;         // variant 1: views in flight (1 | 2)
+  int epi = 0;          // variant 1: 0 direct stores, 1 LDS-transposed full-line stores
+  int nt = 0;           // variant 1: non-temporal stores of the volume
+  int lattice = 0;      // variant 1 lockstep: 1 = lattice assignment of columns to workgroups (balanced), 0 = compact tiles
+  int lockstep = 0;     // variants 1, 2: persistent grid, every XCD group walks one brick at a time (1: behind a barrier, 2: no barrier)
+};
+static DenseTune g_tune;
+
 template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
-                      hipStream_t st) {
+                      unsigned int* bar, hipStream_t st) {
+  const DenseTune t = g_tune;
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   int64_t nb = ceil_div(G, 256);
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
   int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
   if (cb < 32) cb = 32;
-  SlabOrder ord{0, 0, 0, 0, 32, 16, 8, 32};
-  const char* so = getenv("CNRMA_DENSE_SLAB");             // tuning / A-B aid: 0 = z-fastest linear order (x-plane chunks)
-  if (so != nullptr ? so[0] == '1' : G < ((int64_t)1 << 40)) {
+  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt};
+  if (t.slab) {
     ord.on = 1;
-    const char* e;
-    if ((e = getenv("CNRMA_SLAB_Z")) != nullptr) ord.zt = atoi(e);
-    if ((e = getenv("CNRMA_SLAB_S")) != nullptr) ord.st = atoi(e);
-    if ((e = getenv("CNRMA_SLAB_T")) != nullptr) ord.tt = atoi(e);
-    ord.zi = ord.zt;
-    if ((e = getenv("CNRMA_SLAB_ZI")) != nullptr) ord.zi = atoi(e);
     if (ord.zi < 1 || ord.zt % ord.zi != 0) return CNRMA_EINVAL;
     if (ord.zt < 1 || ord.tt < 1 || ord.st < ord.tt || ord.st % ord.tt != 0 || ((int64_t)ord.st * ord.st * ord.zt) % 256 != 0) return CNRMA_EINVAL;
     ord.nsx = (int)ceil_div(p.X, ord.st); ord.nsy = (int)ceil_div(p.Y, ord.st); ord.nsz = (int)ceil_div(p.Z, ord.zt);
-    cb = (int64_t)ord.st * ord.st * ord.zt / 256;          // one supertile per chunk
+    cb = (int64_t)ord.st * ord.st * ord.zt / 256;          // one brick per chunk
     nb = (int64_t)ord.nsx * ord.nsy * ord.nsz * cb;
-  }
-  const char* env = getenv("CNRMA_DENSE_CHUNK");           // tuning / A-B aid: 0 = plain round-robin order
-  if (env != nullptr) cb = atoll(env);
+  } else if (t.chunk >= 0) cb = t.chunk;
   int64_t gx = nb;
   if (cb > 0 && (nb >= 16 * cb || ord.on)) gx = ceil_div(ceil_div(nb, cb), 8) * 8 * cb;      // whole chunks for every XCD group
   else cb = 0;
-  int64_t launch_x = gx;
-  const char* pe = getenv("CNRMA_DENSE_PERSIST");          // tuning aid: workgroups per CU and channel sweep of a persistent grid
-  const int per_cu = pe != nullptr ? atoi(pe) : 0;
-  if (per_cu > 0 && gx > (int64_t)256 * per_cu) launch_x = (int64_t)256 * per_cu;     // a multiple of 8
-  dim3 grid((unsigned)launch_x, (unsigned)ceil_div(p.C, 4 * LPV));
-  hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb, gx, ord);
+  if (t.variant == 0) {
+    int64_t launch_x = gx;
+    if (t.persist > 0 && gx > (int64_t)256 * t.persist) launch_x = (int64_t)256 * t.persist;     // a multiple of 8
+    dim3 grid((unsigned)launch_x, (unsigned)ceil_div(p.C, 4 * LPV));
+    hipLaunchKernelGGL((backproject_accum_coop_kernel<LPV>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb, gx, ord);
+    CNRMA_LAUNCH_CHECK();
+    return 0;
+  }
+  if (t.variant == 2 && p.V <= 64 && (int64_t)p.H * p.W * p.C * 4 < ((int64_t)1 << 31)) {
+    const int lock = (t.lockstep && (bar != nullptr || t.lockstep == 2) && ord.on && ord.zt == 32 && ord.st % 8 == 0 && cb > 0 && cb <= 256) ? 1 : 0;
+    const size_t lds = (size_t)4 * p.V * 64 * sizeof(int32_t);
+    dim3 grid(lock ? (unsigned)(8 * cb) : (unsigned)gx);
+    if (lock)
+      hipLaunchKernelGGL((backproject_accum_hoist_kernel<LPV, 1>), grid, dim3(256), lds, st, p, feat, proj, volume, count, (int)cb,
+                         gx, ord, bar, t.lockstep == 1 ? 1 : 0);
+    else
+      hipLaunchKernelGGL((backproject_accum_hoist_kernel<LPV, 0>), grid, dim3(256), lds, st, p, feat, proj, volume, count, (int)cb,
+                         gx, ord, bar, 0);
+    CNRMA_LAUNCH_CHECK();
+    return 0;
+  }
+  const int lock = (t.lockstep == 1 && bar != nullptr && ord.on && cb > 0 && cb <= 256) ? 1 : 0;
+  if (t.lattice && ord.on && ord.zt == 32 && ord.st % 8 == 0) ord.on = 2;
+  dim3 grid(lock ? (unsigned)(8 * cb) : (unsigned)gx, lock ? 1u : (unsigned)ceil_div(p.C, 4 * LPV));
+#define CNRMA_DENSE_LAUNCH(PIPE, EPI)                                                                                      \
+  do {                                                                                                                     \
+    if (lock)                                                                                                              \
+      hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 1>), grid, dim3(256), 0, st, p, feat, proj, volume, \
+                         count, (int)cb, gx, ord, bar);                                                                    \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 0>), grid, dim3(256), 0, st, p, feat, proj, volume, \
+                         count, (int)cb, gx, ord, bar);                                                                    \
+  } while (0)
+  if (t.pipe == 2) { if (t.epi) CNRMA_DENSE_LAUNCH(2, 1); else CNRMA_DENSE_LAUNCH(2, 0); }
+  else             { if (t.epi) CNRMA_DENSE_LAUNCH(1, 1); else CNRMA_DENSE_LAUNCH(1, 0); }
+#undef CNRMA_DENSE_LAUNCH
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -279,23 +671,32 @@ int launch_accum(const DenseParams& p, const float* feat, const float* proj, flo
 
 }  // namespace
 
+extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
+  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt}; n < 14 keeps the remaining defaults;
+  // n == 0 restores the product configuration.  Host-side global state: debug / A-B runs only.
+  DenseTune t;
+  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt};
+  if (n < 0 || n > 14 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  for (int i = 0; i < n; ++i) *f[i] = v[i];
+  g_tune = t;
+  return 0;
+}
+
 extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
                                            int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
-                                           float* volume, int32_t* count, void* stream) {
+                                           float* volume, int32_t* count, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
   if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
   DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
   hipStream_t st = as_stream(stream);
-  const char* lpv = getenv("CNRMA_DENSE_LPV");             // tuning / A-B aid: lanes (x 4 channels) per voxel and sweep
-  if (lpv != nullptr) {
-    const int l = atoi(lpv);
-    if (l == 16 && C % 64 == 0) return launch_accum_coop<16>(p, feat_nhwc, proj, volume, count, st);
-    if (l == 32 && C % 128 == 0) return launch_accum_coop<32>(p, feat_nhwc, proj, volume, count, st);
-    if (l == 4 && C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, st);
-  }
-  if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, st);
-  if (C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, st);
-  if (C % 8 == 0) return launch_accum_coop<2>(p, feat_nhwc, proj, volume, count, st);
-  if (C % 4 == 0) return launch_accum_coop<1>(p, feat_nhwc, proj, volume, count, st);
+  unsigned int* bar = (workspace != nullptr && workspace_bytes >= CNRMA_DENSE_WORKSPACE_BYTES) ? static_cast<unsigned int*>(workspace) : nullptr;
+  const int l = g_tune.lpv;
+  if (l == 16 && C % 64 == 0) return launch_accum_coop<16>(p, feat_nhwc, proj, volume, count, bar, st);
+  if (l == 4 && C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st);
+  if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, bar, st);
+  if (C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st);
+  if (C % 8 == 0) return launch_accum_coop<2>(p, feat_nhwc, proj, volume, count, bar, st);
+  if (C % 4 == 0) return launch_accum_coop<1>(p, feat_nhwc, proj, volume, count, bar, st);
   return launch_accum<1>(p, feat_nhwc, proj, volume, count, st);
 }
 

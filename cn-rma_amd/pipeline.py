@@ -126,6 +126,95 @@ def forward_scene(cfg, backbone, head, features_nchw, projections, tsdf, offset=
     return out
 
 
+def trace_net(plan, backbone, head, coords, feats, n_dev, voxel_size, device, extra_counts=()):
+    """the sparse half inside a static trace (plan.static): voxelise -> MinkResNet34 -> neck / head -> decode of the point
+    rows [0, n_dev) of the capacity-sized (coords, feats).  Returns the padded detections, the per-level head outputs and
+    one small tensor of live counts -- no device->host read."""
+    x, _ = S.voxelize(coords, feats, voxel_size, n_dev=n_dev)
+    levels = backbone(x)
+    cen, box, cls, pts, css = map(list, head(levels, fused=True))
+    bboxes, scores, valid, sizes = head.get_bboxes_static(cen, box, cls, pts, css)
+    status = plan.status(device)
+    # every live count of the pass in ONE small tensor (read together with the detections, if at all)
+    counts = torch.cat([c.view(1) for c in extra_counts] + [x.cs.n_dev.view(1)] + [l.cs.n_dev.view(1) for l in levels] +
+                       [c[0].n_dev.view(1) for c in css]).to(torch.int32)
+    return dict(bboxes=bboxes, scores=scores, valid=valid, sizes=sizes, status=status, counts=counts, n_levels=len(levels),
+                n_extra=len(extra_counts), levels=levels,
+                head=dict(centerness=[c[0] for c in cen], bbox_pred=[b[0] for b in box], cls_score=[c[0] for c in cls],
+                          points=[p[0] for p in pts], n_dev=[c[0].n_dev for c in css]))
+
+
+class StaticNet:
+    """The sparse half alone (point rows -> raw detections) as a replayable HIP graph: what StaticScene runs after the
+    aggregation, without the geometric half in front.  Used to pin the graph path of the network to the oracle on
+    arbitrary point sets (tests) and by callers that bring their own points."""
+
+    def __init__(self, backbone, head, voxel_size, device, margin=1.2, stream=None):
+        self.backbone, self.head, self.voxel_size = backbone, head, voxel_size
+        self.device = torch.device(device)
+        self.margin = margin
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self.plan = self.graph = self.out = None
+
+    def build(self, coords, feats, capture=True, cap=None):
+        """calibrate eagerly on (coords [M,3], feats [M,C]), then trace statically at point capacity `cap` (default M)
+        and capture.  Returns the eager result dict(bboxes, scores)."""
+        _lib.require_gpu()
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            plan = P.Plan(self.margin)
+            with P.using(plan):
+                x, _ = S.voxelize(coords, feats, self.voxel_size)
+                levels = self.backbone(x)
+                cen, box, cls, pts = map(list, self.head(levels))
+                bboxes, scores = self.head._get_bboxes_single([c[0] for c in cen], [b[0] for b in box], [c[0] for c in cls],
+                                                              [p[0] for p in pts])
+            self.plan = plan
+            M, C = feats.shape
+            self.cap = int(cap or M)
+            self.coords = torch.zeros((self.cap, 3), dtype=torch.float32, device=self.device)
+            self.feats = torch.zeros((self.cap, C), dtype=torch.float32, device=self.device)
+            self.n_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._load(coords, feats)
+            self.out = self._trace()
+            self.stream.synchronize()
+            if capture:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.out = self._trace()
+                self.stream.synchronize()
+        return dict(bboxes=bboxes, scores=scores, level_rows=[len(l) for l in levels])
+
+    def _load(self, coords, feats):
+        n = coords.shape[0]
+        assert n <= self.cap
+        self.coords[:n].copy_(coords, non_blocking=True)
+        self.feats[:n].copy_(feats, non_blocking=True)
+        self.n_dev.fill_(n)
+
+    def _trace(self):
+        self.plan.begin_static()
+        with P.using(self.plan), torch.no_grad():
+            out = trace_net(self.plan, self.backbone, self.head, self.coords, self.feats, self.n_dev, self.voxel_size,
+                            self.device)
+        self.plan.end_static()
+        return out
+
+    def run(self, coords, feats):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._load(coords, feats)
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.out = self._trace()
+            self.done = torch.cuda.Event()
+            self.done.record()
+        self.out["done"] = self.done
+        return self.out
+
+
 class StaticScene:
     """One scene forward as a replayable HIP graph: the whole launch sequence of forward_scene() (dense unprojection,
     march, selection, voxelisation, MinkResNet34, neck/head, decode -- ~350 launches) captured once and replayed per
@@ -161,19 +250,32 @@ class StaticScene:
         self._pin_proj = torch.empty((V, 3, 4), dtype=torch.float32, pin_memory=True)
         self._pin_inv = torch.empty((V, 4, 4), dtype=torch.float32, pin_memory=True)
 
-    def _load(self, features_nchw, projections, tsdf):
-        """stage one scene's inputs into the static buffers (on self.stream, which must be current)"""
+    def _load(self, features_nchw, projections, tsdf, proj_inv=None):
+        """stage one scene's inputs into the static buffers (on self.stream, which must be current).  proj_inv: the
+        [V,4,4] inverse of [P/stride; 0 0 0 1] when the caller pins it (parity tests: LAPACK's inverse is not bit-stable
+        across host CPUs); computed here on the host like ray_marching.py:96-102 otherwise."""
         if self._copied is not None:
             self._copied.synchronize()           # the previous scene's copies out of the pinned buffers have executed
         rma.to_nhwc(features_nchw, out=self.nhwc)
         p = projections.detach().to("cpu", torch.float32)
         self._pin_proj.copy_(rma.scale_projection(p, self.cfg.stride))
-        self._pin_inv.copy_(rma.projection_inverse(p, self.cfg.stride))      # host LAPACK, as ray_marching.py:96-102
+        self._pin_inv.copy_(rma.projection_inverse(p, self.cfg.stride) if proj_inv is None
+                            else proj_inv.detach().to("cpu", torch.float32))
         self.proj_scaled.copy_(self._pin_proj, non_blocking=True)
         self.proj_inv.copy_(self._pin_inv, non_blocking=True)
         self.tsdf.copy_(tsdf.reshape(self.tsdf.shape), non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()
+
+    def _enter(self, *inputs):
+        """order self.stream behind the caller's stream (the 2D backbone / Atlas head that produced the inputs ran
+        there) and keep the inputs' memory from being recycled while self.stream still reads it"""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+            for t in inputs:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.stream)
 
     # ---- the launch sequence ---------------------------------------------------------------------------------------
     def _trace(self):
@@ -184,36 +286,33 @@ class StaticScene:
             if self.dense:
                 out["volume"], out["count"] = rma.backproject_accum(self.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin,
                                                                     cfg.stride, proj_scaled=self.proj_scaled)
+            fixed = cfg.sample_seed is not None          # a fixed seed: every replay draws the same subset (as forward_scene)
             coords, feats, n_sel, info = rma.aggregate_points_static(
                 self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
-                max_points=cfg.max_points, seed=0x5EED if cfg.sample_seed is None else cfg.sample_seed,
-                seed_dev=self.seed_dev)
-            x, _ = S.voxelize(coords, feats, cfg.voxel_size_fcaf3d, n_dev=n_sel)
-            levels = self.backbone(x)
-            cen, box, cls, pts, css = map(list, self.head(levels, fused=True))
-            bboxes, scores, valid, sizes = self.head.get_bboxes_static(cen, box, cls, pts, css)
-            status = plan.status(self.device)
-            self.seed_dev.add_(1)                # the next replay draws a fresh point subset
-            # every live count of the pass in ONE small tensor (read together with the detections, if at all)
-            counts = torch.cat([info["M"].view(1), n_sel.view(1), x.cs.n_dev.view(1)] + [l.cs.n_dev.view(1) for l in levels] +
-                               [c[0].n_dev.view(1) for c in css]).to(torch.int32)
+                max_points=cfg.max_points, seed=cfg.sample_seed if fixed else 0x5EED,
+                seed_dev=None if fixed else self.seed_dev)
+            out.update(trace_net(plan, self.backbone, self.head, coords, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
+                                 extra_counts=[info["M"], n_sel]))
+            if not fixed:
+                self.seed_dev.add_(1)            # the next replay draws a fresh point subset
         plan.end_static()
-        out.update(bboxes=bboxes, scores=scores, valid=valid, sizes=sizes, status=status, counts=counts,
-                   n_levels=len(levels))
+        out.update(points=(coords, feats, n_sel))
         return out
 
-    def calibrate(self, features_nchw, projections, tsdf):
+    def calibrate(self, features_nchw, projections, tsdf, proj_inv=None):
         """one eager forward under a recording plan; several calls (several scenes of the configuration) are merged:
         capacities then cover the largest of them.  Returns the eager result."""
         _lib.require_gpu()
+        self._enter(features_nchw, tsdf)
         with torch.cuda.stream(self.stream):
             plan = P.Plan(self.margin)
             with P.using(plan):
-                eager = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense)
+                eager = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense,
+                                      proj_inv=proj_inv)
         self.plan = plan if self.plan is None else self.plan.merge(plan)
         return eager
 
-    def build(self, features_nchw, projections, tsdf, capture=True, plan=None):
+    def build(self, features_nchw, projections, tsdf, capture=True, plan=None, proj_inv=None):
         """calibrate on this scene (eager) unless calibrate() has been called or a finished `plan` of the same
         configuration is handed in (its sizes/flags are copied), then trace statically and capture.
         Returns the eager result of the calibration done here (None otherwise)."""
@@ -223,10 +322,11 @@ class StaticScene:
             self.plan = P.Plan(self.margin)
             self.plan.sizes, self.plan.flags = list(plan.sizes), list(plan.flags)
         elif self.plan is None:
-            eager = self.calibrate(features_nchw, projections, tsdf)
+            eager = self.calibrate(features_nchw, projections, tsdf, proj_inv)
+        self._enter(features_nchw, tsdf)
         with torch.cuda.stream(self.stream):
             self._alloc_inputs(features_nchw, tsdf)
-            self._load(features_nchw, projections, tsdf)
+            self._load(features_nchw, projections, tsdf, proj_inv)
             self.out = self._trace()                         # plain static run: creates the trace's constants
             self.stream.synchronize()
             if capture:
@@ -236,21 +336,41 @@ class StaticScene:
                 self.stream.synchronize()
         return eager
 
-    def run(self, features_nchw, projections, tsdf):
-        """enqueue one scene on self.stream; returns the static output dict (device tensors, valid until the next run)"""
+    def run(self, features_nchw, projections, tsdf, proj_inv=None):
+        """enqueue one scene on self.stream (ordered behind the caller's current stream, which produced the inputs);
+        returns the static output dict (device tensors, valid until the next run; consumers on another stream wait on
+        `self.done` first -- detections() does)."""
+        self._enter(features_nchw, tsdf)
         with torch.cuda.stream(self.stream):
-            self._load(features_nchw, projections, tsdf)
+            self._load(features_nchw, projections, tsdf, proj_inv)
             if self.graph is not None:
                 self.graph.replay()
             else:
                 self.out = self._trace()
+            self.done = torch.cuda.Event()
+            self.done.record()
+        self.out["done"] = self.done
         return self.out
+
+    def rebuild(self, features_nchw, projections, tsdf):
+        """fold the sizes of the scenes that outgrew the plan (detect()'s eager fall-backs) into the plan and trace /
+        capture again at the larger capacities"""
+        if getattr(self, "outgrown", None) is not None:
+            self.plan.static = False
+            self.plan = self.plan.merge(self.outgrown) if len(self.plan.sizes) == len(self.outgrown.sizes) else self.outgrown
+            self.outgrown, self.n_outgrown = None, 0
+        fresh = P.Plan(self.margin)
+        fresh.sizes, fresh.flags = list(self.plan.sizes), list(self.plan.flags)
+        self.plan = None
+        return self.build(features_nchw, projections, tsdf, capture=True, plan=fresh)
 
     @staticmethod
     def detections(out):
         """static outputs -> (bboxes [K,*], scores [K,n_cls], info) like forward_scene; ONE device->host read.  Raises
         when the scene violated an assumption of the plan (the caller re-runs it with forward_scene)."""
         L = len(out["sizes"])
+        if out.get("done") is not None:
+            torch.cuda.current_stream(out["bboxes"].device).wait_event(out["done"])
         host = _lib.read_ints(torch.cat((out["status"].view(-1), out["valid"].view(-1), out["counts"].view(-1))))
         if host[0] != 0:
             raise _lib.CnrmaError(f"{host[0]} capacity / branch assumption(s) of the static plan violated: re-run eagerly")
@@ -260,15 +380,18 @@ class StaticScene:
             rows.append(torch.arange(r0, r0 + v, device=out["bboxes"].device))
             r0 += k
         rows = torch.cat(rows)
-        nl = out["n_levels"]
-        info = dict(M=counts[0], M_selected=counts[1], M_unique=counts[2], level_rows=counts[3:3 + nl],
-                    head_rows=counts[3 + nl:3 + 2 * nl])
+        nl, ne = out["n_levels"], out.get("n_extra", 2)
+        info = dict(M_unique=counts[ne], level_rows=counts[ne + 1:ne + 1 + nl], head_rows=counts[ne + 1 + nl:ne + 1 + 2 * nl])
+        if ne == 2:
+            info.update(M=counts[0], M_selected=counts[1])
         return out["bboxes"].index_select(0, rows), out["scores"].index_select(0, rows), info
 
-    def detect(self, features_nchw, projections, tsdf):
+    def detect(self, features_nchw, projections, tsdf, rebuild_after=4):
         """run() + detections() with the fallback a server wants: a scene that outgrows the size plan (status != 0) is
-        re-run through the eager path (sizes read back from the device), and its sizes are merged into the plan for
-        the next build().  Returns (bboxes, scores, info); info["static"] tells which path produced them."""
+        re-run through the eager path (sizes read back from the device) and its sizes are kept; after `rebuild_after`
+        such scenes the plan is enlarged and the graph captured again (rebuild()), so a deployment whose scenes grew
+        stops paying a replay plus an eager pass per scene.  Returns (bboxes, scores, info); info["static"] tells which
+        path produced them."""
         out = self.run(features_nchw, projections, tsdf)
         try:
             with torch.cuda.stream(self.stream):          # the read-back waits on the stream the graph runs on
@@ -280,9 +403,15 @@ class StaticScene:
                 grown = P.Plan(self.margin)
                 with P.using(grown):
                     e = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense)
-            self.outgrown = grown if getattr(self, "outgrown", None) is None else self.outgrown.merge(grown)
+            prev = getattr(self, "outgrown", None)
+            same = prev is not None and len(prev.sizes) == len(grown.sizes) and len(prev.flags) == len(grown.flags)
+            self.outgrown = prev.merge(grown) if same else grown
+            self.n_outgrown = getattr(self, "n_outgrown", 0) + 1
             info = {k: e[k] for k in ("M", "M_selected", "M_unique", "level_rows", "head_rows")}
             info["static"] = False
+            if rebuild_after and self.n_outgrown >= rebuild_after:
+                self.rebuild(features_nchw, projections, tsdf)
+                info["rebuilt"] = True
             return e["bboxes"], e["scores"], info
 
 

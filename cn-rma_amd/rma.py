@@ -72,9 +72,45 @@ def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stri
     proj = proj_scaled if proj_scaled is not None else _f32(scale_projection(projections.to(torch.float32), stride)).to(dev)
     volume = torch.empty((C, X, Y, Z), dtype=torch.float32, device=dev)
     count = torch.empty((X, Y, Z), dtype=torch.int32, device=dev)
+    st = stream()
+    ws = _dense_workspace(dev, st)
     call("cnrma_backproject_accum_f32", ptr(features_nhwc), ptr(proj), V, C, H, W, X, Y, Z, float(voxel_size),
-         float(origin[0]), float(origin[1]), float(origin[2]), ptr(volume), ptr(count), stream())
+         float(origin[0]), float(origin[1]), float(origin[2]), ptr(volume), ptr(count), ptr(ws), ws.numel() * 4, st)
     return volume, count
+
+
+_DENSE_WS = {}
+_DENSE_KEYS = ("variant", "slab", "st", "zt", "tt", "zi", "chunk", "persist", "lpv", "pipe", "epi", "lockstep", "lattice", "nt")
+
+
+def _dense_workspace(dev, st):
+    """the zeroed barrier words of the dense kernel's lockstep schedule: one per (device, stream) -- calls on one stream
+    run one after the other and the kernel leaves the words zero"""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st)
+    ws = _DENSE_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(256, dtype=torch.int32, device=dev)
+        _DENSE_WS[key] = ws
+    return ws
+
+
+def dense_tuning(**kw):
+    """debug / A-B aid (scripts/dense_ab.py, traversal-order tests): override schedule switches of the dense kernel;
+    no arguments = the product configuration.  Never called by product code."""
+    import ctypes
+    if not kw:
+        call("cnrma_debug_dense_tuning", None, 0)
+        return
+    base = dict(variant=1, slab=1, st=16, zt=32, tt=8, zi=32, chunk=-1, persist=0, lpv=0, pipe=1, epi=0, lockstep=0, lattice=0, nt=0)
+    base.update(DENSE_DEFAULTS)
+    unknown = set(kw) - set(base)
+    assert not unknown, unknown
+    base.update(kw)
+    arr = (ctypes.c_int * len(_DENSE_KEYS))(*[int(base[k]) for k in _DENSE_KEYS])
+    call("cnrma_debug_dense_tuning", arr, len(_DENSE_KEYS))
+
+
+DENSE_DEFAULTS = {}        # mirrors the non-trivial defaults of csrc/dense.hip's DenseTune (kept in step by a test)
 
 
 class BackprojectAccum(torch.autograd.Function):

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 2
+#define CNRMA_ABI_VERSION 3
 
 int cnrma_abi_version(void);
 
@@ -44,10 +44,20 @@ int cnrma_nchw_to_nhwc_f32(const float* feat_nchw, float* feat_nhwc, int V, int 
  *           clear_3d_features()      ray_marching.py:247-257   (divide by count, zero unseen voxels)
  * proj[V][3][4]: rows 0-1 already divided by backbone2d_stride (ray_marching.py:238-239).
  * volume[C][X][Y][Z] (mean, 0 where count == 0), count[X][Y][Z] int32 (number of views that see the voxel).
+ * workspace: NULL, or CNRMA_DENSE_WORKSPACE_BYTES of device memory, zeroed once by the caller before its first use and
+ *   then left to the library (self-resetting barrier words of the lockstep schedule: a finished call leaves it ready
+ *   for the next one; one workspace per call in flight).  With NULL the kernel runs in plain brick order (same
+ *   results, lower L2 hit rate).
  * ---------------------------------------------------------------------------------------------------------- */
+#define CNRMA_DENSE_WORKSPACE_BYTES 1024
 int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
                                 int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
-                                float* volume, int32_t* count, void* stream);
+                                float* volume, int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Debug / A-B aid (scripts/dense_ab.py, tests of the alternative voxel orders): overrides the dense kernel's schedule
+ * switches {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt} (host-side global state; n = 0
+ * restores the product configuration).  Product code never calls it and nothing reads the environment. */
+int cnrma_debug_dense_tuning(const int* values, int n);
 
 /* Backward of cnrma_backproject_accum_f32 w.r.t. the feature maps (training):
  * grad_feat_nhwc[v][pix_v(g)][c] += grad_volume[c][g] / count[g] for every valid (voxel g, view v) pair; the output is

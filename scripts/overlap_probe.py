@@ -34,7 +34,7 @@ def timed(fns, streams):
 s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
 ref = dense()
 for per in sys.argv[1:]:
-    os.environ["CNRMA_DENSE_PERSIST"] = per
+    rma.dense_tuning(variant=0, persist=int(per))
     v = dense()
     torch.cuda.synchronize()
     assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1])
@@ -42,7 +42,7 @@ for per in sys.argv[1:]:
     for name, fns in (("dense", [dense]), ("dense+march", [dense, march]), ("dense+nhwc", [dense, nhwc]), ("dense+march+nhwc", [dense, march, nhwc])):
         ts = [timed(fns, [s1, s2, s3]) for _ in range(4)]
         print(f"persist {per}: {name:18s} ms {[round(t, 2) for t in ts[1:]]}", flush=True)
-os.environ.pop("CNRMA_DENSE_PERSIST", None)
+rma.dense_tuning()
 for name, fns in (("dense", [dense]), ("march", [march]), ("nhwc", [nhwc]), ("dense+march", [dense, march]),
                   ("dense+nhwc", [dense, nhwc]), ("march+nhwc", [march, nhwc]), ("dense+march+nhwc", [dense, march, nhwc])):
     ts = [timed(fns, [s1, s2, s3]) for _ in range(4)]

@@ -191,15 +191,28 @@ def test_neus_vs_oracle_at_scannet_shape(device, seed, V):
     rows, per_view = rma.rma_view_rows(feats, pinv, tsdf.to(device), sc["dims"], 0.04, sc["origin"], 300, 0.05)
     rows = rows.cpu().numpy()
     exp = exp.numpy()
-    # the kept set may differ only for weights within 1e-6 of the threshold (libm-tail sigmoid): count them
-    if rows.shape[0] != exp.shape[0]:
-        near = np.abs(exp[:, 3] - 0.05) < 1e-6
-        assert abs(rows.shape[0] - exp.shape[0]) <= near.sum()
-        pytest.skip(f"kept-set differs by threshold-adjacent samples: {rows.shape[0]} vs {exp.shape[0]}")
+    # exclude-and-count: the kept set may differ only by samples whose weight lies within 1e-6 of the threshold
+    # (the <= 1-ulp libm tail of torch's CPU sigmoid); such rows are matched out by their bit-exact (place, feature) key,
+    # counted, bounded -- and everything else is compared as strictly as when the sets are equal
+    excluded = 0
+    if rows.shape[0] != exp.shape[0] or count_mismatch(rows[:, :3], exp[:, :3]) != 0:
+        def keys(a):
+            k = np.ascontiguousarray(np.concatenate((a[:, :3], a[:, 4:6]), axis=1)).view(np.uint32)
+            return [r.tobytes() for r in k]
+        kg, ke = keys(rows), keys(exp)
+        sg, se = set(kg), set(ke)
+        only_g = np.array([k not in se for k in kg])
+        only_e = np.array([k not in sg for k in ke])
+        assert (np.abs(rows[only_g, 3] - 0.05) < 1e-6).all() and (np.abs(exp[only_e, 3] - 0.05) < 1e-6).all()
+        excluded = int(only_g.sum() + only_e.sum())
+        assert excluded <= max(4, exp.shape[0] // 100000), excluded
+        rows, exp = rows[~only_g], exp[~only_e]
+    assert rows.shape == exp.shape
     assert count_mismatch(rows[:, :3], exp[:, :3]) == 0
     assert count_mismatch(rows[:, 4:], exp[:, 4:]) == 0
     np.testing.assert_allclose(rows[:, 3], exp[:, 3], rtol=1e-6)
     assert count_mismatch(rows[:, 3], exp[:, 3]) < 1000
+    print(f"threshold-adjacent samples excluded: {excluded} of {exp.shape[0]}")
 
 
 def test_dense_vs_oracle_at_scannet_shape(device):
@@ -336,14 +349,26 @@ def test_channels_last_features_need_no_layout_pass(device):
     assert b.data_ptr() == fcl.data_ptr() and b.is_contiguous() and torch.equal(a, b)
 
 
-def test_dense_traversal_orders_give_identical_volumes(device, monkeypatch):
-    """brick-ordered traversal (default) vs the plain z-fastest order: the same sums in the same view order per voxel --
-    volume and counts bit-identical (ScanNet-sized grid with a ragged last brick: Z = 80 is 2.5 bricks)"""
+def test_dense_traversal_orders_give_identical_volumes(device):
+    """every schedule of the dense kernel -- product default, the round-2 one-gather-at-a-time kernel, plain z-fastest
+    order, two views in flight, LDS-transposed stores, the persistent lockstep grid over 32^3 bricks -- adds the same
+    values in the same view order per voxel: volume and counts bit-identical (ScanNet-sized grid with ragged last
+    bricks: Z = 80 is 2.5 bricks)"""
     from cnrma_amd import rma, synth
     sc = synth.make_scene((6, 32, 60, 80, (72, 100, 80), 4), seed=4)
     feat = rma.to_nhwc(sc["features"][:, 0].to(device))
     proj = sc["projection"][:, 0]
-    vol, cnt = rma.backproject_accum(feat, proj, sc["dims"], 0.04, (0.0, 0.0, 0.0), sc["stride"])
-    monkeypatch.setenv("CNRMA_DENSE_SLAB", "0")
-    vol0, cnt0 = rma.backproject_accum(feat, proj, sc["dims"], 0.04, (0.0, 0.0, 0.0), sc["stride"])
-    assert torch.equal(vol, vol0) and torch.equal(cnt, cnt0) and int(cnt.max()) > 0
+    try:
+        rma.dense_tuning(variant=0, slab=0)
+        vol0, cnt0 = rma.backproject_accum(feat, proj, sc["dims"], 0.04, (0.0, 0.0, 0.0), sc["stride"])
+        assert int(cnt0.max()) > 0
+        for kw in (dict(), dict(variant=0), dict(variant=1, slab=0), dict(variant=1, pipe=2), dict(variant=1, epi=1),
+                   dict(variant=1, pipe=2, epi=1), dict(variant=1, st=32, lockstep=1),
+                   dict(variant=1, st=32, lockstep=1, epi=1, pipe=2), dict(variant=1, st=16, zt=16, tt=4, zi=16),
+                   dict(variant=2), dict(variant=2, slab=0), dict(variant=2, st=32, lockstep=1), dict(variant=2, st=32, lockstep=2),
+                   dict(variant=2, st=24, lockstep=1), dict(variant=1, st=32, lockstep=1, lattice=1), dict(variant=1, st=32, lattice=1)):
+            rma.dense_tuning(**kw)
+            vol, cnt = rma.backproject_accum(feat, proj, sc["dims"], 0.04, (0.0, 0.0, 0.0), sc["stride"])
+            assert torch.equal(vol, vol0) and torch.equal(cnt, cnt0), kw
+    finally:
+        rma.dense_tuning()

@@ -1,0 +1,167 @@
+"""The TIMED path -- pipeline.StaticScene / StaticNet graph replay, what bench.py measures -- compared DIRECTLY with the
+pinned fixtures and the oracle (not with the eager path): dense volume / counts / point places bit-exact against the
+reference's golden vectors, aggregated features and every head output within the north star's 1e-4 of the oracle,
+every level's coordinate set bit-exact.  Reference: ray_marching.py:220-307, :687-807; fcaf3d_backbone.py:89-107;
+fcaf3d_head.py:107-139, :275-349."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import SCENES, count_mismatch, load_golden, t
+from oracle import rma_oracle as RO
+from oracle import sparse_oracle as SO
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _model(C, dev):
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
+    torch.manual_seed(0)
+    backbone = FCAF3DBackbone(C, 34)
+    head = FCAF3DHead(18, (64, 128, 256, 512), 128, 6, 0.01, 2000, None, test_cfg=dict(nms_pre=100))
+    backbone.init_weights()
+    head.init_weights()
+    return backbone.to(dev).eval(), head.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_graph_replay_vs_reference_golden(device, name):
+    """graph replay of the whole scene pass on the reference's own fixture scenes: volume / count bit-exact, the
+    aggregated points (all kept: M <= max_points) in the reference's order with bit-exact places and features within
+    1e-4 (2e-6 achieved), on the first replay and on a replay after another scene went through the same graph"""
+    from cnrma_amd import pipeline
+    g = load_golden(name)
+    feat, proj, tsdf = t(g["features"], device), t(g["projection"]), t(g["tsdf"], device)
+    pinv = t(g["proj_inv"])            # pinned input: LAPACK's inverse is not bit-stable across host CPUs
+    backbone, head = _model(feat.shape[1], device)
+    cfg = pipeline.SceneConfig(g["dims"], voxel_size=g["voxel_size"], origin=g["origin"], stride=g["stride"],
+                               n_steps=g["n_steps"], thr=g["thr"], max_points=500000, sample_seed=11)
+    st = pipeline.StaticScene(cfg, backbone, head, device)
+    st.build(feat, proj, tsdf, proj_inv=pinv)
+    assert st.graph is not None
+    exp = g["points"]
+    for rep in range(3):
+        if rep == 1:                   # push different inputs through the graph in between
+            st.run(feat.flip(0) * 0.5, proj, tsdf * 0.9, proj_inv=pinv)
+            continue
+        out = st.run(feat, proj, tsdf, proj_inv=pinv)
+        b, s, info = pipeline.StaticScene.detections(out)
+        assert (out["count"].cpu().numpy() == g["dense_count"]).all()
+        assert count_mismatch(out["volume"], g["dense_volume"]) == 0
+        coords, pf, n_sel = out["points"]
+        assert info["M"] == exp.shape[0] == int(n_sel) == info["M_selected"]
+        n = exp.shape[0]
+        assert count_mismatch(coords[:n], exp[:, :3]) == 0
+        np.testing.assert_allclose(pf[:n].cpu().numpy(), exp[:, 3:], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(pf[:n].cpu().numpy(), exp[:, 3:], rtol=2e-6, atol=1e-7)     # what we actually achieve
+        assert b.shape[0] == s.shape[0] > 0 and bool(torch.isfinite(b).all())
+
+
+def _fcaf3d_case(n_cls=18, n_reg=6, yaw="fcaf3d"):
+    from test_sparse_gpu import _randomise
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    from projects.mvsdetection.models.fcaf3d_head import FCAF3DHead
+    rng = np.random.RandomState(3)
+    pts = rng.rand(30000, 3).astype(np.float32) * np.array([2.0, 1.6, 1.2], dtype=np.float32) - 0.3
+    pts[:10000, 2] = -0.3 + 0.01 * rng.rand(10000)
+    pts[10000:20000, 0] = 1.7 - 0.01 * rng.rand(10000)
+    feats = rng.randn(30000, 32).astype(np.float32)
+    backbone = FCAF3DBackbone(32, 34)
+    head = FCAF3DHead(n_classes=n_cls, in_channels=(64, 128, 256, 512), out_channels=128, n_reg_outs=n_reg, voxel_size=0.01,
+                      pts_threshold=1500, assigner=None, yaw_parametrization=yaw, test_cfg=dict(nms_pre=300, iou_thr=.5, score_thr=.01))
+    _randomise(backbone, 1)
+    _randomise(head, 2)
+    torch.manual_seed(7)
+    head.init_weights()
+    with torch.no_grad():
+        for sc in head.scales:
+            sc.scale.fill_(1.3)
+    return pts, feats, backbone.eval(), head.eval()
+
+
+@pytest.mark.parametrize("margin", [1.2, 1.7])
+def test_graph_replay_fcaf3d_vs_oracle(device, margin):
+    """voxelise -> MinkResNet34 -> neck / head -> decode as a captured graph (capacity-sized tensors, device-side row
+    counts) against oracle/sparse_oracle.py DIRECTLY: coordinate sets of all levels bit-exact, features / head outputs
+    within 1e-4, decoded boxes of the coarsest level within 1e-3 -- at two capacity margins (the split of short layers
+    over kernel offsets follows the capacity, so the rounding order differs between them; both must hold 1e-4)"""
+    from cnrma_amd import pipeline
+    pts, feats, backbone, head = _fcaf3d_case()
+    Cq, Fq, _ = RO.voxelize(torch.from_numpy(pts), torch.from_numpy(feats), 0.01)
+    levels = SO.backbone_forward(backbone, Cq.numpy(), Fq.numpy())
+    exp = SO.head_forward(head, levels)
+    backbone.to(device); head.to(device)
+    net = pipeline.StaticNet(backbone, head, 0.01, device, margin=margin)
+    P, F = torch.from_numpy(pts).to(device), torch.from_numpy(feats).to(device)
+    net.build(P, F, cap=32768)
+    assert net.graph is not None
+    net.run(P.flip(0)[:20000].contiguous(), F[:20000] * 2.0)          # other inputs through the same graph first
+    out = net.run(P, F)
+    b, s, info = pipeline.StaticScene.detections(out)
+    assert info["M_unique"] == len(Cq)
+    for o, n, (c, f, ts) in zip(out["levels"], info["level_rows"], levels):
+        assert n == len(c) and o.cs.stride == ts
+        got_c = o.cs.C[:n].cpu().numpy().astype(np.int64)
+        k1, k2 = np.argsort(SO._key(got_c), kind="stable"), np.argsort(SO._key(c), kind="stable")
+        assert (got_c[k1] == np.asarray(c)[k2]).all()                 # coordinate set bit-exact
+        f1, f2 = o.F[:n].cpu().numpy()[k1], np.asarray(f)[k2]
+        np.testing.assert_allclose(f1, f2, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(f2).max())))
+    hd = out["head"]
+    for i in range(4):
+        e, n = exp[i], info["head_rows"][i]
+        got_pts = hd["points"][i][:n].cpu().numpy()
+        ck = SO._key(np.concatenate((np.zeros((n, 1)), np.round(got_pts / 0.01)), axis=1).astype(np.int64))
+        ek = SO._key(e["coords"])
+        assert len(ck) == len(ek)
+        common = np.intersect1d(ck, ek)
+        assert len(common) >= 0.99 * len(ek)
+        gi = np.argsort(ck)[np.searchsorted(np.sort(ck), common)]
+        ei = np.argsort(ek)[np.searchsorted(np.sort(ek), common)]
+        for key in ("centerness", "bbox_pred", "cls_score"):
+            g_, e_ = hd[key][i][:n].cpu().numpy()[gi].astype(np.float64), e[key][ei]
+            if key == "bbox_pred":      # exp(scale * reg): compare the exponent (random weights can overflow fp32)
+                with np.errstate(over="ignore", divide="ignore"):
+                    g_ = np.concatenate((np.log(g_[:, :6]), g_[:, 6:]), axis=1)
+                    e_ = np.concatenate((np.log(e_[:, :6]), e_[:, 6:]), axis=1)
+                fin = np.isfinite(e_) & (np.abs(e_) < 80)
+                g_, e_ = g_[fin], e_[fin]
+            np.testing.assert_allclose(g_, e_, rtol=TOL, atol=TOL * max(1.0, np.abs(e_).max()))
+    # decoded boxes of level 3 (no top-k cut at this size): the graph's padded block vs the oracle's decode
+    n3, r0 = info["head_rows"][3], sum(out["sizes"][:3])
+    b3 = out["bboxes"][r0:r0 + n3].cpu().numpy()
+    p3 = hd["points"][3][:n3].cpu().numpy()
+    b_exp = SO.decode_boxes(torch.from_numpy(exp[3]["points"]), torch.from_numpy(exp[3]["bbox_pred"]), "fcaf3d").numpy()
+    o1 = np.lexsort(np.round(p3 / 0.01).T)
+    o2 = np.lexsort(np.round(exp[3]["points"] / 0.01).T)
+    ok = np.isfinite(b_exp[o2]).all(axis=1) & (np.abs(b_exp[o2]).max(axis=1) < 1e4)
+    assert ok.sum() > 0
+    np.testing.assert_allclose(b3[o1][ok], b_exp[o2][ok], rtol=1e-3, atol=1e-3)
+
+
+def test_run_orders_itself_behind_the_producer_stream(device):
+    """the 2D backbone / Atlas head write the inputs on the caller's stream: run() must wait for them (and keep their
+    memory alive) -- features produced by a long-running kernel chain immediately before run(), then freed"""
+    from cnrma_amd import pipeline, synth
+    sc = synth.make_scene("tiny", seed=0)
+    feat0, proj, tsdf = sc["features"][:, 0].to(device), sc["projection"][:, 0], sc["tsdf"][0, 0].to(device)
+    backbone, head = _model(feat0.shape[1], device)
+    cfg = pipeline.SceneConfig(sc["dims"], stride=sc["stride"], max_points=20000, sample_seed=5)
+    st = pipeline.StaticScene(cfg, backbone, head, device)
+    st.build(feat0, proj, tsdf)
+    ref = st.run(feat0, proj, tsdf)
+    torch.cuda.synchronize()
+    ref_vol, ref_b = ref["volume"].clone(), ref["bboxes"].clone()
+    big = torch.randn(4096, 4096, device=device)
+    for _ in range(3):
+        junk = big @ big                                   # keeps the default stream busy for a while
+        feat = feat0 * 3.0
+        feat = feat / 3.0 * 1.0 + (junk[0, 0] * 0.0)       # produced on the default stream, late
+        feat = (feat0 + (feat - feat)).contiguous()       # == feat0, but a fresh allocation written just now
+        out = st.run(feat, proj, tsdf)
+        del feat                                           # the allocator may hand the block out again right away
+        scratch = torch.full((3, 8, 30, 40), 7.0, device=device)
+        b, s, info = pipeline.StaticScene.detections(out)
+        assert torch.equal(out["volume"], ref_vol) and torch.equal(out["bboxes"], ref_b)
+        del scratch
