@@ -71,7 +71,10 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="no graphs: the eager path (device->host reads per scene)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the S block and the f32-convolution block")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S block, the f32-convolution block and the plugin block")
+    ap.add_argument("--through-plugin", action="store_true",
+                    help="drive the registered RayMarching detector -- model(return_loss=False, **data), {scene}_bbox_raw.npz "
+                         "written per scene -- instead of pipeline.StaticScene directly")
     return ap.parse_args()
 
 
@@ -283,8 +286,9 @@ def cpu_baseline(shape_name, Ms_full, C):
 class Workload:
     """>= n_scenes distinct synthetic scenes of one shape resident in HBM + `slots` captured scene graphs"""
 
-    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6):
+    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6, plugin=False):
         import torch
+        self.plugin = plugin
         from cnrma_amd import pipeline, synth
         self.torch, self.pipeline = torch, pipeline
         self.name, self.device, self.rank, self.world, self.args = name, device, rank, world, args
@@ -295,14 +299,54 @@ class Workload:
             self.scenes.append(dict(features=sc["features"][:, 0].contiguous(), projection=sc["projection"][:, 0],
                                     tsdf=sc["tsdf"][0, 0].to(device)))
         self.input_bytes = sum(s["features"].numel() * 4 + s["tsdf"].numel() * 4 for s in self.scenes)
-        self.backbone, self.head = build_model(self.C, device, n_classes, n_reg)
+        if plugin:
+            self._build_plugin_model(n_classes, n_reg)
+            for i, sc_ in enumerate(self.scenes):       # what the DataContainer scatter hands the detector: device tensors
+                sc_.update(projection_dev=sc_["projection"].to(device), name=f"scene{rank:02d}{i:02d}_00",
+                           offset=torch.tensor([0.04 * i, -0.04 * i, 0.0], device=device))
+        else:
+            self.backbone, self.head = build_model(self.C, device, n_classes, n_reg)
         self.cfg = pipeline.SceneConfig(self.dims, stride=self.stride, max_points=500000, sampler="device")
         self.det_w = (6 if n_reg == 6 else 7) + n_classes
         self.slots = []
         self._k = 0
 
+    def _build_plugin_model(self, n_classes, n_reg):
+        """the registered detector built from the ScanNet config's model section (hot-path form: feature maps and TSDF
+        come in as inputs), at this workload's shape; device point sampler (the graph path's precondition)"""
+        import runpy
+        import tempfile
+        import torch
+        import projects.mvsdetection  # noqa: F401
+        from projects.mvsdetection.registry import build_model as build_detector
+        cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+        m = dict(cfg["model"])
+        self.save_dir = tempfile.mkdtemp(prefix="cnrma_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None, save_path=self.save_dir,
+                 voxel_dim_test=list(self.dims), voxel_dim_train=list(self.dims), backbone2d_stride=self.stride,
+                 max_points=500000, point_sampler="device", static_slots=self.args.slots, static_calibration=self.args.scenes)
+        m["detection_backbone"] = dict(type="FCAF3DBackbone", in_channels=self.C, depth=34)
+        torch.manual_seed(0)
+        model = build_detector(m)
+        model.detection_backbone.init_weights()
+        model.detection_head.init_weights()
+        self.model = model.to(self.device).eval()
+        self.backbone, self.head = self.model.detection_backbone, self.model.detection_head
+
+    def _plugin_scene(self, s):
+        return self.model(return_loss=False, features=[s["features"]], projection=[s["projection_dev"]], tsdf=s["tsdf"],
+                          offset=[s["offset"]], scene=[s["name"]])
+
     def build(self):
         torch, pipeline = self.torch, self.pipeline
+        if self.plugin:
+            with torch.no_grad():
+                for s in self.scenes:                            # the calibration scenes (eager); the last one builds the slots
+                    self._plugin_scene(s)
+            ctx = next(iter(self.model._static.values()))
+            assert ctx["built"]
+            self.slots = ctx["slots"]
+            return
         if self.args.eager:
             return
         first = pipeline.StaticScene(self.cfg, self.backbone, self.head, self.device)
@@ -321,7 +365,7 @@ class Workload:
     def alloc_step_buffers(self, sps):
         torch = self.torch
         self.sps = sps
-        if self.args.eager:
+        if self.args.eager or self.plugin:
             return
         torch.cuda.synchronize()
         n_det, n_lvl = self.slots[0].out["bboxes"].shape[0], self.slots[0].out["valid"].shape[0]     # padded rows, levels
@@ -334,6 +378,12 @@ class Workload:
     def step(self):
         """one wave of sps scenes on this GPU (+ one all-gather of the detections when there are several ranks)"""
         torch = self.torch
+        if self.plugin:
+            with torch.no_grad():
+                for j in range(self.sps):
+                    self._plugin_scene(self.scenes[self._k % len(self.scenes)])
+                    self._k += 1
+            return
         if self.args.eager:
             for j in range(self.sps):
                 s = self.scenes[self._k % len(self.scenes)]
@@ -364,13 +414,26 @@ class Workload:
             for st in self.slots:                               # the next wave overwrites det: after the collective
                 st.stream.wait_stream(main)
 
+    def drain(self):
+        """end of a timed window: every result of the window is where its consumer reads it (plugin: the files)"""
+        if self.plugin:
+            self.model.flush()
+
     def violations(self):
+        if self.plugin:
+            return int(getattr(self.model, "static_fallbacks", 0))
         if self.args.eager:
             return 0
         self.torch.cuda.synchronize()
         return int(sum(int(b.item()) for b in self.bad))
 
     def sizes(self):
+        if self.plugin:
+            st = self.slots[0]
+            st.run(self.scenes[0]["features"], self.scenes[0]["projection"], self.scenes[0]["tsdf"])
+            _, _, info = self.pipeline.StaticScene.detections(st.out)
+            return dict(M_rows=info["M"], M_selected=info["M_selected"], M_unique=info["M_unique"], level_rows=info["level_rows"],
+                        head_rows=info["head_rows"])
         if self.args.eager:
             o = self.last
             return dict(M_rows=o["M"], M_selected=o["M_selected"], M_unique=o["M_unique"], level_rows=o["level_rows"],
@@ -389,6 +452,7 @@ def time_windows(wl, args, world, barrier):
     t0 = time.perf_counter()
     for _ in range(max(1, args.warmup)):
         wl.step()
+    wl.drain()
     barrier()
     warm = (time.perf_counter() - t0) / max(1, args.warmup) / sps        # seconds per scene, warm-up estimate
     if not args.scenes_per_step:
@@ -410,6 +474,7 @@ def time_windows(wl, args, world, barrier):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             wl.step()
+        wl.drain()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -421,7 +486,7 @@ def time_windows(wl, args, world, barrier):
     return sps, secs
 
 
-def measure(name, device, rank, world, args, barrier, precision=None):
+def measure(name, device, rank, world, args, barrier, precision=None, plugin=False):
     """build + time one workload; returns the result block"""
     import torch
     from cnrma_amd import sparse as S
@@ -430,7 +495,7 @@ def measure(name, device, rank, world, args, barrier, precision=None):
         S.CONV_PRECISION = precision
     try:
         log(f"workload {name}{' (' + precision + ' conv)' if precision else ''}: generating {args.scenes} scenes")
-        wl = Workload(name, device, rank, world, args)
+        wl = Workload(name, device, rank, world, args, plugin=plugin)
         log("calibrating + capturing the scene graphs")
         wl.build()
         log("timing")
@@ -547,13 +612,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    wl, main_block = measure(args.workload, device, rank, world, args, barrier)
+    wl, main_block = measure(args.workload, device, rank, world, args, barrier, plugin=args.through_plugin)
     V, C, H, W, dims, stride = wl.V, wl.C, wl.H, wl.W, wl.dims, wl.stride
     result = {
         "metric": "scenes/sec fwd (40-view->192^3 voxel): dense unprojection + RMA + voxelise + FCAF3D + decode",
         "value": main_block["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (sparse convolutions f16x3: 22-bit operands, fp32 accumulate; block f32_conv = exact fp32)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}, NCHW fp32 as the 2D "
                                f"backbone writes them; the layout pass to channels-last is inside the timed path), grid "
                                f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000 (device sampler: "
@@ -581,6 +646,22 @@ def main():
     del wl
     torch.cuda.empty_cache()
 
+    if args.through_plugin:
+        result["config"]["driver"] = ("registered RayMarching detector: model(return_loss=False, **data) per scene, "
+                                      "{scene}_bbox_raw.npz written per scene (tmpfs), flush inside the timed window")
+    if not args.no_secondary and not args.through_plugin:
+        # ---- the same workload driven through the plugin API (test.py:205-214 -> RayMarching.forward_test)
+        wlp, bp = measure(args.workload, device, rank, world, args, barrier, plugin=True)
+        result["through_plugin"] = {k: bp[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step",
+                                                        "windows_scenes_per_s", "plan_violations", "host_cpu_cores_busy")}
+        result["through_plugin"]["ratio_to_value"] = bp["value"] / main_block["value"]
+        result["through_plugin"]["note"] = ("the same workload through projects.mvsdetection RayMarching: model(return_loss=False, "
+                                            "features=[..], projection=[..], tsdf=.., offset=[..], scene=[..]) per scene, "
+                                            "{scene}_bbox_raw.npz written per scene (tmpfs), model.flush() inside the window")
+        import shutil
+        shutil.rmtree(wlp.save_dir, ignore_errors=True)
+        del wlp
+        torch.cuda.empty_cache()
     if not args.no_secondary:
         # ---- the same workload with exact-fp32 MFMA convolutions (every rank takes part: the windows hold collectives)
         wl32, b32 = measure(args.workload, device, rank, world, args, barrier, precision="f32")

@@ -33,6 +33,12 @@ class SceneConfig:
         self.sample_seed = sample_seed        # device sampler: fixed seed (None = a fresh subset per call)
 
 
+def _offset_list(offset):
+    if offset is None:
+        return (0.0, 0.0, 0.0)
+    return tuple(float(x) for x in torch.as_tensor(offset, dtype=torch.float32).detach().reshape(3).cpu().tolist())
+
+
 class StageTimer:
     """optional per-stage HIP-event timing on the current stream"""
 
@@ -247,16 +253,19 @@ class StaticScene:
         self.proj_inv = torch.empty((V, 4, 4), dtype=torch.float32, device=dev)
         self.tsdf = torch.empty(tuple(self.cfg.dims), dtype=torch.float32, device=dev)
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.offset_dev = torch.zeros(3, dtype=torch.float32, device=dev)       # switch_pointcloud's per-scene offset
+        self._pin_off = torch.zeros(3, dtype=torch.float32, pin_memory=True)
         self._pin_proj = torch.empty((V, 3, 4), dtype=torch.float32, pin_memory=True)
         self._pin_inv = torch.empty((V, 4, 4), dtype=torch.float32, pin_memory=True)
 
-    def _load(self, features_nchw, projections, tsdf, proj_inv=None):
+    def _load(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
         """stage one scene's inputs into the static buffers (on self.stream, which must be current).  proj_inv: the
         [V,4,4] inverse of [P/stride; 0 0 0 1] when the caller pins it (parity tests: LAPACK's inverse is not bit-stable
         across host CPUs); computed here on the host like ray_marching.py:96-102 otherwise."""
         if self._copied is not None:
             self._copied.synchronize()           # the previous scene's copies out of the pinned buffers have executed
-        rma.to_nhwc(features_nchw, out=self.nhwc)
+        if features_nchw is not None:            # None: the caller's layout pass already wrote into self.nhwc
+            rma.to_nhwc(features_nchw, out=self.nhwc)
         p = projections.detach().to("cpu", torch.float32)
         self._pin_proj.copy_(rma.scale_projection(p, self.cfg.stride))
         self._pin_inv.copy_(rma.projection_inverse(p, self.cfg.stride) if proj_inv is None
@@ -264,6 +273,11 @@ class StaticScene:
         self.proj_scaled.copy_(self._pin_proj, non_blocking=True)
         self.proj_inv.copy_(self._pin_inv, non_blocking=True)
         self.tsdf.copy_(tsdf.reshape(self.tsdf.shape), non_blocking=True)
+        if offset is None:
+            self._pin_off.zero_()
+        else:
+            self._pin_off.copy_(torch.as_tensor(offset, dtype=torch.float32).detach().reshape(3).cpu())
+        self.offset_dev.copy_(self._pin_off, non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()
 
@@ -291,7 +305,8 @@ class StaticScene:
                 self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                 max_points=cfg.max_points, seed=cfg.sample_seed if fixed else 0x5EED,
                 seed_dev=None if fixed else self.seed_dev)
-            out.update(trace_net(plan, self.backbone, self.head, coords, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
+            moved = coords + self.offset_dev     # ray_marching.py:364 (one fp32 add per coordinate, as the reference)
+            out.update(trace_net(plan, self.backbone, self.head, moved, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
                                  extra_counts=[info["M"], n_sel]))
             if not fixed:
                 self.seed_dev.add_(1)            # the next replay draws a fresh point subset
@@ -299,7 +314,7 @@ class StaticScene:
         out.update(points=(coords, feats, n_sel))
         return out
 
-    def calibrate(self, features_nchw, projections, tsdf, proj_inv=None):
+    def calibrate(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
         """one eager forward under a recording plan; several calls (several scenes of the configuration) are merged:
         capacities then cover the largest of them.  Returns the eager result."""
         _lib.require_gpu()
@@ -308,7 +323,7 @@ class StaticScene:
             plan = P.Plan(self.margin)
             with P.using(plan):
                 eager = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense,
-                                      proj_inv=proj_inv)
+                                      proj_inv=proj_inv, offset=_offset_list(offset))
         self.plan = plan if self.plan is None else self.plan.merge(plan)
         return eager
 
@@ -336,13 +351,13 @@ class StaticScene:
                 self.stream.synchronize()
         return eager
 
-    def run(self, features_nchw, projections, tsdf, proj_inv=None):
+    def run(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
         """enqueue one scene on self.stream (ordered behind the caller's current stream, which produced the inputs);
         returns the static output dict (device tensors, valid until the next run; consumers on another stream wait on
         `self.done` first -- detections() does)."""
         self._enter(features_nchw, tsdf)
         with torch.cuda.stream(self.stream):
-            self._load(features_nchw, projections, tsdf, proj_inv)
+            self._load(features_nchw, projections, tsdf, proj_inv, offset)
             if self.graph is not None:
                 self.graph.replay()
             else:
@@ -386,13 +401,13 @@ class StaticScene:
             info.update(M=counts[0], M_selected=counts[1])
         return out["bboxes"].index_select(0, rows), out["scores"].index_select(0, rows), info
 
-    def detect(self, features_nchw, projections, tsdf, rebuild_after=4):
+    def detect(self, features_nchw, projections, tsdf, rebuild_after=4, offset=None):
         """run() + detections() with the fallback a server wants: a scene that outgrows the size plan (status != 0) is
         re-run through the eager path (sizes read back from the device) and its sizes are kept; after `rebuild_after`
         such scenes the plan is enlarged and the graph captured again (rebuild()), so a deployment whose scenes grew
         stops paying a replay plus an eager pass per scene.  Returns (bboxes, scores, info); info["static"] tells which
         path produced them."""
-        out = self.run(features_nchw, projections, tsdf)
+        out = self.run(features_nchw, projections, tsdf, offset=offset)
         try:
             with torch.cuda.stream(self.stream):          # the read-back waits on the stream the graph runs on
                 b, s, info = self.detections(out)
@@ -402,7 +417,8 @@ class StaticScene:
             with torch.cuda.stream(self.stream):
                 grown = P.Plan(self.margin)
                 with P.using(grown):
-                    e = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense)
+                    e = forward_scene(self.cfg, self.backbone, self.head, features_nchw, projections, tsdf, dense=self.dense,
+                                      offset=_offset_list(offset))
             prev = getattr(self, "outgrown", None)
             same = prev is not None and len(prev.sizes) == len(grown.sizes) and len(prev.flags) == len(grown.flags)
             self.outgrown = prev.merge(grown) if same else grown

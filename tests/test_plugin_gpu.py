@@ -203,3 +203,40 @@ def test_raymarching_train_step_with_atlas3d(device, tmp_path):
     assert torch.isfinite(out["loss"]) and torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
     g3d = [p.grad for p in model.backbone3d.parameters()]
     assert all(g is not None and torch.isfinite(g).all() for g in g3d)
+
+
+def test_forward_test_graph_path_writes_the_same_files_as_the_eager_path(device, tmp_path):
+    """the inference fast path of the plugin (point_sampler="device": scenes of a repeating shape as replayed HIP graphs,
+    several in flight, files written when a slot is reused / at flush()) against the eager path of the same detector on
+    the same scenes: same files, same keys, same row counts, boxes / scores within 1e-4 -- per-scene offsets included"""
+    from cnrma_amd import synth
+    scenes = []
+    for i in range(7):
+        sc = synth.make_scene("tiny", seed=i, boxes=i % 3)
+        scenes.append(dict(features=[sc["features"][:, 0].to(device)], projection=[sc["projection"][:, 0].to(device)],
+                           tsdf=sc["tsdf"].to(device), offset=[torch.tensor([0.25 * i, -0.5, 0.125 * (i % 2)], device=device)],
+                           scene=[f"scene{i:04d}_00"]))
+    dims = synth.SHAPES["tiny"][4]
+    fast = _model(tmp_path / "fast", dims, device, max_points=100000)
+    fast.point_sampler, fast.static_slots, fast.static_calibration = "device", 2, 3
+    slow = _model(tmp_path / "slow", dims, device, max_points=100000)
+    slow.point_sampler, slow.static_test = "device", False
+    slow.load_state_dict(fast.state_dict())
+    with torch.no_grad():
+        for d in scenes:
+            assert fast(return_loss=False, **d) == [{}]
+            assert slow(return_loss=False, **d) == [{}]
+    ctx = next(iter(fast._static.values()))
+    assert ctx["built"] and len(ctx["slots"]) == 2 and ctx["k"] == 4            # 3 calibration scenes, 4 graph replays
+    assert sum(p is not None for p in ctx["pending"]) == 2                      # two scenes still in flight
+    fast.flush()
+    assert getattr(fast, "static_fallbacks", 0) == 0
+    for d in scenes:
+        n = d["scene"][0]
+        a = np.load(tmp_path / "fast" / "results" / n / f"{n}_bbox_raw.npz")
+        b = np.load(tmp_path / "slow" / "results" / n / f"{n}_bbox_raw.npz")
+        assert set(a.files) == set(b.files) == {"bboxes", "scores"} and a["bboxes"].shape == b["bboxes"].shape
+        ka = np.lexsort(tuple(np.round(a["bboxes"][:, i], 3) for i in range(5, -1, -1)))
+        kb = np.lexsort(tuple(np.round(b["bboxes"][:, i], 3) for i in range(5, -1, -1)))
+        np.testing.assert_allclose(a["bboxes"][ka], b["bboxes"][kb], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(a["scores"][ka], b["scores"][kb], rtol=1e-4, atol=1e-6)
