@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--through-plugin", action="store_true",
                     help="drive the registered RayMarching detector -- model(return_loss=False, **data), {scene}_bbox_raw.npz "
                          "written per scene -- instead of pipeline.StaticScene directly")
+    ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
+                    "'variant=0' = the round-2 kernel (cnrma_debug_dense_tuning; never set by the driver)")
     return ap.parse_args()
 
 
@@ -334,7 +336,7 @@ class Workload:
         self.backbone, self.head = self.model.detection_backbone, self.model.detection_head
 
     def _plugin_scene(self, s):
-        return self.model(return_loss=False, features=[s["features"]], projection=[s["projection_dev"]], tsdf=s["tsdf"],
+        return self.model(return_loss=False, features=[s["features"]], projection=[s["projection_dev"]], tsdf=s["tsdf"][None, None],
                           offset=[s["offset"]], scene=[s["name"]])
 
     def build(self):
@@ -611,6 +613,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.dense_tuning:
+        from cnrma_amd import rma
+        rma.dense_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.dense_tuning.split(","))})
 
     wl, main_block = measure(args.workload, device, rank, world, args, barrier, plugin=args.through_plugin)
     V, C, H, W, dims, stride = wl.V, wl.C, wl.H, wl.W, wl.dims, wl.stride
