@@ -48,6 +48,8 @@ PMC_TRAFFIC = {
 }
 
 
+PASS_DEFAULT = {}             # workload -> scenes per sparse-network pass (measured: see DESIGN.md "Scenes per pass")
+
 _T0 = time.perf_counter()
 
 
@@ -65,6 +67,9 @@ def parse():
     ap.add_argument("--workload", default="NS", help="NS = north-star shape (default); S = ScanNet config; St; tiny")
     ap.add_argument("--slots", type=int, default=3, help="scene graphs in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--scenes", type=int, default=8, help="distinct scenes rotated per GPU")
+    ap.add_argument("--scenes-per-pass", type=int, default=0,
+                    help="scenes collated into one sparse-network pass per graph (pipeline.StaticBatch; 1 = one scene per graph, "
+                         "0 = the workload's default)")
     ap.add_argument("--scenes-per-step", type=int, default=0, help="0 = chosen from the warm-up (see --window-s)")
     ap.add_argument("--window-s", type=float, default=2.0, help="minimum length of one timed window of K steps")
     ap.add_argument("--windows", type=int, default=3)
@@ -355,6 +360,18 @@ class Workload:
         for s in self.scenes:                                    # capacities cover every scene of the rotation
             first.calibrate(s["features"], s["projection"], s["tsdf"])
         s0 = self.scenes[0]
+        self.B = self.args.scenes_per_pass or PASS_DEFAULT.get(self.name, 1)
+        if self.B > 1:
+            group = [(s_["features"], s_["projection"], s_["tsdf"]) for s_ in self.scenes[:self.B]]
+            self.slots = []
+            for _ in range(self.args.slots):
+                sb = pipeline.StaticBatch(self.cfg, self.backbone, self.head, self.device, self.B)
+                sb.build(group, first.plan)
+                self.slots.append(sb)
+            del first
+            self.bad = [torch.zeros(1, dtype=torch.int32, device=self.device) for _ in self.slots]
+            self.det = None
+            return
         first.build(s0["features"], s0["projection"], s0["tsdf"])
         self.slots = [first]
         for _ in range(1, self.args.slots):
@@ -370,7 +387,8 @@ class Workload:
         if self.args.eager or self.plugin:
             return
         torch.cuda.synchronize()
-        n_det, n_lvl = self.slots[0].out["bboxes"].shape[0], self.slots[0].out["valid"].shape[0]     # padded rows, levels
+        o0 = self.slots[0].out
+        n_det, n_lvl = o0["bboxes"].shape[-2], o0["valid"].shape[-1]                                 # padded rows, levels
         self.det = torch.zeros((sps, n_det, self.det_w), dtype=torch.float32, device=self.device)
         self.det_valid = torch.zeros((sps, n_lvl), dtype=torch.int32, device=self.device)
         if self.world > 1:
@@ -393,7 +411,25 @@ class Workload:
                 self.last = self.pipeline.forward_scene(self.cfg, self.backbone, self.head, s["features"], s["projection"], s["tsdf"])
             return
         main = torch.cuda.current_stream()
-        for j in range(self.sps):
+        if getattr(self, "B", 1) > 1:
+            B = self.B
+            for j in range(0, self.sps, B):
+                group = []
+                for _ in range(B):
+                    s = self.scenes[self._k % len(self.scenes)]
+                    self._k += 1
+                    group.append((s["features"], s["projection"], s["tsdf"]))
+                i = (self._k // B) % len(self.slots)
+                sb = self.slots[i]
+                out = sb.run(group)
+                with torch.cuda.stream(sb.stream):
+                    nb = out["bboxes"].shape[2]
+                    self.det[j:j + B, :, :nb].copy_(out["bboxes"], non_blocking=True)
+                    self.det[j:j + B, :, nb:].copy_(out["scores"], non_blocking=True)
+                    self.det_valid[j:j + B].copy_(out["valid"], non_blocking=True)
+                    self.bad[i] += out["status"]
+                self.last_out, self.last_slot = out, sb
+        for j in range(self.sps if getattr(self, "B", 1) <= 1 else 0):
             s = self.scenes[self._k % len(self.scenes)]
             i = self._k % len(self.slots)
             self._k += 1
@@ -440,7 +476,10 @@ class Workload:
             o = self.last
             return dict(M_rows=o["M"], M_selected=o["M_selected"], M_unique=o["M_unique"], level_rows=o["level_rows"],
                         head_rows=o["head_rows"])
-        _, _, info = self.pipeline.StaticScene.detections(self.last_out)
+        if getattr(self, "B", 1) > 1:
+            info = self.last_slot.detections(self.last_out)[0][2]
+        else:
+            _, _, info = self.pipeline.StaticScene.detections(self.last_out)
         return dict(M_rows=info["M"], M_selected=info["M_selected"], M_unique=info["M_unique"], level_rows=info["level_rows"],
                     head_rows=info["head_rows"])
 
@@ -448,7 +487,9 @@ class Workload:
 def time_windows(wl, args, world, barrier):
     """warm-up, choice of scenes_per_step, then `windows` windows of exactly `steps` steps; returns per-window seconds"""
     import torch
-    sps = args.scenes_per_step or max(2, len(wl.slots))
+    q = max(1, len(wl.slots)) * getattr(wl, "B", 1)                     # scenes of one round over the slots
+    sps = args.scenes_per_step or max(2, q)
+    sps = -(-sps // getattr(wl, "B", 1)) * getattr(wl, "B", 1)
     wl.alloc_step_buffers(sps)
     barrier()
     t0 = time.perf_counter()
@@ -459,7 +500,6 @@ def time_windows(wl, args, world, barrier):
     warm = (time.perf_counter() - t0) / max(1, args.warmup) / sps        # seconds per scene, warm-up estimate
     if not args.scenes_per_step:
         want = args.window_s / max(1, args.steps) / max(warm, 1e-6)
-        q = max(1, len(wl.slots))
         sps = int(min(256, max(q, -(-int(want + 0.999) // q) * q)))
         if world > 1:
             import torch.distributed as dist

@@ -1380,9 +1380,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
 
 // per-channel sum / sum of squares in fp64, deterministic two-stage (partials [nblk][2C])
 __global__ __launch_bounds__(256) void colstats_partial_kernel(const float* __restrict__ in, int64_t n_cap,
-                                                               const int32_t* __restrict__ n_dev, int C,
+                                                               const int32_t* __restrict__ n_dev,
+                                                               const int32_t* __restrict__ row0_dev, int C,
                                                                double* __restrict__ part) {
   const int64_t n = live_rows(n_cap, n_dev);
+  if (row0_dev != nullptr) in += (int64_t)__builtin_nontemporal_load(row0_dev) * C;     // a scene's row segment
   // thread -> channel c = tid % C (C <= 256), row group = tid / C
   const int c = threadIdx.x % C;
   const int groups = blockDim.x / C;
@@ -1431,12 +1433,18 @@ __global__ __launch_bounds__(256) void colstats_final_kernel(const double* __res
 }
 
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ in, int64_t n_cap,
-                                                             const int32_t* __restrict__ n_dev, int C,
+                                                             const int32_t* __restrict__ n_dev,
+                                                             const int32_t* __restrict__ row0_dev, int C,
                                                              const double* __restrict__ stats,
                                                              const float* __restrict__ weight,
                                                              const float* __restrict__ bias, float eps, int relu,
                                                              float* __restrict__ out) {
   const int64_t n = live_rows(n_cap, n_dev);
+  if (row0_dev != nullptr) {
+    const int64_t r0 = (int64_t)__builtin_nontemporal_load(row0_dev) * C;
+    in += r0;
+    out += r0;
+  }
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(t % C);
     const float mean = (float)stats[c];
@@ -2244,17 +2252,17 @@ extern "C" int cnrma_sparse_maxpool_f32(const float* in_feats, int C, const int3
 
 extern "C" size_t cnrma_instnorm_workspace_bytes(int C) { return (size_t)(1024 * 2 * C + 2 * C) * sizeof(double); }
 
-extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, int C,
-                                         const float* weight, const float* bias, float eps, int relu,
-                                         float* out_feats, double* stats_ws, void* stream) {
+extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev,
+                                         const int32_t* row0_dev, int C, const float* weight, const float* bias, float eps,
+                                         int relu, float* out_feats, double* stats_ws, void* stream) {
   if (n_cap <= 0 || C <= 0 || C > 256) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
   const int nblk = 1024;
   double* part = stats_ws + 2 * C;
-  hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, in_feats, n_cap, n_dev, C, part);
+  hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, in_feats, n_cap, n_dev, row0_dev, C, part);
   hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n_cap, n_dev, stats_ws);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, st, in_feats, n_cap,
-                     n_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
+                     n_dev, row0_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

@@ -119,6 +119,8 @@ def forward_scene(cfg, backbone, head, features_nchw, projections, tsdf, offset=
         cfg.depth_points, offset=offset, max_points=cfg.max_points, sampler=cfg.sampler, mask=mask, seed=cfg.sample_seed)
     tm.mark("rma")
     x, _ = S.voxelize(coords, pfeats, cfg.voxel_size_fcaf3d)
+    if P.current() is not None:
+        P.current().mark("net")              # what follows scales with the number of scenes in a pass (Plan.scaled)
     tm.mark("voxelize")
     levels = backbone(x)
     tm.mark("backbone")
@@ -335,7 +337,7 @@ class StaticScene:
         eager = None
         if plan is not None:
             self.plan = P.Plan(self.margin)
-            self.plan.sizes, self.plan.flags = list(plan.sizes), list(plan.flags)
+            self.plan.sizes, self.plan.flags, self.plan.marks = list(plan.sizes), list(plan.flags), dict(plan.marks)
         elif self.plan is None:
             eager = self.calibrate(features_nchw, projections, tsdf, proj_inv)
         self._enter(features_nchw, tsdf)
@@ -375,7 +377,7 @@ class StaticScene:
             self.plan = self.plan.merge(self.outgrown) if len(self.plan.sizes) == len(self.outgrown.sizes) else self.outgrown
             self.outgrown, self.n_outgrown = None, 0
         fresh = P.Plan(self.margin)
-        fresh.sizes, fresh.flags = list(self.plan.sizes), list(self.plan.flags)
+        fresh.sizes, fresh.flags, fresh.marks = list(self.plan.sizes), list(self.plan.flags), dict(self.plan.marks)
         self.plan = None
         return self.build(features_nchw, projections, tsdf, capture=True, plan=fresh)
 
@@ -429,6 +431,124 @@ class StaticScene:
                 self.rebuild(features_nchw, projections, tsdf)
                 info["rebuilt"] = True
             return e["bboxes"], e["scores"], info
+
+
+class StaticBatch:
+    """Several scenes per static pass: the geometric half (layout, dense unprojection, march, selection) per scene, then
+    ONE collated multi-scene sparse tensor (batch id = scene, what ME.utils.batch_sparse_collate builds for B samples,
+    ray_marching.py:328-330) through the backbone / neck / head, per-scene instance norm / pruning / decode with
+    device-side row counts -- captured as ONE HIP graph.  The ~300 latency-bound launches of the network (35 of its 51
+    convolutions run on < 12 k rows per scene) are thereby shared by the scenes of a pass.
+
+    The size plan is derived from a calibrated SINGLE-scene plan (Plan.scaled): per-scene capacities for the geometric
+    half, n_scenes x the single-scene capacities for the network."""
+
+    def __init__(self, cfg, backbone, head, device, n_scenes, margin=1.2, dense=True, stream=None):
+        self.cfg, self.backbone, self.head = cfg, backbone, head
+        self.device = torch.device(device)
+        self.B, self.margin, self.dense = int(n_scenes), margin, dense
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        # input holders: one StaticScene per scene of the pass, used for its static input buffers and its loader only
+        self.holders = [StaticScene(cfg, backbone, head, device, margin, dense, stream=self.stream) for _ in range(self.B)]
+        self.graph = self.plan = self.out = None
+
+    def build(self, scenes, plan, capture=True):
+        """scenes: B tuples (features_nchw, projections, tsdf[, offset]); plan: a calibrated single-scene Plan (merged over
+        the scenes of the configuration, StaticScene.calibrate)."""
+        _lib.require_gpu()
+        assert len(scenes) == self.B
+        self.plan = plan.scaled(self.B)
+        with torch.cuda.stream(self.stream):
+            for h, sc_ in zip(self.holders, scenes):
+                h._alloc_inputs(sc_[0], sc_[2])
+            self._load(scenes)
+            self.out = self._trace()
+            self.stream.synchronize()
+            if capture:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.out = self._trace()
+                self.stream.synchronize()
+
+    def _load(self, scenes):
+        for h, sc_ in zip(self.holders, scenes):
+            h._load(sc_[0], sc_[1], sc_[2], None, sc_[3] if len(sc_) > 3 else None)
+
+    def _trace(self):
+        cfg, plan, B = self.cfg, self.plan, self.B
+        plan.begin_static()
+        out = {}
+        with P.using(plan), torch.no_grad():
+            vols, pts, Ms = [], [], []
+            fixed = cfg.sample_seed is not None
+            for b, h in enumerate(self.holders):                  # the geometric half, scene by scene
+                if self.dense:
+                    vols.append(rma.backproject_accum(h.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin, cfg.stride,
+                                                      proj_scaled=h.proj_scaled))
+                coords, feats, n_sel, info = rma.aggregate_points_static(
+                    h.nhwc, h.proj_inv, h.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
+                    max_points=cfg.max_points, seed=(cfg.sample_seed if fixed else 0x5EED) + 7919 * b * (0 if fixed else 1),
+                    seed_dev=None if fixed else h.seed_dev)
+                pts.append((coords + h.offset_dev, feats, n_sel))
+                Ms += [info["M"].view(1), n_sel.view(1)]
+                if not fixed:
+                    h.seed_dev.add_(1)
+            x = S.sparse_collate_static(pts, cfg.voxel_size_fcaf3d)
+            levels = self.backbone(x)
+            cen, box, cls, pt, css = map(list, self.head(levels, fused=True))
+            bboxes, scores, valid, sizes = self.head.get_bboxes_static_multi(cen, box, cls, pt, css, B)
+            status = plan.status(self.device)
+            per_level = [l.cs.counts_dev()[0] for l in levels] + [c[0].counts_dev()[0] for c in css]
+            counts = torch.cat(Ms + [x.cs.counts_dev()[0]] + per_level).to(torch.int32)
+        plan.end_static()
+        if self.dense:
+            out.update(volume=[v[0] for v in vols], count=[v[1] for v in vols])
+        out.update(bboxes=bboxes, scores=scores, valid=valid, sizes=sizes, status=status, counts=counts, n_levels=len(levels))
+        return out
+
+    def run(self, scenes):
+        """enqueue one pass of B scenes on self.stream; returns the static output dict (valid until the next run)"""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+            for sc_ in scenes:
+                for t_ in (sc_[0], sc_[2]):
+                    if torch.is_tensor(t_) and t_.is_cuda:
+                        t_.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self._load(scenes)
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.out = self._trace()
+            self.done = torch.cuda.Event()
+            self.done.record()
+        self.out["done"] = self.done
+        return self.out
+
+    def detections(self, out):
+        """static outputs -> [(bboxes, scores, info)] per scene; ONE device->host read for the whole pass"""
+        B, L = self.B, len(out["sizes"])
+        if out.get("done") is not None:
+            torch.cuda.current_stream(self.device).wait_event(out["done"])
+        host = _lib.read_ints(torch.cat((out["status"].view(-1), out["valid"].view(-1), out["counts"].view(-1))))
+        if host[0] != 0:
+            raise _lib.CnrmaError(f"{host[0]} capacity / branch assumption(s) of the static plan violated: re-run eagerly")
+        valid = host[1:1 + B * L]
+        counts = host[1 + B * L:]
+        nl = out["n_levels"]
+        res = []
+        for b in range(B):
+            rows, r0 = [], 0
+            for k, v in zip(out["sizes"], valid[b * L:(b + 1) * L]):
+                rows.append(torch.arange(r0, r0 + v, device=self.device))
+                r0 += k
+            rows = torch.cat(rows)
+            lv = counts[2 * B + B:]                               # after (M, M_sel) x B and the B unique counts
+            info = dict(M=counts[2 * b], M_selected=counts[2 * b + 1], M_unique=counts[2 * B + b],
+                        level_rows=[lv[l * B + b] for l in range(nl)], head_rows=[lv[(nl + l) * B + b] for l in range(nl)])
+            res.append((out["bboxes"][b].index_select(0, rows), out["scores"][b].index_select(0, rows), info))
+        return res
 
 
 def gather_padded_detections(det, valid, det_all=None, valid_all=None):

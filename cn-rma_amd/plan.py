@@ -49,6 +49,7 @@ class Plan:
     def __init__(self, margin=1.2, slack=256):
         self.margin, self.slack = float(margin), int(slack)
         self.sizes, self.flags = [], []
+        self.marks = {}            # name -> (len(sizes), len(flags)) at the time of mark(): splits the record sequence
         self.static = False
         self._reset()
         self._consts = []          # device constants of the static trace, created by the first (un-captured) static run
@@ -65,6 +66,23 @@ class Plan:
         self.sizes.append(int(n))
         return int(n)
 
+    def mark(self, name):
+        """calibration: remember where in the record sequence a stage begins (scaled() splits there)"""
+        if not self.static:
+            self.marks[name] = (len(self.sizes), len(self.flags))
+
+    def scaled(self, n_scenes, split="net"):
+        """the plan of a pass over `n_scenes` scenes derived from this single-scene plan: the records before the mark
+        (the per-scene geometric half: one aggregation, one voxelisation per scene) are consumed once per scene, entry
+        by entry; the records behind it (the network over the collated tensor) scale with the number of scenes"""
+        i, j = self.marks[split]
+        assert j == 0, "per-scene stages record sizes only"
+        p = Plan(self.margin, self.slack)
+        p.sizes = [s for s in self.sizes[:i] for _ in range(n_scenes)] + [s * n_scenes for s in self.sizes[i:]]
+        p.flags = list(self.flags)
+        p.marks = dict(self.marks)
+        return p
+
     def record_flag(self, f):
         assert not self.static
         self.flags.append(bool(f))
@@ -76,6 +94,7 @@ class Plan:
         valid for both" (see next_flag callers)."""
         assert not self.static and len(self.sizes) == len(other.sizes) and len(self.flags) == len(other.flags), \
             "calibration runs of one configuration must record the same sequence"
+        assert self.marks == other.marks
         self.sizes = [max(a, b) for a, b in zip(self.sizes, other.sizes)]
         self.flags = [a if a == b else None for a, b in zip(self.flags, other.flags)]
         return self

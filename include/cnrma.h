@@ -378,13 +378,15 @@ int cnrma_sparse_convtr_gen_f32(const int32_t* in_coords, const float* in_feats,
 int cnrma_sparse_maxpool_f32(const float* in_feats, int C, const int32_t* nbr, int K, float* out_feats,
                              int64_t no_cap, const int32_t* no_dev, void* stream);
 
-/* MinkowskiInstanceNorm (single scene): per-channel mean / biased variance over all rows, eps = 1e-8,
- * affine (weight, bias), optional ReLU (fcaf3d_backbone.py:29-30).  stats_ws: cnrma_instnorm_workspace_bytes(C);
- * on return stats_ws[0..C) = mean, [C..2C) = biased variance (fp64). */
+/* MinkowskiInstanceNorm of ONE scene's row segment: per-channel mean / biased variance over the rows
+ * [row0, row0 + n) -- row0 = *row0_dev (NULL: 0), n = min(n_cap, *n_dev) --, eps = 1e-8, affine (weight, bias),
+ * optional ReLU (fcaf3d_backbone.py:29-30).  A multi-scene tensor (scene-major rows) takes one call per scene with the
+ * scene's device-side offset / count.  stats_ws: cnrma_instnorm_workspace_bytes(C); on return stats_ws[0..C) = mean,
+ * [C..2C) = biased variance (fp64). */
 size_t cnrma_instnorm_workspace_bytes(int C);
-int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, int C, const float* weight,
-                              const float* bias, float eps, int relu, float* out_feats, double* stats_ws,
-                              void* stream);
+int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, const int32_t* row0_dev, int C,
+                              const float* weight, const float* bias, float eps, int relu, float* out_feats,
+                              double* stats_ws, void* stream);
 
 /* union-add of two sparse tensors at the same tensor stride (`inputs[i] + x`, fcaf3d_head.py:114):
  * output rows = all rows of A (in order) followed by the rows of B that are not in A.

@@ -185,13 +185,28 @@ class FCAF3DHead(nn.Module):
         plan = P.current()
         if plan is not None and plan.static:
             # static trace (one scene): the branch of the calibration run, its premise registered as an assumption
+            B = x.cs.n_batch
             if plan.next_flag():                     # True: no calibration scene needed pruning; None (scenes differ) -> prune
-                plan.watch(x.cs.n_dev, 0, self.pts_threshold)
+                if B <= 1:
+                    plan.watch(x.cs.n_dev, 0, self.pts_threshold)
+                else:                                # several scenes per pass: the premise holds per scene
+                    cnt, _ = x.cs.counts_dev()
+                    for b in range(B):
+                        plan.watch(cnt[b:b + 1], 0, self.pts_threshold)
                 return x
             with torch.no_grad():
                 interpolated = S.interpolate(scores, x.C, x.cs.n_dev)
-                mask = S.topk_mask(interpolated, self.pts_threshold, n_dev=x.cs.n_dev)   # keeps every row when n <= threshold
-            return S.prune(x, mask, n_keep=self.pts_threshold)
+                if B <= 1:
+                    mask = S.topk_mask(interpolated, self.pts_threshold, n_dev=x.cs.n_dev)   # keeps every row when n <= threshold
+                else:                                # per scene: the other scenes' rows ranked -inf and never kept
+                    flat, scene = interpolated.view(-1), x.C[:, 0]
+                    low = torch.full_like(flat, float("-inf"))
+                    mask = None
+                    for b in range(B):
+                        mine = scene == b
+                        m = S.topk_mask(torch.where(mine, flat, low), self.pts_threshold, n_dev=x.cs.n_dev) & mine.to(torch.uint8)
+                        mask = m if mask is None else mask | m
+            return S.prune(x, mask, n_keep=min(B * self.pts_threshold, x.cs.n))
         with torch.no_grad():
             counts = x.cs.batch_counts()
             skip = all(c <= self.pts_threshold for c in counts)
@@ -339,6 +354,45 @@ class FCAF3DHead(nn.Module):
             scores.append(sc)
             sizes.append(k)
         return torch.cat(boxes), torch.cat(scores), torch.cat(valid), sizes
+
+    def get_bboxes_static_multi(self, centernesses, bbox_preds, cls_scores, points, coord_sets, n_scenes):
+        """get_bboxes_static for several scenes in one row set per level (static trace of pipeline.StaticBatch).  Per level
+        and scene: the rows of the other scenes are ranked -inf, the nms_pre best are taken with the radix select; a scene
+        with no more than nms_pre rows on the level keeps them all, in row order like the reference (:247-256 only cuts
+        when there are more).  Returns (bboxes [B,K,6|7], scores [B,K,n_cls], valid int32 [B,L], sizes): scene b / level l
+        owns rows [sum(sizes[:l]), +sizes[l]) of block b, of which the first valid[b,l] are detections."""
+        plan = P.current()
+        nms_pre = self.test_cfg.nms_pre if self.test_cfg is not None else 0
+        B = n_scenes
+        boxes, scores, valid, sizes = [[] for _ in range(B)], [[] for _ in range(B)], [[] for _ in range(B)], []
+        for cen, box, cls, pts, cs in zip(centernesses, bbox_preds, cls_scores, points, coord_sets):
+            cen, box, cls, pts, cs = cen[0], box[0], cls[0], pts[0], cs[0]
+            plan.next_flag()                                     # the single-scene branch of the calibration: not needed here
+            cap, n_dev = cs.n, cs.n_dev
+            k = min(nms_pre, cap) if nms_pre > 0 else cap
+            cnt, _ = cs.counts_dev()
+            ms = S.max_scores(cls, cen)
+            live = torch.arange(cap, device=ms.device, dtype=torch.int32) < n_dev
+            # ONE stable sort per level on the key (scene, descending score) -- scores are >= 0, so their bit patterns order
+            # them; dead rows sort behind every scene --: each scene's rows become a contiguous run in rank order, found
+            # through the device-side offsets; B radix selects per level cost 4x as much
+            scene = torch.where(live, cs.C[:, 0], torch.full_like(cs.C[:, 0], B)).long()
+            order = torch.sort((scene << 32) | (0xFFFFFFFF - ms.view(torch.int32).long()), stable=True)[1]
+            off = torch.cumsum(cnt, 0) - cnt
+            slot = plan.const(lambda: torch.arange(k, device=ms.device, dtype=torch.int64))
+            big = plan.const(lambda: torch.full((k,), cap, device=ms.device, dtype=torch.int64))
+            for b in range(B):
+                ids = order.index_select(0, (off[b:b + 1].long() + slot).clamp_(max=cap - 1))   # scene b's best, in score order
+                nb = torch.clamp(cnt[b:b + 1], max=k)
+                asc = torch.sort(torch.where(slot < nb, ids, big))[0].clamp_(max=cap - 1)         # the same rows in row order
+                ids = torch.where(cnt[b:b + 1] <= k, asc, ids)
+                bx, sc = S.select_decode(ids, cls, cen, box, pts, self.yaw_parametrization)
+                boxes[b].append(bx)
+                scores[b].append(sc)
+                valid[b].append(nb.to(torch.int32))
+            sizes.append(k)
+        return (torch.stack([torch.cat(x) for x in boxes]), torch.stack([torch.cat(x) for x in scores]),
+                torch.stack([torch.cat(v) for v in valid]), sizes)
 
     def get_bboxes_fused(self, centernesses, bbox_preds, cls_scores, points, scenes, n_scenes):
         """decode of forward(..., fused=True): per level ONE row set for all scenes + the rows' scene ids.  Per scene the
