@@ -279,8 +279,12 @@ def cpu_baseline(shape_name, Ms_full, C):
     dense_scene = t_dense / n_views * V_full * (C_full / C_s)
     rma_scene = t_rma / n_views * V_full * (H / rows)
     est = dense_scene + rma_scene + t_sparse
+    fx_dense, fx_rma = V_full / n_views * (C_full / C_s), V_full / n_views * (H / rows)
     return dict(value=1.0 / est, unit="scenes/s", cores=cores, kind="port",
                 stage_s=dict(dense=dense_scene, rma=rma_scene, sparse=t_sparse),
+                extrapolated=dict(dense=f"x{fx_dense:g} ({n_views} of {V_full} views x {C_s} of {C_full} channels, linear)",
+                                  rma=f"x{fx_rma:g} ({n_views} of {V_full} views x {rows} of {H} image rows, linear)",
+                                  sparse="x1 (full point set)"),
                 sample=f"oracle/ (torch-CPU restatement of the reference, {cores} threads of {os.cpu_count()} host cores -- more "
                        f"threads ran slower --, best of up to 3 reps after 1 warm-up): dense unprojection on {n_views} of {V_full} views x {C_s} of {C_full} channels "
                        f"({t_dense:.2f} s, {r_dense} reps); RMA on {n_views} of {V_full} views x {rows} of {H} image rows "
@@ -721,6 +725,9 @@ def main():
             if rank == 0 and not args.no_profile:
                 bs["roofline"] = profile_block(wls, bs, "S")
             bs["workload"] = "S: ScanNet config shape, V=40, C=32, 120x160 maps (stride 4), grid 192x192x80 (BASELINE configs[1])"
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                log("cpu baseline of the S block")
+                bs["cpu_baseline"] = cpu_baseline("S", bs["M_selected"], 32)
             result["S"] = bs
             del wls
             torch.cuda.empty_cache()

@@ -1975,7 +1975,7 @@ extern "C" int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K,
 // second kernel adds every output row's pair products in ascending k -- a fixed order, so results are deterministic --
 // and applies the fused epilogue.  Slots inside a run are handed out by atomics: the layout of the list varies from run to
 // run, the values do not (a GEMM row does not depend on its neighbours).
-constexpr int PAIR_HDR = 128;      // ints: cnt[32] | fill[32] | base[33] | n_vrows
+constexpr int PAIR_HDR = 128;      // ints: cnt[32] | fill[32] | base[33] | n_vrows | overflow flag
 
 constexpr int PAIR_EPT = 32;                    // table entries per thread and chunk (chunk = 8192 entries per block)
 
@@ -2015,14 +2015,17 @@ __global__ __launch_bounds__(256) void pairs_plan_kernel(int K, int32_t* __restr
   __syncthreads();
   for (int k = 0; k < K; ++k) {
     const int lo = base[k], hi = base[k + 1], live = lo + hdr[k];
-    for (int t = lo / 128 + threadIdx.x; t < hi / 128; t += 256) tile_tap[t] = k;
-    for (int r = live + threadIdx.x; r < hi; r += 256) pair_src[r] = -1;
+    // slots at or beyond pair_cap do not exist (a caller-chosen capacity below the provable bound): never written, and
+    // the fill / reduce kernels treat such entries as absent
+    for (int t = lo / 128 + threadIdx.x; t < hi / 128 && (int64_t)t < pair_cap / 128; t += 256) tile_tap[t] = k;
+    for (int r = live + threadIdx.x; r < hi && (int64_t)r < pair_cap; r += 256) pair_src[r] = -1;
   }
 }
 
 __global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t* __restrict__ nbr, int64_t no_cap,
                                                          const int32_t* __restrict__ no_dev, int K, int32_t* __restrict__ hdr,
-                                                         int32_t* __restrict__ pair_src, int32_t* __restrict__ pos) {
+                                                         int32_t* __restrict__ pair_src, int32_t* __restrict__ pos,
+                                                         int64_t pair_cap) {
   // slot = run base + one global reservation per offset and 8192-entry chunk + rank inside the chunk (LDS atomics):
   // per-entry global atomics on 27 words serialise at the memory side (3 ms for 660 k entries)
   __shared__ int hist[32], gbase[32];
@@ -2052,7 +2055,8 @@ __global__ __launch_bounds__(256) void pairs_fill_kernel(const int32_t* __restri
       if (src[j] >= 0) {
         const int k = tap_of(t, K);
         slot = gbase[k] + atomicAdd(&hist[k], 1);
-        pair_src[slot] = src[j];
+        if ((int64_t)slot < pair_cap) pair_src[slot] = src[j];
+        else { slot = -1; hdr[64 + 34] = 1; }                  // capacity below the bound: entry dropped, flagged
       }
       pos[t] = slot;
     }
@@ -2141,7 +2145,8 @@ extern "C" int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float*
   const int64_t blocks = ceil_div(no_cap * K, 256 * PAIR_EPT);
   hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr);
   hipLaunchKernelGGL(pairs_plan_kernel, dim3(1), dim3(256), 0, st, K, hdr, tile_tap, pair_src, pair_cap);
-  hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr, pair_src, pos);
+  hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr, pair_src, pos,
+                     pair_cap);
   CNRMA_LAUNCH_CHECK();
   const int rc = launch_conv(in_feats, Cin, pair_src, 1, nullptr, Cout, nullptr, nullptr, nullptr, 0, prod, pair_cap, hdr + 64 + 33,
                              1, nullptr, 0, st, weight_split, nullptr, 0, nullptr, 0, 1, in_amax, nullptr, tile_tap, K);

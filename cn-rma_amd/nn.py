@@ -31,6 +31,14 @@ class MinkowskiConvolution(nn.Module):
         with torch.no_grad():
             self.kernel.uniform_(-stdv, stdv)
 
+    def train(self, mode=True):
+        S.invalidate_weight_cache(self)      # writes through param.data (EMA hooks) bump no version counter
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        S.invalidate_weight_cache(self)
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, x, scale=None, shift=None, residual=None, act=None):
         if torch.is_grad_enabled() and (x.F.requires_grad or self.kernel.requires_grad) and scale is None and \
                 residual is None and act is None:

@@ -22,6 +22,7 @@ import os
 import threading
 
 import torch
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _lib
 from . import plan as P
@@ -456,11 +457,41 @@ def _amax_slot(device):
     return pool[1][i * _AMAX_WORDS:(i + 1) * _AMAX_WORDS]
 
 
+# Prepared weight images (fp16 / bf16 splits) are cached per weight tensor in a weak table -- nothing is attached to the
+# Parameter itself, so pickling a module never drags GPU buffers along -- keyed on (_version, data_ptr, device).  Writes
+# through `param.data` (EMA hooks, manual .data.copy_()) change neither: call invalidate_weight_cache() after them;
+# load_state_dict() and Module.train() of the sparse modules do so themselves (cnrma_amd.nn).
+_WEIGHT_CACHE = WeakIdKeyDictionary()          # identity-keyed: Tensor.__eq__ is elementwise
+
+
+def _cache_get(weight, kind):
+    d = _WEIGHT_CACHE.get(weight)
+    return None if d is None else d.get(kind)
+
+
+def _cache_put(weight, kind, value):
+    try:
+        _WEIGHT_CACHE.setdefault(weight, {})[kind] = value
+    except TypeError:
+        pass
+
+
+def invalidate_weight_cache(module_or_tensor=None):
+    """drop the prepared weight images of one tensor, of every parameter of a module, or (None) of everything"""
+    if module_or_tensor is None:
+        _WEIGHT_CACHE.clear()
+    elif isinstance(module_or_tensor, torch.nn.Module):
+        for p_ in module_or_tensor.parameters():
+            _WEIGHT_CACHE.pop(p_, None)
+    else:
+        _WEIGHT_CACHE.pop(module_or_tensor, None)
+
+
 def split_weights_f16(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> fp16 [2,K,Cout,Cin] (hi / lo pieces of weight * 2^s) + a trailer word
     holding max|weight| (the kernel derives s from it).  Cached on the weight tensor like split_weights()."""
     tag = (weight._version, weight.data_ptr(), weight.device)
-    hit = getattr(weight, "_cnrma_split_f16", None)
+    hit = _cache_get(weight, "_cnrma_split_f16")
     if hit is not None and hit[0] == tag:
         return hit[1]
     w = weight.detach().contiguous().float()
@@ -469,10 +500,7 @@ def split_weights_f16(weight):
     K, Cin, Cout = w.shape
     ws = torch.empty(_lib.load().cnrma_sparse_conv_f16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights_f16", ptr(w), K, Cin, Cout, ptr(ws), stream())
-    try:
-        weight._cnrma_split_f16 = (tag, ws)
-    except AttributeError:
-        pass
+    _cache_put(weight, "_cnrma_split_f16", (tag, ws))
     return ws
 
 
@@ -480,7 +508,7 @@ def weights_bf16(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [K,Cout_p,Cin] (round to nearest) for the "bf16" convolutions;
     cached on the weight tensor like the other prepared images"""
     tag = (weight._version, weight.data_ptr(), weight.device)
-    hit = getattr(weight, "_cnrma_bf16", None)
+    hit = _cache_get(weight, "_cnrma_bf16")
     if hit is not None and hit[0] == tag:
         return hit[1]
     w = weight.detach().contiguous().float()
@@ -489,10 +517,7 @@ def weights_bf16(weight):
     K, Cin, Cout = w.shape
     ws = torch.empty(_lib.load().cnrma_sparse_conv_bf16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights_bf16", ptr(w), K, Cin, Cout, ptr(ws), stream())
-    try:
-        weight._cnrma_bf16 = (tag, ws)
-    except AttributeError:
-        pass
+    _cache_put(weight, "_cnrma_bf16", (tag, ws))
     return ws
 
 
@@ -510,7 +535,7 @@ def split_weights(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [3,K,Cout_p,Cin] (hi / mid / lo pieces, Cout padded to 128).  The result is cached ON
     the weight tensor object (so it dies with it) and rebuilt when the tensor is modified in place or moved."""
     tag = (weight._version, weight.data_ptr(), weight.device)
-    hit = getattr(weight, "_cnrma_split", None)
+    hit = _cache_get(weight, "_cnrma_split")
     if hit is not None and hit[0] == tag:
         return hit[1]
     w = weight.detach().contiguous().float()
@@ -519,10 +544,7 @@ def split_weights(weight):
     K, Cin, Cout = w.shape
     ws = torch.empty(_lib.load().cnrma_sparse_conv_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights", ptr(w), K, Cin, Cout, ptr(ws), stream())
-    try:
-        weight._cnrma_split = (tag, ws)
-    except AttributeError:
-        pass
+    _cache_put(weight, "_cnrma_split", (tag, ws))
     return ws
 
 

@@ -33,17 +33,17 @@ def timed(fns, streams):
 
 s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
 ref = dense()
-for per in sys.argv[1:]:
-    rma.dense_tuning(variant=0, persist=int(per))
+# usage: overlap_probe.py [dense-tuning spec ...]   e.g.  variant=1  variant=1,pipe=2  variant=0
+for spec in sys.argv[1:] or ["default"]:
+    kw = {} if spec == "default" else {k: int(v) for k, v in (kv.split("=") for kv in spec.split(","))}
+    rma.dense_tuning(**kw)
     v = dense()
     torch.cuda.synchronize()
     assert torch.equal(v[0], ref[0]) and torch.equal(v[1], ref[1])
     del v
-    for name, fns in (("dense", [dense]), ("dense+march", [dense, march]), ("dense+nhwc", [dense, nhwc]), ("dense+march+nhwc", [dense, march, nhwc])):
+    for name, fns in (("dense", [dense]), ("march", [march]), ("nhwc", [nhwc]), ("dense+march", [dense, march]),
+                      ("dense+nhwc", [dense, nhwc]), ("nhwc+dense", [nhwc, dense]), ("march+nhwc", [march, nhwc]),
+                      ("dense+march+nhwc", [dense, march, nhwc])):
         ts = [timed(fns, [s1, s2, s3]) for _ in range(4)]
-        print(f"persist {per}: {name:18s} ms {[round(t, 2) for t in ts[1:]]}", flush=True)
+        print(f"{spec:22s} {name:18s} ms {[round(t, 2) for t in ts[1:]]}", flush=True)
 rma.dense_tuning()
-for name, fns in (("dense", [dense]), ("march", [march]), ("nhwc", [nhwc]), ("dense+march", [dense, march]),
-                  ("dense+nhwc", [dense, nhwc]), ("march+nhwc", [march, nhwc]), ("dense+march+nhwc", [dense, march, nhwc])):
-    ts = [timed(fns, [s1, s2, s3]) for _ in range(4)]
-    print(f"{name:18s} ms {[round(t, 2) for t in ts]}", flush=True)
