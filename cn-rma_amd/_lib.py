@@ -28,6 +28,7 @@ SIGNATURES = {
     "cnrma_rma_sigmoid_table_f32": (c_int, [P, L, P, P]),
     "cnrma_debug_div_by_voxel_size_f32": (c_int, [P, L, F, P, P, P]),
     "cnrma_rma_neus_march_f32": (c_int, [P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
+    "cnrma_nchw_to_nhwc_march_f32": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
     "cnrma_rma_neus_emit_rows_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, P, I, P, L, P, P, F, F, F, P, I, P, I, P, I, P, P]),
     "cnrma_sample_workspace_bytes": (c_size_t, []),
     "cnrma_sample_mask": (c_int, [P, L, I, ctypes.c_uint32, P, P, P, P]),

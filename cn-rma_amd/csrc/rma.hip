@@ -231,22 +231,23 @@ __device__ __forceinline__ TabSample fetch_step(const Ray& r, int n, const March
   return o;
 }
 
-__global__ __launch_bounds__(256) void neus_march_kernel(MarchParams p, const float* __restrict__ proj_inv,
-                                                         const float* __restrict__ tab, int32_t* __restrict__ count,
-                                                         double* __restrict__ wsum, int2* __restrict__ kept, int cap,
-                                                         int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view) {
+__device__ __forceinline__ void neus_march_block(const MarchParams& p, const float* __restrict__ proj_inv,
+                                                 const float* __restrict__ tab, int32_t* __restrict__ count,
+                                                 double* __restrict__ wsum, int2* __restrict__ kept, int cap,
+                                                 int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view,
+                                                 unsigned vblock) {
   // thread -> ray: a wave marches an 8 x 8 pixel tile (a block a 16 x 16 tile) instead of 64 consecutive pixels of an image
   // row: the bundle stays a compact patch of voxels at every step, so one table line serves more lanes
   int64_t r;
   if (tiles_x > 0) {
-    const int view_t = blockIdx.x / tiles_per_view, tile = blockIdx.x - view_t * tiles_per_view;
+    const int view_t = (int)(vblock / (unsigned)tiles_per_view), tile = (int)(vblock - (unsigned)view_t * (unsigned)tiles_per_view);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int u = tx * 16 + (w & 1) * 8 + (l & 7), v = ty * 16 + (w >> 1) * 8 + (l >> 3);
     if (u >= p.W || v >= p.H) return;
     r = ((int64_t)view_t * p.H + v) * p.W + u;
   } else {
-    r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    r = (int64_t)vblock * blockDim.x + threadIdx.x;
   }
   Ray ray; int view, pix;
   if (!ray_setup(p, proj_inv, r, &ray, &view, &pix)) return;
@@ -292,6 +293,63 @@ __global__ __launch_bounds__(256) void neus_march_kernel(MarchParams p, const fl
   }
   count[r] = c;
   wsum[r] = ws;
+}
+
+__global__ __launch_bounds__(256) void neus_march_kernel(MarchParams p, const float* __restrict__ proj_inv,
+                                                         const float* __restrict__ tab, int32_t* __restrict__ count,
+                                                         double* __restrict__ wsum, int2* __restrict__ kept, int cap,
+                                                         int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view) {
+  neus_march_block(p, proj_inv, tab, count, wsum, kept, cap, overflow, tiles_x, tiles_per_view, blockIdx.x);
+}
+
+// Layout pass + march in ONE launch.  The NCHW -> channels-last pass is a pure HBM stream (25 GB at the north-star shape);
+// the march works on cache-resident data and does not read the feature maps at all.  As two launches they run one after
+// the other (kernels that fill the chip do not overlap across streams here: 4.9 + 2.1 = 7.0 ms).  Here they are ONE grid
+// whose every `stride`-th workgroup is a march block (stride odd: with an even stride all march blocks land on 2 of the
+// 8 XCDs, blocks being dealt round-robin), so both kinds are co-resident on every CU: 6.66 ms at the north-star shape.
+// Not more: both halves live off occupancy (the march waits on dependent table look-ups, the copy on HBM), so sharing
+// the wave slots mostly time-slices them -- a persistent variant in which every workgroup alternated 16 layout tiles
+// with one march tile (two atomic work counters) took 6.91 ms, the same as the two launches.  The two halves are
+// independent, so the results are those of the two separate launches, bit for bit.
+__global__ __launch_bounds__(256) void layout_march_kernel(MarchParams p, const float* __restrict__ proj_inv,
+                                                           const float* __restrict__ tab, int32_t* __restrict__ count,
+                                                           double* __restrict__ wsum, int2* __restrict__ kept, int cap,
+                                                           int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view,
+                                                           unsigned n_march, unsigned stride,
+                                                           const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int64_t HW, unsigned n_px_tiles, unsigned n_c_blocks) {
+  __shared__ float tile[64][65];
+  const unsigned b = blockIdx.x;
+  if (b % stride == stride - 1 && b / stride < n_march) {
+    neus_march_block(p, proj_inv, tab, count, wsum, kept, cap, overflow, tiles_x, tiles_per_view, b / stride);
+    return;
+  }
+  const unsigned before = (b + 1) / stride < n_march ? (b + 1) / stride : n_march;       // march blocks at smaller indices
+  const unsigned lb = b - before;
+  // 64 channels x 64 pixels with 16-byte accesses on both sides (nchw_to_nhwc_v4_kernel of util.hip; HW % 4 == C % 4 == 0)
+  const int64_t view = lb / (n_px_tiles * n_c_blocks);
+  const unsigned rem = lb - (unsigned)view * (n_px_tiles * n_c_blocks);
+  const int64_t p0 = (int64_t)(rem % n_px_tiles) * 64;
+  const int c0 = (int)(rem / n_px_tiles) * 64;
+  const float* sv = src + view * C * HW;
+  float* dv = dst + view * C * HW;
+  const int q = threadIdx.x & 15, rr = threadIdx.x >> 4;     // 16 quads x 16 rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = rr + 16 * j;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 + c < C && p0 + 4 * q < HW) v = *reinterpret_cast<const float4*>(sv + (int64_t)(c0 + c) * HW + p0 + 4 * q);
+    tile[c][4 * q + 0] = v.x; tile[c][4 * q + 1] = v.y; tile[c][4 * q + 2] = v.z; tile[c][4 * q + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int px = rr + 16 * j;
+    if (c0 + 4 * q < C && p0 + px < HW) {
+      const float4 o = make_float4(tile[4 * q + 0][px], tile[4 * q + 1][px], tile[4 * q + 2][px], tile[4 * q + 3][px]);
+      *reinterpret_cast<float4*>(dv + (p0 + px) * C + c0 + 4 * q) = o;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void sigmoid_table_kernel(const float* __restrict__ tsdf, int64_t n, float* __restrict__ tab) {
@@ -569,6 +627,43 @@ extern "C" int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* 
   return 0;
 }
 
+static int launch_march(const MarchParams& p, const float* proj_inv, const float* tsdf, const float* sig_table,
+                        int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow, const float* feat_nchw,
+                        float* feat_nhwc, int C, hipStream_t st) {
+  const int64_t R = (int64_t)p.V * p.H * p.W, HW = (int64_t)p.H * p.W;
+  hipError_t e = cnrma_fill_bytes(overflow, 0, 4 * sizeof(int32_t), st);     // [0] violations, [1..3] reserved
+  if (e != hipSuccess) return -(int)e;
+  const bool table = sig_table != nullptr && (int64_t)p.X * p.Y * p.Z < ((int64_t)1 << 31);
+  const int tx = (int)ceil_div(p.W, 16), ty = (int)ceil_div(p.H, 16);
+  const int64_t n_march = (int64_t)p.V * tx * ty;
+  if (feat_nchw != nullptr) {
+    const int64_t npx = ceil_div(HW, 64), ncb = ceil_div(C, 64), n_layout = npx * ncb * p.V;
+    const bool v4 = HW % 4 == 0 && C % 4 == 0 && ((((uintptr_t)feat_nchw) | ((uintptr_t)feat_nhwc)) & 15) == 0;
+    // worth it when the layout pass is the larger half (at the ScanNet shape it is 0.04 of 0.28 ms: two launches)
+    if (table && v4 && n_layout + n_march < ((int64_t)1 << 31) && n_layout >= 8 * n_march) {
+      unsigned stride = (unsigned)((n_layout + n_march) / n_march);
+      if (stride % 2 == 0) --stride;                                 // odd: march blocks on all 8 XCDs
+      hipLaunchKernelGGL(layout_march_kernel, dim3((unsigned)(n_layout + n_march)), dim3(256), 0, st, p, proj_inv, sig_table,
+                         count, wsum, reinterpret_cast<int2*>(kept), cap, overflow, tx, tx * ty, (unsigned)n_march, stride,
+                         feat_nchw, feat_nhwc, C, HW, (unsigned)npx, (unsigned)ncb);
+      CNRMA_LAUNCH_CHECK();
+      return 0;
+    }
+    const int rc = cnrma_nchw_to_nhwc_f32(feat_nchw, feat_nhwc, p.V, C, p.H, p.W, st);      // not fusable: two launches
+    if (rc != 0) return rc;
+  }
+  if (table) {
+    hipLaunchKernelGGL(neus_march_kernel, dim3((unsigned)n_march), dim3(256), 0, st, p, proj_inv, sig_table, count, wsum,
+                       reinterpret_cast<int2*>(kept), cap, overflow, tx, tx * ty);
+  } else {
+    if (tsdf == nullptr) return CNRMA_EINVAL;
+    hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, st, p, proj_inv, tsdf, count, wsum,
+                       reinterpret_cast<int2*>(kept), cap, overflow);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const float* sig_table, int V, int H,
                                         int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
                                         int n_steps, float t_one, float thr, int32_t* count, double* wsum, void* kept,
@@ -576,23 +671,20 @@ extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf
   if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr) return CNRMA_EINVAL;
   if (tsdf == nullptr && sig_table == nullptr) return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
-  int64_t R = (int64_t)V * H * W;
-  hipError_t e = cnrma_fill_bytes(overflow, 0, sizeof(int32_t), as_stream(stream));
-  if (e != hipSuccess) return -(int)e;
-  if (sig_table != nullptr && (int64_t)X * Y * Z < ((int64_t)1 << 31)) {
-    const char* te = getenv("CNRMA_MARCH_TILE");           // tuning / A-B aid: 0 = one image-row segment per wave
-    const bool tiled = te == nullptr || te[0] != '0';
-    const int tx = (int)ceil_div(W, 16), ty = (int)ceil_div(H, 16);
-    const unsigned blocks = tiled ? (unsigned)((int64_t)V * tx * ty) : (unsigned)ceil_div(R, 256);
-    hipLaunchKernelGGL(neus_march_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, proj_inv, sig_table, count, wsum,
-                       reinterpret_cast<int2*>(kept), cap, overflow, tiled ? tx : 0, tx * ty);
-  } else {
-    if (tsdf == nullptr) return CNRMA_EINVAL;
-    hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
-                       proj_inv, tsdf, count, wsum, reinterpret_cast<int2*>(kept), cap, overflow);
-  }
-  CNRMA_LAUNCH_CHECK();
-  return 0;
+  return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, nullptr, nullptr, 0, as_stream(stream));
+}
+
+extern "C" int cnrma_nchw_to_nhwc_march_f32(const float* feat_nchw, float* feat_nhwc, int C, const float* proj_inv,
+                                            const float* tsdf, const float* sig_table, int V, int H, int W, int X, int Y,
+                                            int Z, float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
+                                            float thr, int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow,
+                                            void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr || C <= 0 ||
+      feat_nchw == nullptr || feat_nhwc == nullptr)
+    return CNRMA_EINVAL;
+  if (tsdf == nullptr && sig_table == nullptr) return CNRMA_EINVAL;
+  MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
+  return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, feat_nchw, feat_nhwc, C, as_stream(stream));
 }
 
 extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,

@@ -257,6 +257,13 @@ class StaticScene:
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.offset_dev = torch.zeros(3, dtype=torch.float32, device=dev)       # switch_pointcloud's per-scene offset
         self._pin_off = torch.zeros(3, dtype=torch.float32, pin_memory=True)
+        cfg = self.cfg
+        # the march runs with the layout pass, in _load (one launch), into buffers the graph reads
+        self.march = rma._March(self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
+                                "neus", 0)
+        if self.march.kept_cap() <= 0:
+            raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
+        self.march_out = self.march.march_buffers()
         self._pin_proj = torch.empty((V, 3, 4), dtype=torch.float32, pin_memory=True)
         self._pin_inv = torch.empty((V, 4, 4), dtype=torch.float32, pin_memory=True)
 
@@ -266,8 +273,6 @@ class StaticScene:
         across host CPUs); computed here on the host like ray_marching.py:96-102 otherwise."""
         if self._copied is not None:
             self._copied.synchronize()           # the previous scene's copies out of the pinned buffers have executed
-        if features_nchw is not None:            # None: the caller's layout pass already wrote into self.nhwc
-            rma.to_nhwc(features_nchw, out=self.nhwc)
         p = projections.detach().to("cpu", torch.float32)
         self._pin_proj.copy_(rma.scale_projection(p, self.cfg.stride))
         self._pin_inv.copy_(rma.projection_inverse(p, self.cfg.stride) if proj_inv is None
@@ -280,8 +285,14 @@ class StaticScene:
         else:
             self._pin_off.copy_(torch.as_tensor(offset, dtype=torch.float32).detach().reshape(3).cpu())
         self.offset_dev.copy_(self._pin_off, non_blocking=True)
+        # layout pass (NCHW -> the static channels-last buffer) and march in ONE launch; features_nchw None = the caller's
+        # own layout pass already wrote self.nhwc; a tensor that is channels-last in memory is copied as it is
+        if features_nchw is not None and features_nchw.permute(0, 2, 3, 1).is_contiguous():
+            self.nhwc.copy_(features_nchw.permute(0, 2, 3, 1), non_blocking=True)
+            features_nchw = None
         self._copied = torch.cuda.Event()
-        self._copied.record()
+        self._copied.record()                    # the pinned staging buffers are free again once this point has executed
+        self.march.march(layout_from=features_nchw, into=self.march_out)
 
     def _enter(self, *inputs):
         """order self.stream behind the caller's stream (the 2D backbone / Atlas head that produced the inputs ran
@@ -306,7 +317,7 @@ class StaticScene:
             coords, feats, n_sel, info = rma.aggregate_points_static(
                 self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                 max_points=cfg.max_points, seed=cfg.sample_seed if fixed else 0x5EED,
-                seed_dev=None if fixed else self.seed_dev)
+                seed_dev=None if fixed else self.seed_dev, marched=(self.march, self.march_out))
             moved = coords + self.offset_dev     # ray_marching.py:364 (one fp32 add per coordinate, as the reference)
             out.update(trace_net(plan, self.backbone, self.head, moved, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
                                  extra_counts=[info["M"], n_sel]))
@@ -488,7 +499,7 @@ class StaticBatch:
                 coords, feats, n_sel, info = rma.aggregate_points_static(
                     h.nhwc, h.proj_inv, h.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                     max_points=cfg.max_points, seed=(cfg.sample_seed if fixed else 0x5EED) + 7919 * b * (0 if fixed else 1),
-                    seed_dev=None if fixed else h.seed_dev)
+                    seed_dev=None if fixed else h.seed_dev, marched=(h.march, h.march_out))
                 pts.append((coords + h.offset_dev, feats, n_sel))
                 Ms += [info["M"].view(1), n_sel.view(1)]
                 if not fixed:

@@ -210,22 +210,39 @@ class _March:
             return 0
         return int(1.0 / self.thr) + 2
 
-    def march(self):
-        """phase 1 + kept-sample records (NeuS with thr > 1/62 only)"""
+    def march(self, layout_from=None, into=None):
+        """phase 1 + kept-sample records (NeuS with thr > 1/62 only).  layout_from: the scene's NCHW feature maps -- the
+        channels-last layout pass into self.feat then runs in the SAME launch as the march (cnrma_nchw_to_nhwc_march_f32:
+        the HBM-bound copy hides the VALU-bound march).  into: (cnt, wsum, kept, overflow, table) buffers to (re)use."""
         cap = self.kept_cap()
-        cnt = torch.empty(self.R, dtype=torch.int32, device=self.dev)
-        wsum = torch.empty(self.R, dtype=torch.float64, device=self.dev)
-        kept = torch.empty((self.R, cap, 2), dtype=torch.int32, device=self.dev)
-        overflow = torch.empty(1, dtype=torch.int32, device=self.dev)
+        if into is not None:
+            cnt, wsum, kept, overflow, tab = into
+        else:
+            cnt = torch.empty(self.R, dtype=torch.int32, device=self.dev)
+            wsum = torch.empty(self.R, dtype=torch.float64, device=self.dev)
+            kept = torch.empty((self.R, cap, 2), dtype=torch.int32, device=self.dev)
+            overflow = torch.empty(4, dtype=torch.int32, device=self.dev)      # [0] violations; [1..2] scratch of the fused launch
+            tab = torch.empty_like(self.tsdf) if SIGMOID_TABLE else None
+        overflow_all, overflow = overflow, overflow[:1]
         self._overflow = overflow
-        tab = None
-        if SIGMOID_TABLE:        # sigmoid(-tsdf) once per voxel instead of once per marched step (bit-identical)
-            tab = torch.empty_like(self.tsdf)
+        if tab is not None:      # sigmoid(-tsdf) once per voxel instead of once per marched step (bit-identical)
             call("cnrma_rma_sigmoid_table_f32", ptr(self.tsdf), self.tsdf.numel(), ptr(tab), stream())
-        call("cnrma_rma_neus_march_f32", ptr(self.pinv), ptr(self.tsdf), ptr(tab), self.V, self.H, self.W, self.X, self.Y,
-             self.Z, self.vs, *self.org, self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow),
-             stream())
+        tail = (ptr(self.pinv), ptr(self.tsdf), ptr(tab), self.V, self.H, self.W, self.X, self.Y, self.Z, self.vs, *self.org,
+                self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow_all), stream())
+        if layout_from is not None:
+            src = _f32(layout_from)
+            assert tuple(src.shape) == (self.V, self.C, self.H, self.W) and self.feat.is_contiguous()
+            call("cnrma_nchw_to_nhwc_march_f32", ptr(src), ptr(self.feat), self.C, *tail)
+        else:
+            call("cnrma_rma_neus_march_f32", *tail)
         return cnt, wsum, kept, overflow
+
+    def march_buffers(self):
+        """persistent outputs of march() for a static slot: (cnt, wsum, kept, overflow, table)"""
+        cap = self.kept_cap()
+        return (torch.empty(self.R, dtype=torch.int32, device=self.dev), torch.empty(self.R, dtype=torch.float64, device=self.dev),
+                torch.empty((self.R, cap, 2), dtype=torch.int32, device=self.dev),
+                torch.empty(4, dtype=torch.int32, device=self.dev), torch.empty_like(self.tsdf) if SIGMOID_TABLE else None)
 
     def emit_rows(self, row_offset, n_out, kept, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat,
                   feat_stride, out_sample=None, n_out_dev=None):
@@ -411,17 +428,21 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
 
 
 def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05,
-                            offset=(0.0, 0.0, 0.0), max_points=None, seed=0, seed_dev=None, reference_quirks=True):
+                            offset=(0.0, 0.0, 0.0), max_points=None, seed=0, seed_dev=None, reference_quirks=True,
+                            marched=None):
     """aggregate_points() without a device->host read (the static trace of plan.Plan; NeuS single-march only): the row
     count M stays on the device, the selection always goes through the device sampler (it keeps every row when
     M <= max_points) and the outputs are capacity-sized.  Returns (coords [cap,3], feats [cap,C], n_dev int32 [1], info);
     rows >= n_dev[0] are undefined."""
     plan = P.current()
     assert plan is not None and plan.static
-    m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0)
-    if m.kept_cap() <= 0:
-        raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
-    cnt, wsum, kept, overflow = m.march()
+    if marched is not None:          # (march object, its outputs): the march already ran (with the layout pass, outside the trace)
+        m, (cnt, wsum, kept, overflow) = marched[0], marched[1][:4]
+    else:
+        m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0)
+        if m.kept_cap() <= 0:
+            raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
+        cnt, wsum, kept, overflow = m.march()
     if reference_quirks:
         _drop_single_sample_views(cnt, wsum, m.V)
     off = exclusive_scan(cnt)

@@ -112,7 +112,8 @@ int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const floa
 
 /* Single-march variant of the NeuS pair (production path).  cnrma_rma_neus_march_f32 = phase 1 plus a per-ray record
  * of the kept samples: kept[ray][cap] x {int32 weight bits, int32 step} (8 bytes each), cap >= floor(1/thr) + 2 (a
- * ray's weights sum to <= 1, so it keeps at most 1/thr samples; overflow[0] counts violations and must read 0).
+ * ray's weights sum to <= 1, so it keeps at most 1/thr samples; overflow: int32[4] -- [0] counts violations and must read
+ * 0, [1..3] are scratch words of the launch).
  * cnrma_rma_neus_emit_rows_f32 = phase 2 from those records: a per-ray pass moves the records of the selected samples to
  * their output position (records: scratch of 16 bytes x n_out), then one 8-lane group per OUTPUT row (n_out of them)
  * writes the row -- nothing is re-marched.
@@ -127,6 +128,15 @@ int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const flo
                              int Y, int Z, float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
                              float thr, int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow,
                              void* stream);
+
+/* The layout pass (cnrma_nchw_to_nhwc_f32) and the march (cnrma_rma_neus_march_f32) of one scene in ONE launch: the two
+ * are independent (the march does not read the feature maps), one is a pure HBM stream and the other VALU-bound on
+ * cache-resident data, and as separate launches they do not overlap.  Same outputs as the two calls, bit for bit; falls
+ * back to two launches when the 16-byte layout kernel does not apply (H*W % 4, C % 4, alignment) or without sig_table. */
+int cnrma_nchw_to_nhwc_march_f32(const float* feat_nchw, float* feat_nhwc, int C, const float* proj_inv, const float* tsdf,
+                                 const float* sig_table, int V, int H, int W, int X, int Y, int Z, float voxel_size, float ox,
+                                 float oy, float oz, int n_steps, float t_one, float thr, int32_t* count, double* wsum,
+                                 void* kept, int cap, int32_t* overflow, void* stream);
 
 /* Backward of cnrma_rma_neus_emit_rows_f32 w.r.t. the feature maps (training; the weights carry no
  * gradient: the reference computes them under torch.no_grad(), ray_marching.py:705).

@@ -13,18 +13,16 @@ tsdf = sc["tsdf"][0, 0].to(dev)
 m = rma._March(feat, pinv, tsdf, dims, 0.04, (0, 0, 0), 300, 0.05, "neus", 0)
 res = {}
 for rep in range(4):
-    for mode in (False, True, "rows"):
+    for mode in (False, True):          # (the image-row variant of the table kernel was removed with its environment switch)
         rma.SIGMOID_TABLE = bool(mode)
-        os.environ["CNRMA_MARCH_TILE"] = "0" if mode == "rows" else "1"
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); out = m.march(); b.record(); torch.cuda.synchronize()
         res.setdefault(mode, []).append(a.elapsed_time(b))
         res[("out", mode)] = out
 print(wl, "per-step sigmoid kernel ms:", [round(x, 3) for x in res[False]])
 print(wl, "table kernel, 8x8-pixel tiles per wave (+table build) ms:", [round(x, 3) for x in res[True]])
-print(wl, "table kernel, image-row segments per wave (+table build) ms:", [round(x, 3) for x in res["rows"]])
 c0, w0, k0, _ = res[("out", False)]
-for mode in (True, "rows"):
+for mode in (True,):
     c1, w1, k1, _ = res[("out", mode)]
     live = torch.arange(k0.shape[1], device=dev)[None, :] < c0[:, None].clamp(max=k0.shape[1])
     print(mode, "counts equal", torch.equal(c0, c1), "wsum equal", torch.equal(w0, w1), "records equal", bool((k0[live] == k1[live]).all()),
