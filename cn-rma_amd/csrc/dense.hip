@@ -40,7 +40,7 @@ __device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, flo
 // boxes in which a ray meets several of its voxels.  Measured at the north-star shape (scripts/dense_ab.py, results
 // bit-identical): 13.3 -> 10.7 ms; 64 x 64 x 16 slabs 12.8, 32 x 32 x 16 11.5, 16 x 16 x 64 10.8, 8 x 8 x 32 11.5,
 // 128 x 128 x 16 19.0 ms.  Stores stay 32-byte runs along z per lane group, merged in L2 (zt >= 16).
-struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
+struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt, own; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
 
 __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrder& o, int64_t gv, int* x, int* y, int* z) {
   const int64_t per = (int64_t)o.st * o.st * o.zt;
@@ -418,11 +418,18 @@ __global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe
       }
   } else {
     int64_t lb = blockIdx.x;
-    if (chunk_blocks > 0) {
+    int sweep = blockIdx.y;
+    if (ord.own > 0) {
+      // one channel sweep per XCD group (8 sweeps <-> 8 groups): every group walks ALL bricks in order for its own 128-byte
+      // slice of the pixel rows, so the workgroups resident on an XCD are one contiguous run of neighbouring bricks (not
+      // every 8th brick) and no feature line is fetched by two XCDs (dense_l2sim: read hit rate 34 % -> 41 %)
+      sweep = (int)(lb & 7);
+      lb >>= 3;
+    } else if (chunk_blocks > 0) {
       const int64_t grp = lb & 7, k = lb >> 3;
       lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
     }
-    accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, lb, blockIdx.y * (4 * LPV), blockIdx.y == 0, ord, lds_wave);
+    accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, lb, sweep * (4 * LPV), sweep == 0, ord, lds_wave);
   }
 }
 
@@ -578,6 +585,7 @@ struct DenseTune {
   int pipe = 1;         // variant 1: views in flight (1 | 2)
   int epi = 0;          // variant 1: 0 direct stores, 1 LDS-transposed full-line stores
   int nt = 0;           // variant 1: non-temporal stores of the volume
+  int own = 0;          // variant 1: one channel sweep per XCD group (needs exactly 8 sweeps)
   int lattice = 0;      // variant 1 lockstep: 1 = lattice assignment of columns to workgroups (balanced), 0 = compact tiles
   int lockstep = 0;     // variants 1, 2: persistent grid, every XCD group walks one brick at a time (1: behind a barrier, 2: no barrier)
 };
@@ -592,7 +600,7 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
   int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
   if (cb < 32) cb = 32;
-  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt};
+  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt, 0};
   if (t.slab) {
     ord.on = 1;
     if (ord.zi < 1 || ord.zt % ord.zi != 0) return CNRMA_EINVAL;
@@ -627,7 +635,9 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   }
   const int lock = (t.lockstep == 1 && bar != nullptr && ord.on && cb > 0 && cb <= 256) ? 1 : 0;
   if (t.lattice && ord.on && ord.zt == 32 && ord.st % 8 == 0) ord.on = 2;
-  dim3 grid(lock ? (unsigned)(8 * cb) : (unsigned)gx, lock ? 1u : (unsigned)ceil_div(p.C, 4 * LPV));
+  const int n_sweeps = (int)ceil_div(p.C, 4 * LPV);
+  if (t.own && !lock && ord.on && n_sweeps == 8 && nb * 8 < ((int64_t)1 << 31)) ord.own = 1;
+  dim3 grid(lock ? (unsigned)(8 * cb) : (ord.own ? (unsigned)(nb * 8) : (unsigned)gx), (lock || ord.own) ? 1u : (unsigned)n_sweeps);
 #define CNRMA_DENSE_LAUNCH(PIPE, EPI)                                                                                      \
   do {                                                                                                                     \
     if (lock)                                                                                                              \
@@ -672,11 +682,11 @@ int launch_accum(const DenseParams& p, const float* feat, const float* proj, flo
 }  // namespace
 
 extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
-  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt}; n < 14 keeps the remaining defaults;
+  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own}; n < 15 keeps the remaining defaults;
   // n == 0 restores the product configuration.  Host-side global state: debug / A-B runs only.
   DenseTune t;
-  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt};
-  if (n < 0 || n > 14 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own};
+  if (n < 0 || n > 15 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_tune = t;
   return 0;

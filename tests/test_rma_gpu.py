@@ -366,7 +366,7 @@ def test_dense_traversal_orders_give_identical_volumes(device):
                    dict(variant=1, pipe=2, epi=1), dict(variant=1, st=32, lockstep=1),
                    dict(variant=1, st=32, lockstep=1, epi=1, pipe=2), dict(variant=1, st=16, zt=16, tt=4, zi=16),
                    dict(variant=2), dict(variant=2, slab=0), dict(variant=2, st=32, lockstep=1), dict(variant=2, st=32, lockstep=2),
-                   dict(variant=2, st=24, lockstep=1), dict(variant=1, st=32, lockstep=1, lattice=1), dict(variant=1, st=32, lattice=1)):
+                   dict(variant=2, st=24, lockstep=1), dict(variant=1, st=32, lockstep=1, lattice=1), dict(variant=1, st=32, lattice=1), dict(variant=1, own=1)):
             rma.dense_tuning(**kw)
             vol, cnt = rma.backproject_accum(feat, proj, sc["dims"], 0.04, (0.0, 0.0, 0.0), sc["stride"])
             assert torch.equal(vol, vol0) and torch.equal(cnt, cnt0), kw
