@@ -40,7 +40,7 @@ __device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, flo
 // boxes in which a ray meets several of its voxels.  Measured at the north-star shape (scripts/dense_ab.py, results
 // bit-identical): 13.3 -> 10.7 ms; 64 x 64 x 16 slabs 12.8, 32 x 32 x 16 11.5, 16 x 16 x 64 10.8, 8 x 8 x 32 11.5,
 // 128 x 128 x 16 19.0 ms.  Stores stay 32-byte runs along z per lane group, merged in L2 (zt >= 16).
-struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt, own; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
+struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt, own, stagger; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
 
 __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrder& o, int64_t gv, int* x, int* y, int* z) {
   const int64_t per = (int64_t)o.st * o.st * o.zt;
@@ -66,15 +66,15 @@ __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrde
 // (w / (st/4) + (st/2) * (j / 4),  w % (st/4) + (st/4) * (j % 4)) --, so every workgroup samples the whole brick and meets
 // each view's frustum boundary in the same proportion as its neighbours: equal work per view, the precondition for staying in
 // phase.  A wave still owns 2 columns x 32 consecutive z (full 128-byte store runs per channel plane).
-__device__ __forceinline__ bool lattice_decode(const DenseParams& p, const SlabOrder& o, int64_t lb, int* x, int* y, int* z) {
+__device__ __forceinline__ bool lattice_decode(const DenseParams& p, const SlabOrder& o, int64_t lb, int tid, int* x, int* y, int* z) {
   const int cb = o.st * o.st / 8;
   const int64_t sv = lb / cb;
   if (sv >= (int64_t)o.nsx * o.nsy * o.nsz) return false;
-  const int w = (int)(lb - sv * cb), j = (int)(threadIdx.x >> 5), q4 = o.st / 4;
+  const int w = (int)(lb - sv * cb), j = tid >> 5, q4 = o.st / 4;
   const int sy = (int)(sv % o.nsy), sx = (int)((sv / o.nsy) % o.nsx), sz = (int)(sv / ((int64_t)o.nsy * o.nsx));
   *x = sx * o.st + w / q4 + (o.st / 2) * (j >> 2);
   *y = sy * o.st + w % q4 + q4 * (j & 3);
-  *z = sz * 32 + (int)(threadIdx.x & 31);
+  *z = sz * 32 + (tid & 31);
   return *x < p.X && *y < p.Y && *z < p.Z;
 }
 
@@ -268,17 +268,17 @@ template <int LPV, int PIPE, int EPI>
 __device__ __forceinline__ void accum_block(const DenseParams& p, const float* __restrict__ feat,
                                             const float* __restrict__ proj, float* __restrict__ volume,
                                             int32_t* __restrict__ count, int64_t lb, int c0, bool write_count,
-                                            const SlabOrder& ord, float* __restrict__ lds_wave) {
+                                            const SlabOrder& ord, float* __restrict__ lds_wave, int tid) {
   constexpr int VPG = 64 / LPV;
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  const int lane = threadIdx.x & 63;
-  const int64_t g = lb * blockDim.x + threadIdx.x;
+  const int lane = tid & 63;
+  const int64_t g = lb * 256 + tid;
   float wx = 0.f, wy = 0.f, wz = 0.f;
   bool in_grid;
   int64_t lin = -1;
   if (ord.on) {
     int x = 0, y = 0, z = 0;
-    in_grid = ord.on == 2 ? lattice_decode(p, ord, lb, &x, &y, &z) : slab_decode(p, ord, g, &x, &y, &z);
+    in_grid = ord.on == 2 ? lattice_decode(p, ord, lb, tid, &x, &y, &z) : slab_decode(p, ord, g, &x, &y, &z);
     if (in_grid) {
       lin = ((int64_t)x * p.Y + y) * p.Z + z;
       wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;      // as voxel_world()
@@ -413,7 +413,15 @@ __global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe
     const int n_sweeps = (int)ceil_div_dev(p.C, 4 * LPV);
     for (int sw = 0; sw < n_sweeps; ++sw)
       for (int64_t ch = grp; ch < n_chunks; ch += 8) {
-        accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, ch * chunk_blocks + slot, sw * 4 * LPV, sw == 0, ord, lds_wave);
+        // stagger: released together, the waves of a CU would project at the same time and then wait for memory at the
+        // same time (lockstep 2x slower than free-running); wave w of every workgroup starts w x stagger x 64 cycles late,
+        // so that at any moment a quarter of the waves is in each quarter of the view step
+        for (int i = 0; i < ord.stagger * (int)(threadIdx.x >> 6); ++i) __builtin_amdgcn_s_sleep(1);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));            // per-thread values are recomputed per brick instead of being hoisted out of
+                                                 // the brick loop (hoisted they spilled, and a scratch access in the view loop
+                                                 // puts a vmcnt(0) in front of every gather)
+        accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, ch * chunk_blocks + slot, sw * 4 * LPV, sw == 0, ord, lds_wave, tid);
         group_barrier(bar + grp * 32, (unsigned)chunk_blocks);
       }
   } else {
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe
       const int64_t grp = lb & 7, k = lb >> 3;
       lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
     }
-    accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, lb, sweep * (4 * LPV), sweep == 0, ord, lds_wave);
+    accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, lb, sweep * (4 * LPV), sweep == 0, ord, lds_wave, (int)threadIdx.x);
   }
 }
 
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void backproject_accum_hoist_kernel(DensePa
     int64_t lin = -1;
     if (LOCK != 0) {
       int x = 0, y = 0, z = 0;
-      in_grid = lattice_decode(p, ord, lb, &x, &y, &z);
+      in_grid = lattice_decode(p, ord, lb, (int)threadIdx.x, &x, &y, &z);
       if (in_grid) {
         lin = ((int64_t)x * p.Y + y) * p.Z + z;
         wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;
@@ -586,6 +594,7 @@ struct DenseTune {
   int epi = 0;          // variant 1: 0 direct stores, 1 LDS-transposed full-line stores
   int nt = 0;           // variant 1: non-temporal stores of the volume
   int own = 0;          // variant 1: one channel sweep per XCD group (needs exactly 8 sweeps)
+  int stagger = 0;      // variant 1 lockstep: start delay per wave index, in units of 64 cycles
   int lattice = 0;      // variant 1 lockstep: 1 = lattice assignment of columns to workgroups (balanced), 0 = compact tiles
   int lockstep = 0;     // variants 1, 2: persistent grid, every XCD group walks one brick at a time (1: behind a barrier, 2: no barrier)
 };
@@ -600,7 +609,7 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
   int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
   if (cb < 32) cb = 32;
-  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt, 0};
+  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt, 0, t.stagger};
   if (t.slab) {
     ord.on = 1;
     if (ord.zi < 1 || ord.zt % ord.zi != 0) return CNRMA_EINVAL;
@@ -682,11 +691,11 @@ int launch_accum(const DenseParams& p, const float* feat, const float* proj, flo
 }  // namespace
 
 extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
-  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own}; n < 15 keeps the remaining defaults;
+  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger}; n < 16 keeps the remaining defaults;
   // n == 0 restores the product configuration.  Host-side global state: debug / A-B runs only.
   DenseTune t;
-  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own};
-  if (n < 0 || n > 15 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own, &t.stagger};
+  if (n < 0 || n > 16 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_tune = t;
   return 0;
