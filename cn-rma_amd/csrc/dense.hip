@@ -40,7 +40,7 @@ __device__ __forceinline__ void voxel_world(const DenseParams& p, int64_t g, flo
 // boxes in which a ray meets several of its voxels.  Measured at the north-star shape (scripts/dense_ab.py, results
 // bit-identical): 13.3 -> 10.7 ms; 64 x 64 x 16 slabs 12.8, 32 x 32 x 16 11.5, 16 x 16 x 64 10.8, 8 x 8 x 32 11.5,
 // 128 x 128 x 16 19.0 ms.  Stores stay 32-byte runs along z per lane group, merged in L2 (zt >= 16).
-struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt, own, stagger; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
+struct SlabOrder { int on, nsx, nsy, nsz, zt, st, tt, zi, nt, own, stagger, groups; };  // zt: z-layers per brick, st: brick side, tt: tile side (columns), zi: inner z run
 
 __device__ __forceinline__ bool slab_decode(const DenseParams& p, const SlabOrder& o, int64_t gv, int* x, int* y, int* z) {
   const int64_t per = (int64_t)o.st * o.st * o.zt;
@@ -256,9 +256,9 @@ __device__ __forceinline__ void group_barrier(unsigned int* w, unsigned int n) {
   if (threadIdx.x == 0) {
     const unsigned int old = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int goal = (old / n + 1u) * n;
-    for (int spin = 0; spin < 4096; ++spin) {
-      if ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - goal) >= 0) break;
-      __builtin_amdgcn_s_sleep(8);
+    for (int spin = 0; spin < 1024; ++spin) {             // sparse polls: every poll is an uncached memory transaction that
+      if ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - goal) >= 0) break;     // competes with the
+      __builtin_amdgcn_s_sleep(64);                        // gathers of the workgroups still at work (~1.7 us apart)
     }
   }
   __syncthreads();
@@ -408,11 +408,15 @@ __global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe
   if constexpr (LOCK != 0) {
     // persistent grid: gridDim.x = 8 * chunk_blocks; group = blockIdx.x & 7 walks chunks group, group + 8, ...; all channel
     // sweeps inside (blockIdx.y unused)
-    const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // ord.groups = 8: one brick per XCD at a time; 16: two independent groups per XCD (b and b + 8 share an XCD), each on its
+    // own brick behind its own barrier -- while one group drains / decodes / projects, the other one's gathers keep the
+    // memory pipeline busy
+    const int NG = ord.groups;
+    const int grp = blockIdx.x % NG, slot = blockIdx.x / NG;
     const int64_t n_chunks = n_phys / chunk_blocks;
     const int n_sweeps = (int)ceil_div_dev(p.C, 4 * LPV);
     for (int sw = 0; sw < n_sweeps; ++sw)
-      for (int64_t ch = grp; ch < n_chunks; ch += 8) {
+      for (int64_t ch = grp; ch < n_chunks; ch += NG) {
         // stagger: released together, the waves of a CU would project at the same time and then wait for memory at the
         // same time (lockstep 2x slower than free-running); wave w of every workgroup starts w x stagger x 64 cycles late,
         // so that at any moment a quarter of the waves is in each quarter of the view step
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe
                                                  // the brick loop (hoisted they spilled, and a scratch access in the view loop
                                                  // puts a vmcnt(0) in front of every gather)
         accum_block<LPV, PIPE, EPI>(p, feat, proj, volume, count, ch * chunk_blocks + slot, sw * 4 * LPV, sw == 0, ord, lds_wave, tid);
-        group_barrier(bar + grp * 32, (unsigned)chunk_blocks);
+        group_barrier(bar + grp * 16, (unsigned)chunk_blocks);
       }
   } else {
     int64_t lb = blockIdx.x;
@@ -595,6 +599,7 @@ struct DenseTune {
   int nt = 0;           // variant 1: non-temporal stores of the volume
   int own = 0;          // variant 1: one channel sweep per XCD group (needs exactly 8 sweeps)
   int stagger = 0;      // variant 1 lockstep: start delay per wave index, in units of 64 cycles
+  int groups = 8;       // variant 1 lockstep: 8 = one brick per XCD at a time, 16 = two independent half-size groups per XCD
   int lattice = 0;      // variant 1 lockstep: 1 = lattice assignment of columns to workgroups (balanced), 0 = compact tiles
   int lockstep = 0;     // variants 1, 2: persistent grid, every XCD group walks one brick at a time (1: behind a barrier, 2: no barrier)
 };
@@ -609,7 +614,7 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
   int64_t cb = ceil_div((int64_t)p.Y * p.Z, 256);
   if (cb < 32) cb = 32;
-  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt, 0, t.stagger};
+  SlabOrder ord{0, 0, 0, 0, t.zt, t.st, t.tt, t.zi, t.nt, 0, t.stagger, t.groups == 16 ? 16 : 8};
   if (t.slab) {
     ord.on = 1;
     if (ord.zi < 1 || ord.zt % ord.zi != 0) return CNRMA_EINVAL;
@@ -646,7 +651,7 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   if (t.lattice && ord.on && ord.zt == 32 && ord.st % 8 == 0) ord.on = 2;
   const int n_sweeps = (int)ceil_div(p.C, 4 * LPV);
   if (t.own && !lock && ord.on && n_sweeps == 8 && nb * 8 < ((int64_t)1 << 31)) ord.own = 1;
-  dim3 grid(lock ? (unsigned)(8 * cb) : (ord.own ? (unsigned)(nb * 8) : (unsigned)gx), (lock || ord.own) ? 1u : (unsigned)n_sweeps);
+  dim3 grid(lock ? (unsigned)(ord.groups * cb) : (ord.own ? (unsigned)(nb * 8) : (unsigned)gx), (lock || ord.own) ? 1u : (unsigned)n_sweeps);
 #define CNRMA_DENSE_LAUNCH(PIPE, EPI)                                                                                      \
   do {                                                                                                                     \
     if (lock)                                                                                                              \
@@ -691,11 +696,11 @@ int launch_accum(const DenseParams& p, const float* feat, const float* proj, flo
 }  // namespace
 
 extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
-  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger}; n < 16 keeps the remaining defaults;
+  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups}; n < 17 keeps the remaining defaults;
   // n == 0 restores the product configuration.  Host-side global state: debug / A-B runs only.
   DenseTune t;
-  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own, &t.stagger};
-  if (n < 0 || n > 16 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own, &t.stagger, &t.groups};
+  if (n < 0 || n > 17 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_tune = t;
   return 0;
