@@ -35,7 +35,7 @@ SIGNATURES = {
     "cnrma_topk_mask_f32": (c_int, [P, P, L, I, P, P, P]),
     "cnrma_rma_depth_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P]),
     "cnrma_rma_depth_emit_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P, F, F, F,
-                                         P, I, P, I, P, I, P]),
+                                         P, I, P, I, P, I, L, L, P]),
     "cnrma_rma_drop_single_sample_views": (c_int, [P, P, I, L, P]),
     "cnrma_rma_mean_weight": (c_int, [P, P, P, P]),
     "cnrma_scan_workspace_bytes": (c_size_t, [L]),

@@ -169,6 +169,8 @@ struct EmitDst {
   const int32_t* sel;    // may be NULL
   const float* w_div;    // device scalar, may be NULL
   float ax, ay, az;
+  int64_t sel_cap = 0;   // > 0: rows m >= sel_cap have no selection entry (static trace: capacity of the row list) -> dropped
+  int64_t out_cap = 0;   // > 0: output rows j >= out_cap do not exist -> dropped
 };
 
 // kept: optional per-ray record of the kept samples, [ray][cap] x {weight bits, step}; lets the emission run one
@@ -428,9 +430,11 @@ __device__ __forceinline__ void emit_row(const EmitDst& d, int64_t m, float x, f
                                          const float* __restrict__ f, int C, int64_t ray, int step) {
   int64_t j = m;
   if (d.sel) {
+    if (d.sel_cap > 0 && m >= d.sel_cap) return;
     j = d.sel[m];
     if (j < 0) return;
   }
+  if (d.out_cap > 0 && j >= d.out_cap) return;
   if (d.xyz) {
     float* q = d.xyz + j * d.xyz_stride;
     q[0] = x + d.ax; q[1] = y + d.ay; q[2] = z + d.az;
@@ -806,10 +810,13 @@ extern "C" int cnrma_rma_depth_emit_f32(const float* proj_inv, const float* tsdf
                                         float oz, int n_steps, float t_one, int select_grids,
                                         const int32_t* row_offset, const int32_t* sel_index, const float* w_div,
                                         float addx, float addy, float addz, float* out_xyz, int xyz_stride,
-                                        float* out_w, int w_stride, float* out_feat, int feat_stride, void* stream) {
-  if (bad_dims(V, H, W, X, Y, Z, n_steps) || C <= 0 || select_grids < 0) return CNRMA_EINVAL;
+                                        float* out_w, int w_stride, float* out_feat, int feat_stride, int64_t sel_cap,
+                                        int64_t out_cap, void* stream) {
+  if (bad_dims(V, H, W, X, Y, Z, n_steps) || C <= 0 || select_grids < 0 || sel_cap < 0 || out_cap < 0) return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, 0.0f);
   EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, nullptr, sel_index, w_div, addx, addy, addz};
+  d.sel_cap = sel_cap;
+  d.out_cap = out_cap;
   int64_t R = (int64_t)V * H * W;
   hipLaunchKernelGGL(depth_emit_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, as_stream(stream), p,
                      select_grids, C, proj_inv, tsdf, feat_nhwc, row_offset, d);

@@ -259,11 +259,13 @@ class StaticScene:
         self._pin_off = torch.zeros(3, dtype=torch.float32, pin_memory=True)
         cfg = self.cfg
         # the march runs with the layout pass, in _load (one launch), into buffers the graph reads
-        self.march = rma._March(self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
-                                "neus", 0)
-        if self.march.kept_cap() <= 0:
-            raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
-        self.march_out = self.march.march_buffers()
+        self.march = self.march_out = None
+        if cfg.ray_marching_type == "neus":
+            self.march = rma._March(self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps,
+                                    cfg.thr, "neus", 0)
+            if self.march.kept_cap() <= 0:
+                raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
+            self.march_out = self.march.march_buffers()
         self._pin_proj = torch.empty((V, 3, 4), dtype=torch.float32, pin_memory=True)
         self._pin_inv = torch.empty((V, 4, 4), dtype=torch.float32, pin_memory=True)
 
@@ -292,7 +294,10 @@ class StaticScene:
             features_nchw = None
         self._copied = torch.cuda.Event()
         self._copied.record()                    # the pinned staging buffers are free again once this point has executed
-        self.march.march(layout_from=features_nchw, into=self.march_out)
+        if self.march is not None:
+            self.march.march(layout_from=features_nchw, into=self.march_out)
+        elif features_nchw is not None:          # depth mode: the layout pass alone (its two small kernels run inside the trace)
+            rma.to_nhwc(features_nchw, out=self.nhwc)
 
     def _enter(self, *inputs):
         """order self.stream behind the caller's stream (the 2D backbone / Atlas head that produced the inputs ran
@@ -317,7 +322,9 @@ class StaticScene:
             coords, feats, n_sel, info = rma.aggregate_points_static(
                 self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                 max_points=cfg.max_points, seed=cfg.sample_seed if fixed else 0x5EED,
-                seed_dev=None if fixed else self.seed_dev, marched=(self.march, self.march_out))
+                seed_dev=None if fixed else self.seed_dev,
+                marched=(self.march, self.march_out) if self.march is not None else None,
+                mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0)
             moved = coords + self.offset_dev     # ray_marching.py:364 (one fp32 add per coordinate, as the reference)
             out.update(trace_net(plan, self.backbone, self.head, moved, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
                                  extra_counts=[info["M"], n_sel]))
@@ -499,7 +506,8 @@ class StaticBatch:
                 coords, feats, n_sel, info = rma.aggregate_points_static(
                     h.nhwc, h.proj_inv, h.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                     max_points=cfg.max_points, seed=(cfg.sample_seed if fixed else 0x5EED) + 7919 * b * (0 if fixed else 1),
-                    seed_dev=None if fixed else h.seed_dev, marched=(h.march, h.march_out))
+                    seed_dev=None if fixed else h.seed_dev, marched=(h.march, h.march_out) if h.march is not None else None,
+                    mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0)
                 pts.append((coords + h.offset_dev, feats, n_sel))
                 Ms += [info["M"].view(1), n_sel.view(1)]
                 if not fixed:

@@ -255,7 +255,7 @@ class _March:
              stream())
 
     def emit(self, row_offset, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride,
-             out_sample=None):
+             out_sample=None, sel_cap=0, out_cap=0):
         head = (ptr(self.pinv), ptr(self.tsdf), ptr(self.feat), self.V, self.C, self.H, self.W, self.X, self.Y, self.Z,
                 self.vs, *self.org, self.N, self.t_one)
         tail = (ptr(row_offset), ptr(sel_index), ptr(w_div), float(add[0]), float(add[1]), float(add[2]),
@@ -263,7 +263,7 @@ class _March:
         if self.mode == "neus":
             call("cnrma_rma_neus_emit_f32", *head, self.thr, *tail, ptr(out_sample), stream())
         else:
-            call("cnrma_rma_depth_emit_f32", *head, self.k, *tail, stream())
+            call("cnrma_rma_depth_emit_f32", *head, self.k, *tail, int(sel_cap), int(out_cap), stream())
 
 
 def exclusive_scan(count):
@@ -429,15 +429,20 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
 
 def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05,
                             offset=(0.0, 0.0, 0.0), max_points=None, seed=0, seed_dev=None, reference_quirks=True,
-                            marched=None):
+                            marched=None, mode="neus", select_grids=0):
     """aggregate_points() without a device->host read (the static trace of plan.Plan; NeuS single-march only): the row
     count M stays on the device, the selection always goes through the device sampler (it keeps every row when
     M <= max_points) and the outputs are capacity-sized.  Returns (coords [cap,3], feats [cap,C], n_dev int32 [1], info);
     rows >= n_dev[0] are undefined."""
     plan = P.current()
     assert plan is not None and plan.static
+    depth = mode == "depth"
+    kept = overflow = None
     if marched is not None:          # (march object, its outputs): the march already ran (with the layout pass, outside the trace)
         m, (cnt, wsum, kept, overflow) = marched[0], marched[1][:4]
+    elif depth:                      # ray_projection_depth (:809-956): a fixed number of rows per ray with a sign change
+        m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, 0.0, "depth", select_grids)
+        cnt, wsum = m.count()
     else:
         m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0)
         if m.kept_cap() <= 0:
@@ -452,15 +457,20 @@ def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, ori
     call("cnrma_sum_f64", ptr(wsum), ptr(wtot), m.R, ptr(ws), stream())
     m_total = off[m.R:]
     call("cnrma_rma_mean_weight", ptr(wtot), m_total.data_ptr(), ptr(mean_w), stream())
-    M_cap = plan.next_cap(bound=m.R * kept.shape[1], n_dev=m_total, lo=1)      # lo = 1: M == 0 is the reference's TypeError
-    plan.watch(overflow, 0, 0)
+    rows_per_ray = max(1, 2 * m.k) if depth else kept.shape[1]
+    M_cap = plan.next_cap(bound=m.R * rows_per_ray, n_dev=m_total, lo=1)      # lo = 1: M == 0 is the reference's TypeError
+    if overflow is not None:
+        plan.watch(overflow, 0, 0)
     n_keep = int(max_points) if max_points is not None else M_cap
     mask = sample_mask_device(m_total, M_cap, n_keep, seed=seed, seed_dev=seed_dev)
     sel, n_sel = mask_to_index(mask)
     cap = min(M_cap, n_keep)
     coords = torch.empty((cap, 3), dtype=torch.float32, device=m.dev)
     feats = torch.empty((cap, m.C), dtype=torch.float32, device=m.dev)
-    m.emit_rows(off, cap, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C, n_out_dev=n_sel)
+    if depth:
+        m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C, sel_cap=M_cap, out_cap=cap)
+    else:
+        m.emit_rows(off, cap, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C, n_out_dev=n_sel)
     info = dict(M=m_total, M_selected=n_sel, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m)
     return coords, feats, n_sel, info
 

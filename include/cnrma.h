@@ -182,7 +182,9 @@ int cnrma_rma_depth_emit_f32(const float* proj_inv, const float* tsdf, const flo
                              int n_steps, float t_one, int select_grids, const int32_t* row_offset,
                              const int32_t* sel_index, const float* w_div, float addx, float addy, float addz,
                              float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
-                             int feat_stride, void* stream);
+                             int feat_stride, int64_t sel_cap, int64_t out_cap, void* stream);
+/* sel_cap / out_cap (0 = unbounded): capacities of sel_index and of the output buffers when the row count stays on the
+ * device (static trace): rows beyond them are dropped instead of written. */
 
 /* Reference quirk: a view whose rays keep exactly ONE sample in total is dropped (ray_marching.py:781-782: squeeze()
  * makes the index 0-dim, len() raises, the bare except skips the view): zeroes that view's counts and weight sums. */

@@ -242,15 +242,15 @@ class RayMarching(MultiViewBase):
 
     # ---- inference fast path: the scene as one replayed HIP graph (cnrma_amd.pipeline.StaticScene) ----------------------
     def _static_eligible(self, inputs):
-        """The graph path takes a scene when nothing in it needs the host: NeuS marching, the max_points subset drawn on
+        """The graph path takes a scene when nothing in it needs the host: NeuS or depth marching, the max_points subset drawn on
         the device (point_sampler="device"; the reference's numpy draw needs the row count on the host), one sample per
         GPU (the reference's own structural limit, ray_marching.py:707), eval mode.  Everything else -- and every scene
         that outgrows the size plan -- goes through the eager path (_run)."""
-        if not self.static_test or self.training or self.ray_marching_type != "neus":
+        if not self.static_test or self.training or self.ray_marching_type not in ("neus", "depth"):
             return False
         if self.max_points is not None and self.point_sampler != "device":
             return False
-        if self.neus_threshold is None or self.neus_threshold <= 1.0 / 62:
+        if self.ray_marching_type == "neus" and (self.neus_threshold is None or self.neus_threshold <= 1.0 / 62):
             return False
         proj = inputs.get("projection")
         if proj is None or proj.shape[0] != 1:
@@ -290,8 +290,9 @@ class RayMarching(MultiViewBase):
         key = (tuple(feats.shape), tuple(self.voxel_dim), dense_in_graph, str(feats.device))
         ctx = self._static.get(key)
         if ctx is None:
-            cfg = pipeline.SceneConfig(self.voxel_dim, self.voxel_size, org, self.backbone2d_stride, 300, self.neus_threshold,
-                                       self.max_points, self.voxel_size_fcaf3d, "neus", None, "device")
+            cfg = pipeline.SceneConfig(self.voxel_dim, self.voxel_size, org, self.backbone2d_stride, 300,
+                                       self.neus_threshold if self.ray_marching_type == "neus" else 0.05,
+                                       self.max_points, self.voxel_size_fcaf3d, self.ray_marching_type, self.depth_points, "device")
             first = pipeline.StaticScene(cfg, self.detection_backbone, self.detection_head, feats.device, dense=dense_in_graph)
             ctx = dict(cfg=cfg, slots=[first], pending=[None] * max(1, self.static_slots), seen=0, k=0, built=False)
             self._static[key] = ctx

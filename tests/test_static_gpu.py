@@ -248,3 +248,39 @@ def test_detect_recaptures_after_repeated_plan_violations(device):
     b0, s0 = _sorted(eager["bboxes"].cpu().numpy(), eager["scores"].cpu().numpy())
     b1, s1 = _sorted(b.cpu().numpy(), s.cpu().numpy())
     np.testing.assert_allclose(b1, b0, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_static_depth_mode_vs_reference_golden(device, k):
+    """ray_projection_depth (ray_marching.py:809-956; `ray_marching_type='depth'`, depth_points = k) inside the static trace /
+    graph -- row count on the device, capacity-guarded emission -- against the reference's golden depth rows of the fixture
+    scene: places bit-exact, aggregated features (f * w / mean(w)) within 1e-6; row counts and detections equal to the eager
+    path's"""
+    from helpers import load_golden, t
+    from cnrma_amd import pipeline
+    g = load_golden("mini_p")
+    # the fixture holds the reference's depth rows of view 0: a one-view scene
+    feat, proj, tsdf, pinv = t(g["features"][:1], device), t(g["projection"][:1]), t(g["tsdf"], device), t(g["proj_inv"][:1])
+    backbone, head = _model(feat.shape[1], device)
+    cfg = pipeline.SceneConfig(g["dims"], voxel_size=g["voxel_size"], origin=g["origin"], stride=g["stride"],
+                               n_steps=g["n_steps"], max_points=20000, sample_seed=9, ray_marching_type="depth", depth_points=k)
+    st = pipeline.StaticScene(cfg, backbone, head, device)
+    eager = st.build(feat, proj, tsdf, proj_inv=pinv)
+    assert st.graph is not None and st.march is None
+    st.run(feat * 0.5, proj, tsdf * 0.7, proj_inv=pinv)                  # other inputs through the graph first
+    out = st.run(feat, proj, tsdf, proj_inv=pinv)
+    b, s, info = pipeline.StaticScene.detections(out)
+    exp = g[f"depth_rows_k{k}"]
+    n = exp.shape[0]
+    assert info["M"] == eager["M"] == n > 0 and info["M_unique"] == eager["M_unique"]
+    assert info["level_rows"] == eager["level_rows"] and info["head_rows"] == eager["head_rows"]
+    coords, pf, n_sel = out["points"]
+    assert int(n_sel) == n
+    assert (coords[:n].cpu().numpy().view(np.uint32) == exp[:, :3].astype(np.float32).view(np.uint32)).all()
+    w = exp[:, 3].astype(np.float64)
+    want = exp[:, 4:] * (exp[:, 3:4] / np.float32(w.sum() / n))
+    np.testing.assert_allclose(pf[:n].cpu().numpy(), want, rtol=2e-6, atol=1e-7)
+    b0, s0 = _sorted(eager["bboxes"].cpu().numpy(), eager["scores"].cpu().numpy())
+    b1, s1 = _sorted(b.cpu().numpy(), s.cpu().numpy())
+    np.testing.assert_allclose(b1, b0, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)
