@@ -599,6 +599,7 @@ struct DenseTune {
   int nt = 0;           // variant 1: non-temporal stores of the volume
   int own = 0;          // variant 1: one channel sweep per XCD group (needs exactly 8 sweeps)
   int stagger = 0;      // variant 1 lockstep: start delay per wave index, in units of 64 cycles
+  int ldspad = 0;       // variant 1: KB of unused dynamic LDS per workgroup (caps the workgroups per CU: leaves room for co-resident kernels)
   int groups = 8;       // variant 1 lockstep: 8 = one brick per XCD at a time, 16 = two independent half-size groups per XCD
   int lattice = 0;      // variant 1 lockstep: 1 = lattice assignment of columns to workgroups (balanced), 0 = compact tiles
   int lockstep = 0;     // variants 1, 2: persistent grid, every XCD group walks one brick at a time (1: behind a barrier, 2: no barrier)
@@ -658,8 +659,8 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
       hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 1>), grid, dim3(256), 0, st, p, feat, proj, volume, \
                          count, (int)cb, gx, ord, bar);                                                                    \
     else                                                                                                                   \
-      hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 0>), grid, dim3(256), 0, st, p, feat, proj, volume, \
-                         count, (int)cb, gx, ord, bar);                                                                    \
+      hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 0>), grid, dim3(256), (size_t)t.ldspad * 1024, st, p,  \
+                         feat, proj, volume, count, (int)cb, gx, ord, bar);                                               \
   } while (0)
   if (t.pipe == 2) { if (t.epi) CNRMA_DENSE_LAUNCH(2, 1); else CNRMA_DENSE_LAUNCH(2, 0); }
   else             { if (t.epi) CNRMA_DENSE_LAUNCH(1, 1); else CNRMA_DENSE_LAUNCH(1, 0); }
@@ -696,11 +697,11 @@ int launch_accum(const DenseParams& p, const float* feat, const float* proj, flo
 }  // namespace
 
 extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
-  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups}; n < 17 keeps the remaining defaults;
+  // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups, ldspad}; n < 18 keeps the remaining defaults;
   // n == 0 restores the product configuration.  Host-side global state: debug / A-B runs only.
   DenseTune t;
-  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own, &t.stagger, &t.groups};
-  if (n < 0 || n > 17 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  int* f[] = {&t.variant, &t.slab, &t.st, &t.zt, &t.tt, &t.zi, &t.chunk, &t.persist, &t.lpv, &t.pipe, &t.epi, &t.lockstep, &t.lattice, &t.nt, &t.own, &t.stagger, &t.groups, &t.ldspad};
+  if (n < 0 || n > 18 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_tune = t;
   return 0;

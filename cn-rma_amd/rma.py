@@ -80,7 +80,7 @@ def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stri
 
 
 _DENSE_WS = {}
-_DENSE_KEYS = ("variant", "slab", "st", "zt", "tt", "zi", "chunk", "persist", "lpv", "pipe", "epi", "lockstep", "lattice", "nt", "own", "stagger", "groups")
+_DENSE_KEYS = ("variant", "slab", "st", "zt", "tt", "zi", "chunk", "persist", "lpv", "pipe", "epi", "lockstep", "lattice", "nt", "own", "stagger", "groups", "ldspad")
 
 
 def _dense_workspace(dev, st):
@@ -101,7 +101,7 @@ def dense_tuning(**kw):
     if not kw:
         call("cnrma_debug_dense_tuning", None, 0)
         return
-    base = dict(variant=1, slab=1, st=16, zt=32, tt=8, zi=32, chunk=-1, persist=0, lpv=0, pipe=1, epi=0, lockstep=0, lattice=0, nt=0, own=0, stagger=0, groups=8)
+    base = dict(variant=1, slab=1, st=16, zt=32, tt=8, zi=32, chunk=-1, persist=0, lpv=0, pipe=1, epi=0, lockstep=0, lattice=0, nt=0, own=0, stagger=0, groups=8, ldspad=0)
     base.update(DENSE_DEFAULTS)
     unknown = set(kw) - set(base)
     assert not unknown, unknown

@@ -55,7 +55,7 @@ int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V
                                 float* volume, int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Debug / A-B aid (scripts/dense_ab.py, tests of the alternative voxel orders): overrides the dense kernel's schedule
- * switches {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups} (host-side global state; n = 0
+ * switches {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups, ldspad} (host-side global state; n = 0
  * restores the product configuration).  Product code never calls it and nothing reads the environment. */
 int cnrma_debug_dense_tuning(const int* values, int n);
 
