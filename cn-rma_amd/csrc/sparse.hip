@@ -1456,6 +1456,73 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   }
 }
 
+// ---- BatchNorm (training) backward over the rows of a [n][C] matrix -----------------------------------------------------
+// s1[c] = sum_r dy[r][c], s2[c] = sum_r dy[r][c] * x[r][c] in fp64, deterministic two-stage like colstats; then
+// dgamma = (s2 - mean * s1) / sigma, dbeta = s1, dx = gamma / sigma * (dy - s1 / n - xhat * dgamma / n)
+__global__ __launch_bounds__(256) void colsum2_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              int64_t n, int C, double* __restrict__ part) {
+  const int c = threadIdx.x % C;
+  const int groups = blockDim.x / C;
+  const int gi = threadIdx.x / C;
+  double s = 0.0, q = 0.0;
+  if (gi < groups) {
+    for (int64_t r = (int64_t)blockIdx.x * groups + gi; r < n; r += (int64_t)gridDim.x * groups) {
+      const double g = (double)dy[r * C + c];
+      s += g;
+      q += g * (double)x[r * C + c];
+    }
+  }
+  __shared__ double sm[2 * 256];
+  sm[threadIdx.x] = s;
+  sm[256 + threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double ts = 0.0, tq = 0.0;
+    for (int g = 0; g < groups; ++g) { ts += sm[g * C + threadIdx.x]; tq += sm[256 + g * C + threadIdx.x]; }
+    part[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = ts;
+    part[(int64_t)blockIdx.x * 2 * C + C + threadIdx.x] = tq;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_backward_final_kernel(const double* __restrict__ part, int nblk, int C, int64_t n,
+                                                                const double* __restrict__ stats, float eps,
+                                                                float* __restrict__ dweight, float* __restrict__ dbias,
+                                                                double* __restrict__ sums) {
+  const int c = blockIdx.x;
+  __shared__ double ss[256], qq[256];
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) { s += part[(int64_t)b * 2 * C + c]; q += part[(int64_t)b * 2 * C + C + c]; }
+  ss[threadIdx.x] = s; qq[threadIdx.x] = q;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) { ss[threadIdx.x] += ss[threadIdx.x + d]; qq[threadIdx.x] += qq[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = stats[c], inv = 1.0 / sqrt(stats[C + c] + (double)eps);
+    const double dg = (qq[0] - mean * ss[0]) * inv;
+    if (dweight) dweight[c] = (float)dg;
+    if (dbias) dbias[c] = (float)ss[0];
+    sums[c] = ss[0] / (double)n;          // mean(dy)
+    sums[C + c] = dg / (double)n;         // mean(dy * xhat)
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                int64_t n, int C, const double* __restrict__ stats,
+                                                                const double* __restrict__ sums,
+                                                                const float* __restrict__ weight, float eps,
+                                                                float* __restrict__ dx) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * C; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(t % C);
+    const float mean = (float)stats[c];
+    const float inv = 1.0f / sqrtf((float)stats[C + c] + eps);
+    const float xhat = (x[t] - mean) * inv;
+    const float g = weight ? weight[c] : 1.0f;
+    dx[t] = g * inv * (dy[t] - (float)sums[c] - xhat * (float)sums[C + c]);
+  }
+}
+
 __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ in, int64_t n_cap,
                                                      const int32_t* __restrict__ n_dev, int C, float* __restrict__ out) {
   const int64_t n = live_rows(n_cap, n_dev);
@@ -2268,6 +2335,27 @@ extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, c
   hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n_cap, n_dev, stats_ws);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, st, in_feats, n_cap,
                      n_dev, row0_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// BatchNorm1d training backward for the rows of x [n][C] (C <= 256): stats = {mean[C], biased var[C]} in fp64 as the forward
+// (cnrma_sparse_instnorm_f32 with the layer's eps) left them; ws: cnrma_instnorm_workspace_bytes(C).
+extern "C" int cnrma_bn_backward_f32(const float* grad_out, const float* x, int64_t n, int C, const double* stats,
+                                     const float* weight, float eps, float* grad_in, float* grad_weight, float* grad_bias,
+                                     double* ws, void* stream) {
+  if (n <= 0 || C <= 0 || C > 256 || grad_out == nullptr || x == nullptr || stats == nullptr || grad_in == nullptr ||
+      ws == nullptr)
+    return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = 1024;
+  double* sums = ws;                  // [2C]
+  double* part = ws + 2 * C;          // [nblk][2C]
+  hipLaunchKernelGGL(colsum2_partial_kernel, dim3(nblk), dim3(256), 0, st, grad_out, x, n, C, part);
+  hipLaunchKernelGGL(bn_backward_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n, stats, eps, grad_weight,
+                     grad_bias, sums);
+  hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(grid_for(n * C, 256, 4096)), dim3(256), 0, st, grad_out, x, n, C, stats,
+                     sums, weight, eps, grad_in);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

@@ -105,7 +105,7 @@ class MinkowskiBatchNorm(nn.Module):
 
     def forward(self, x):
         if self.training:
-            return S.SparseTensor(self.bn(x.F), x.cs)
+            return S.SparseTensor(S.batch_norm_train(x.F, self.bn), x.cs)
         scale, shift = self.folded()
         return S.SparseTensor(x.F * scale + shift, x.cs)
 

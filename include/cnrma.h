@@ -400,6 +400,13 @@ int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_
                               const float* weight, const float* bias, float eps, int relu, float* out_feats,
                               double* stats_ws, void* stream);
 
+/* MinkowskiBatchNorm in training (nn.BatchNorm1d over the rows, fcaf3d_backbone.py / fcaf3d_head.py blocks): the forward is
+ * cnrma_sparse_instnorm_f32 with the layer's eps (it leaves {mean, biased variance} in stats_ws); this is the backward:
+ * grad_weight = sum dy * xhat, grad_bias = sum dy, grad_in = weight / sigma * (dy - mean(dy) - xhat * mean(dy * xhat)).
+ * fp64 column sums in a fixed order (deterministic).  ws: cnrma_instnorm_workspace_bytes(C). */
+int cnrma_bn_backward_f32(const float* grad_out, const float* x, int64_t n, int C, const double* stats, const float* weight,
+                          float eps, float* grad_in, float* grad_weight, float* grad_bias, double* ws, void* stream);
+
 /* union-add of two sparse tensors at the same tensor stride (`inputs[i] + x`, fcaf3d_head.py:114):
  * output rows = all rows of A (in order) followed by the rows of B that are not in A.
  * a_hash maps A's coords -> A rows.  out_coords [Na+Nb cap][4], out_feats likewise; n_out device word.

@@ -36,6 +36,15 @@ def step():
     out["loss"].backward()
     opt.step()
     return float(out["loss"].detach())
+from cnrma_amd import sparse as S_
+for bn_hip in (True, False, True, False):
+    S_.BN_TRAIN_HIP = bn_hip
+    for _ in range(2): l = step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): l = step()
+    torch.cuda.synchronize()
+    print(f"  BatchNorm through {'the HIP kernels' if bn_hip else 'torch'}: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms per step", flush=True)
+S_.BN_TRAIN_HIP = False
 for _ in range(2): l = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 5

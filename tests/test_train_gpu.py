@@ -203,3 +203,35 @@ def test_full_size_train_step_at_scannet_shape(device, tmp_path):
         opt.step()
         losses.append(float(out["loss"].detach()))
     assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("n,C", [(5000, 64), (777, 128), (40000, 32), (300, 256)])
+def test_batch_norm_train_kernels_match_torch(device, n, C):
+    """MinkowskiBatchNorm in training mode runs on the library's column-statistics kernels (forward) and
+    cnrma_bn_backward_f32 (backward): output, running statistics and all three gradients against nn.BatchNorm1d"""
+    from cnrma_amd import sparse as S
+    torch.manual_seed(n + C)
+    x = (torch.randn(n, C, device=device) * 3 + 1.5)
+    g = torch.randn(n, C, device=device)
+    ref = torch.nn.BatchNorm1d(C).to(device).train()
+    got = torch.nn.BatchNorm1d(C).to(device).train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.normal_()
+        got.load_state_dict(ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    prev, S.BN_TRAIN_HIP = S.BN_TRAIN_HIP, True
+    try:
+        yg = S.batch_norm_train(xg, got)
+    finally:
+        S.BN_TRAIN_HIP = prev
+    yr.backward(g)
+    yg.backward(g)
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(got.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(got.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(got.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == 1
