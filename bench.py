@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--through-plugin", action="store_true",
                     help="drive the registered RayMarching detector -- model(return_loss=False, **data), {scene}_bbox_raw.npz "
                          "written per scene -- instead of pipeline.StaticScene directly")
+    ap.add_argument("--pace", type=int, default=1, help="1 = the host waits for a slot's previous scene before refilling it "
+                    "(what a caller that consumes the detections does anyway; +1 %% over enqueueing blindly), 0 = enqueue as fast as possible")
     ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
                     "'variant=0' = the round-2 kernel (cnrma_debug_dense_tuning; never set by the driver)")
     return ap.parse_args()
@@ -439,6 +441,8 @@ class Workload:
             i = self._k % len(self.slots)
             self._k += 1
             st = self.slots[i]
+            if self.args.pace and getattr(st, "done", None) is not None:
+                st.done.synchronize()                           # host paces itself: a slot is refilled when its scene has left it
             out = st.run(s["features"], s["projection"], s["tsdf"])
             with torch.cuda.stream(st.stream):                  # results leave the slot's static buffers in stream order
                 nb = out["bboxes"].shape[1]
