@@ -57,7 +57,9 @@ class MultiViewBase(nn.Module):
         statistics are to be shared, else view by view), or taken from the inputs when there is no 2D network"""
         if self.fpn is None:
             f = inputs["features"]
-            return torch.stack(f, dim=1) if isinstance(f, (list, tuple)) else f
+            if isinstance(f, (list, tuple)):       # one sample per GPU (the reference's structural limit): a view, no 12.6-GB stack copy
+                return f[0].unsqueeze(1) if len(f) == 1 else torch.stack(f, dim=1)
+            return f
         images = inputs["imgs"].transpose(0, 1)
         if batched:
             x = self.backbone2d(self.normalizer(images.reshape(-1, *images.shape[2:])))
@@ -70,18 +72,31 @@ class MultiViewBase(nn.Module):
         clear_3d_features() runs ONE kernel over all of them (sum in view order + mean), which is bit-identical."""
         self._views.append((projection, feature))
 
+    def _whole(self, views_of, hint):
+        """the [V, ...] tensor the per-view slices handed to aggregate_2d_features were cut from -- `hint`, when the slices
+        are exactly its rows (the detectors' own loop): no re-stacking copy (12.6 GB at the north-star shape)"""
+        if hint is not None and hint.shape[0] == len(views_of) and tuple(hint.shape[1:]) == tuple(views_of[0].shape) and \
+                all(v.data_ptr() == hint[i].data_ptr() and v.stride() == hint[i].stride() for i, v in enumerate(views_of)):
+            return hint
+        return torch.stack(views_of, dim=0)
+
     def clear_3d_features(self):
-        projs = torch.stack([p for p, _ in self._views], dim=0)        # [V,B,3,4]
-        feats = torch.stack([f for _, f in self._views], dim=0)        # [V,B,C,H,W]
+        hint = getattr(self, "_view_source", (None, None))
+        projs = self._whole([p for p, _ in self._views], hint[0])      # [V,B,3,4]
+        feats = self._whole([f for _, f in self._views], hint[1])      # [V,B,C,H,W]
+        self._view_source = (None, None)
+        projs_cpu = projs.detach().cpu()                               # ONE device->host copy for all views
         vols, valids = [], []
         org = self.origin.view(-1).tolist()
+        self._nhwc = {}                # channels-last copies of this scene's feature maps, shared with the ray marching
         for b in range(feats.shape[1]):
             if torch.is_grad_enabled() and feats.requires_grad:      # training: gradient of the volume -> feature maps
-                vol, cnt = rma.BackprojectAccum.apply(feats[:, b], projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                vol, cnt = rma.BackprojectAccum.apply(feats[:, b], projs_cpu[:, b], self.voxel_dim, self.voxel_size, org,
                                                       self.backbone2d_stride)
             else:
                 nhwc = rma.to_nhwc(feats[:, b])
-                vol, cnt = rma.backproject_accum(nhwc, projs[:, b].cpu(), self.voxel_dim, self.voxel_size, org,
+                self._nhwc[(feats.data_ptr(), b)] = nhwc
+                vol, cnt = rma.backproject_accum(nhwc, projs_cpu[:, b], self.voxel_dim, self.voxel_size, org,
                                                  self.backbone2d_stride)
             vols.append(vol)
             valids.append((cnt > 0).unsqueeze(0))
