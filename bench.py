@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--through-plugin", action="store_true",
                     help="drive the registered RayMarching detector -- model(return_loss=False, **data), {scene}_bbox_raw.npz "
                          "written per scene -- instead of pipeline.StaticScene directly")
+    ap.add_argument("--plugin-static", type=int, default=1, help="--through-plugin only: 0 = force the detector's eager path "
+                    "(what the reference's default numpy point sampler takes)")
     ap.add_argument("--pace", type=int, default=1, help="1 = the host waits for a slot's previous scene before refilling it "
                     "(what a caller that consumes the detections does anyway; +1 %% over enqueueing blindly), 0 = enqueue as fast as possible")
     ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
@@ -338,7 +340,8 @@ class Workload:
         self.save_dir = tempfile.mkdtemp(prefix="cnrma_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None, save_path=self.save_dir,
                  voxel_dim_test=list(self.dims), voxel_dim_train=list(self.dims), backbone2d_stride=self.stride,
-                 max_points=500000, point_sampler="device", static_slots=self.args.slots, static_calibration=self.args.scenes)
+                 max_points=500000, point_sampler="device", static_slots=self.args.slots, static_calibration=self.args.scenes,
+                 static_test=bool(self.args.plugin_static))
         m["detection_backbone"] = dict(type="FCAF3DBackbone", in_channels=self.C, depth=34)
         torch.manual_seed(0)
         model = build_detector(m)
@@ -357,6 +360,9 @@ class Workload:
             with torch.no_grad():
                 for s in self.scenes:                            # the calibration scenes (eager); the last one builds the slots
                     self._plugin_scene(s)
+            if not self.args.plugin_static:
+                self.slots = []
+                return
             ctx = next(iter(self.model._static.values()))
             assert ctx["built"]
             self.slots = ctx["slots"]
@@ -475,6 +481,8 @@ class Workload:
         return int(sum(int(b.item()) for b in self.bad))
 
     def sizes(self):
+        if self.plugin and not self.slots:
+            return dict(M_rows=None, M_selected=None, M_unique=None, level_rows=None, head_rows=None)
         if self.plugin:
             st = self.slots[0]
             st.run(self.scenes[0]["features"], self.scenes[0]["projection"], self.scenes[0]["tsdf"])
