@@ -88,7 +88,15 @@ class RayMarching(MultiViewBase):
         import atexit
         import weakref
         ref = weakref.ref(self)
-        atexit.register(lambda: ref() is not None and ref().flush())
+
+        def _flush_at_exit():
+            m = ref()
+            if m is not None:
+                try:
+                    m.flush()                 # results of the scenes still in flight when the test loop ended
+                except Exception as e:       # the device may already be gone at interpreter exit: say so, do not raise
+                    print(f"RayMarching: could not flush pending detections at exit: {e!r}")
+        atexit.register(_flush_at_exit)
         self.initialize_volume()
 
     def initialize_volume(self):
