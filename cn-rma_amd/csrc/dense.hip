@@ -374,12 +374,18 @@ __device__ __forceinline__ void accum_block(const DenseParams& p, const float* _
     // transpose through the wave's own LDS tile [4*LPV channels][64 voxels (+1 pad)] so that every store instruction
     // writes ONE channel plane for the wave's 64 voxels (two full 128-B lines in brick order) instead of 8 planes x 32 B
     constexpr int LD = 65;
+    // everything the epilogue needs is re-derived here from a laundered thread index, so that nothing of it is live
+    // across the view loop (kept live it pushed the loop over its 128 registers: scratch reloads = a vmcnt(0) per view)
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));
+    const int lane2 = t2 & 63, sub2 = lane2 % LPV, vsel2 = lane2 / LPV;
+    float* ldsw = lds_wave + 0 * (t2 & 0);
 #pragma unroll
     for (int grp = 0; grp < LPV; ++grp) {
-      const int cv = __shfl(cnt, grp * VPG + vsel, 64);
+      const int cv = __shfl(cnt, grp * VPG + vsel2, 64);
       const float denom = (float)cv;
       const float4 a = acc[grp];
-      float* t = lds_wave + (4 * sub) * LD + grp * VPG + vsel;
+      float* t = ldsw + (4 * sub2) * LD + grp * VPG + vsel2;
       t[0 * LD] = cv > 0 ? a.x / denom : 0.0f;
       t[1 * LD] = cv > 0 ? a.y / denom : 0.0f;
       t[2 * LD] = cv > 0 ? a.z / denom : 0.0f;
@@ -389,7 +395,7 @@ __device__ __forceinline__ void accum_block(const DenseParams& p, const float* _
     if (in_grid) {
       float* o = volume + (int64_t)c0 * G + lin;
 #pragma unroll
-      for (int c = 0; c < 4 * LPV; ++c) o[(int64_t)c * G] = lds_wave[c * LD + lane];
+      for (int c = 0; c < 4 * LPV; ++c) o[(int64_t)c * G] = ldsw[c * LD + lane2];
     }
     __builtin_amdgcn_wave_barrier();
   }
