@@ -37,6 +37,47 @@ static inline hipError_t cnrma_fill_bytes(void* p, int byte, size_t n_bytes, hip
   return hipGetLastError();
 }
 
+// Up to three byte fills in ONE launch (hash keys + values + a status word of a coordinate-set build: three launches of
+// ~5 us each, 21 times per scene).  Regions 4-byte aligned, sizes multiples of 4 bytes; blocks are dealt to the regions in
+// proportion to their sizes.
+struct FillRegion { uint32_t* p; uint32_t word; size_t n_words; unsigned first_block, n_blocks; };
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void cnrma_fill3_kernel(FillRegion a, FillRegion b, FillRegion c) {
+  const FillRegion& r = blockIdx.x >= c.first_block ? c : (blockIdx.x >= b.first_block ? b : a);
+  if (r.n_blocks == 0) return;
+  const unsigned lb = blockIdx.x - r.first_block;
+  const size_t n4 = (((uintptr_t)r.p & 15) == 0) ? r.n_words / 4 : 0;
+  const uint4 w4 = make_uint4(r.word, r.word, r.word, r.word);
+  for (size_t i = (size_t)lb * blockDim.x + threadIdx.x; i < n4; i += (size_t)r.n_blocks * blockDim.x)
+    reinterpret_cast<uint4*>(r.p)[i] = w4;
+  for (size_t i = 4 * n4 + (size_t)lb * blockDim.x + threadIdx.x; i < r.n_words; i += (size_t)r.n_blocks * blockDim.x)
+    r.p[i] = r.word;
+}
+static inline hipError_t cnrma_fill_bytes3(void* p1, int b1, size_t n1, void* p2, int b2, size_t n2, void* p3, int b3, size_t n3,
+                                           hipStream_t st) {
+  void* ps[3] = {p1, p2, p3};
+  const int bs[3] = {b1, b2, b3};
+  const size_t ns[3] = {n1, n2, n3};
+  FillRegion r[3];
+  unsigned total = 0;
+  for (int i = 0; i < 3; ++i) {
+    if ((ns[i] & 3) != 0 || ((uintptr_t)ps[i] & 3) != 0) {          // odd shapes: the plain path, one launch each
+      hipError_t e = cnrma_fill_bytes(p1, b1, n1, st);
+      if (e == hipSuccess) e = cnrma_fill_bytes(p2, b2, n2, st);
+      if (e == hipSuccess) e = cnrma_fill_bytes(p3, b3, n3, st);
+      return e;
+    }
+    const uint32_t b = (uint32_t)(bs[i] & 0xFF);
+    size_t blocks = ns[i] ? (ns[i] / 16 + 255) / 256 : 0;
+    blocks = ns[i] && blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    r[i] = FillRegion{reinterpret_cast<uint32_t*>(ps[i]), b | (b << 8) | (b << 16) | (b << 24), ns[i] / 4, total, (unsigned)blocks};
+    total += (unsigned)blocks;
+  }
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(cnrma_fill3_kernel<0>, dim3(total), dim3(256), 0, st, r[0], r[1], r[2]);
+  return hipGetLastError();
+}
+
 // live row count of a device-counted tensor: min(capacity, *n_dev) (n_dev may be NULL)
 __device__ __forceinline__ int64_t live_rows(int64_t cap, const int32_t* n_dev) {
   if (n_dev == nullptr) return cap;

@@ -219,13 +219,10 @@ int run_unique(const void* src, int64_t n_cap, const int32_t* n_dev, float vs, i
   if (out_cap <= 0 || out_cap > n_cap) out_cap = n_cap;
   if (n_cap <= 0 || cap < 2 || (cap & (cap - 1)) != 0 || cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
   UniqueWs w = carve_unique_ws(workspace, n_cap);
-  hipError_t e = cnrma_fill_bytes(keys, 0xFF, (size_t)cap * sizeof(uint64_t), st);
-  if (e != hipSuccess) return -(int)e;
-  e = cnrma_fill_bytes(vals, 0x7F, (size_t)cap * sizeof(int32_t), st);
+  hipError_t e = cnrma_fill_bytes3(keys, 0xFF, (size_t)cap * sizeof(uint64_t), vals, 0x7F, (size_t)cap * sizeof(int32_t),
+                                   w.range_err, 0, 4, st);                      // one launch instead of three
   if (e != hipSuccess) return -(int)e;
   const unsigned nb = (unsigned)ceil_div(n_cap, 256);
-  e = cnrma_fill_bytes(w.range_err, 0, 4, st);
-  if (e != hipSuccess) return -(int)e;
   hipLaunchKernelGGL((uniq_insert_kernel<MODE>), dim3(nb), dim3(256), 0, st, src, n_cap, n_dev, vs, new_stride,
                      batch_id, keys, vals, cap, w.slot, w.range_err);
   hipLaunchKernelGGL(uniq_flag_kernel, dim3(nb), dim3(256), 0, st, n_cap, n_dev, vals, w.slot, w.flag);
