@@ -83,6 +83,7 @@ def parse():
                          "written per scene -- instead of pipeline.StaticScene directly")
     ap.add_argument("--plugin-static", type=int, default=1, help="--through-plugin only: 0 = force the detector's eager path "
                     "(what the reference's default numpy point sampler takes)")
+    ap.add_argument("--dense-branch", type=int, default=0, help="A/B aid: 1 = the dense kernel as a parallel branch of the scene graph")
     ap.add_argument("--pace", type=int, default=1, help="1 = the host waits for a slot's previous scene before refilling it "
                     "(what a caller that consumes the detections does anyway; +1 %% over enqueueing blindly), 0 = enqueue as fast as possible")
     ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
@@ -671,6 +672,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.dense_branch:
+        from cnrma_amd import pipeline as _pl
+        _pl.DENSE_BRANCH = True
     if args.dense_tuning:
         from cnrma_amd import rma
         rma.dense_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.dense_tuning.split(","))})

@@ -15,6 +15,11 @@ from . import plan as P
 from . import sparse as S
 
 
+DENSE_BRANCH = False     # StaticScene: the dense unprojection as a parallel branch of the scene graph (fork / join inside the
+                         # capture).  Measured (bench.py --dense-branch 1): NS 40.8 vs 43.0 scenes/s, S 163 vs 202 -- a graph with a
+                         # second stream in it replays slower than the linear chain, and the chip-filling kernel gains nothing
+
+
 class SceneConfig:
     def __init__(self, dims, voxel_size=0.04, origin=(0.0, 0.0, 0.0), stride=4, n_steps=300, thr=0.05,
                  max_points=500000, voxel_size_fcaf3d=0.01, ray_marching_type="neus", depth_points=None,
@@ -315,9 +320,20 @@ class StaticScene:
         plan.begin_static()
         out = {}
         with P.using(plan), torch.no_grad():
+            side = None
             if self.dense:
-                out["volume"], out["count"] = rma.backproject_accum(self.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin,
-                                                                    cfg.stride, proj_scaled=self.proj_scaled)
+                # the dense volume is an output of the scene (the Atlas 3D network's input), nothing downstream in the hot path
+                # reads it: DENSE_BRANCH runs it as a parallel branch of the graph (forked stream, joined at the end) -- off
+                # by default, see the note at the switch
+                main = torch.cuda.current_stream(self.device)
+                if DENSE_BRANCH:
+                    if getattr(self, "_side", None) is None:
+                        self._side = torch.cuda.Stream(device=self.device)
+                    side = self._side
+                    side.wait_stream(main)
+                with torch.cuda.stream(side if side is not None else main):
+                    out["volume"], out["count"] = rma.backproject_accum(self.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin,
+                                                                        cfg.stride, proj_scaled=self.proj_scaled)
             fixed = cfg.sample_seed is not None          # a fixed seed: every replay draws the same subset (as forward_scene)
             coords, feats, n_sel, info = rma.aggregate_points_static(
                 self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
@@ -330,6 +346,8 @@ class StaticScene:
                                  extra_counts=[info["M"], n_sel]))
             if not fixed:
                 self.seed_dev.add_(1)            # the next replay draws a fresh point subset
+            if side is not None:
+                torch.cuda.current_stream(self.device).wait_stream(side)          # join
         plan.end_static()
         out.update(points=(coords, feats, n_sel))
         return out
