@@ -86,6 +86,10 @@ def parse():
     ap.add_argument("--dense-branch", type=int, default=0, help="A/B aid: 1 = the dense kernel as a parallel branch of the scene graph")
     ap.add_argument("--pace", type=int, default=1, help="1 = the host waits for a slot's previous scene before refilling it "
                     "(what a caller that consumes the detections does anyway; +1 %% over enqueueing blindly), 0 = enqueue as fast as possible")
+    ap.add_argument("--feature-layout", default="channels_last", choices=["channels_last", "nchw"],
+                    help="memory layout of the resident feature maps [V,C,H,W]: channels_last (default) = what the plugin's 2D stack "
+                         "hands over (MultiViewBase.channels_last_2d: the 2D network runs in torch.channels_last), read in place; "
+                         "nchw = the reference's layout, converted by the layout pass inside the timed path")
     ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
                     "'variant=0' = the round-2 kernel (cnrma_debug_dense_tuning; never set by the driver)")
     return ap.parse_args()
@@ -303,17 +307,19 @@ def cpu_baseline(shape_name, Ms_full, C):
 class Workload:
     """>= n_scenes distinct synthetic scenes of one shape resident in HBM + `slots` captured scene graphs"""
 
-    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6, plugin=False):
+    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6, plugin=False, layout=None):
         import torch
         self.plugin = plugin
+        self.layout = layout or args.feature_layout
         from cnrma_amd import pipeline, synth
         self.torch, self.pipeline = torch, pipeline
         self.name, self.device, self.rank, self.world, self.args = name, device, rank, world, args
         self.V, self.C, self.H, self.W, self.dims, self.stride = synth.SHAPES[name]
         self.scenes = []
         for i in range(args.scenes):
-            sc = synth.make_scene(name, seed=1000 * rank + i, boxes=2 + i % 4, device=device)
-            self.scenes.append(dict(features=sc["features"][:, 0].contiguous(), projection=sc["projection"][:, 0],
+            sc = synth.make_scene(name, seed=1000 * rank + i, boxes=2 + i % 4, device=device, channels_last=self.layout == "channels_last")
+            f = sc["features"][:, 0]                       # [V,C,H,W]; channels_last: a permuted view of a [V,H,W,C] block
+            self.scenes.append(dict(features=f if self.layout == "channels_last" else f.contiguous(), projection=sc["projection"][:, 0],
                                     tsdf=sc["tsdf"][0, 0].to(device)))
         self.input_bytes = sum(s["features"].numel() * 4 + s["tsdf"].numel() * 4 for s in self.scenes)
         if plugin:
@@ -339,16 +345,21 @@ class Workload:
         cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
         m = dict(cfg["model"])
         self.save_dir = tempfile.mkdtemp(prefix="cnrma_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        # the config's model section as shipped (max_points, point sampler, graph path: its defaults); only what defines the
+        # measured hot path is replaced: the 2D / Atlas 3D networks are not built (their OUTPUTS are the resident inputs, SURVEY
+        # 8d), the grid and the stride are the workload's, the result files go to tmpfs
         m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None, save_path=self.save_dir,
-                 voxel_dim_test=list(self.dims), voxel_dim_train=list(self.dims), backbone2d_stride=self.stride,
-                 max_points=500000, point_sampler="device", static_slots=self.args.slots, static_calibration=self.args.scenes,
-                 static_test=bool(self.args.plugin_static))
+                 voxel_dim_test=list(self.dims), voxel_dim_train=list(self.dims), backbone2d_stride=self.stride)
         m["detection_backbone"] = dict(type="FCAF3DBackbone", in_channels=self.C, depth=34)
         torch.manual_seed(0)
         model = build_detector(m)
         model.detection_backbone.init_weights()
         model.detection_head.init_weights()
         self.model = model.to(self.device).eval()
+        # runtime attributes, not constructor keywords: slots in flight as the rest of the bench, every resident scene calibrates
+        self.model.static_slots, self.model.static_calibration = self.args.slots, self.args.scenes
+        if not self.args.plugin_static:
+            self.model.static_test = False
         self.backbone, self.head = self.model.detection_backbone, self.model.detection_head
 
     def _plugin_scene(self, s):
@@ -528,7 +539,7 @@ def time_windows(wl, args, world, barrier):
         for _ in range(2):                                               # warm passes at the final wave size
             wl.step()
     barrier()
-    secs = []
+    secs, per_rank = [], []
     for _ in range(max(1, args.windows)):
         barrier()
         t0 = time.perf_counter()
@@ -539,14 +550,17 @@ def time_windows(wl, args, world, barrier):
         dt = time.perf_counter() - t0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64, device=wl.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            mine = torch.tensor([dt], dtype=torch.float64, device=wl.device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)                                 # each rank's own clock around the same K steps
+            per_rank.append([float(x.item()) for x in every])
+            dt = max(per_rank[-1])                                       # MAX over ranks
         secs.append(dt)
+    wl.per_rank_window_s = per_rank
     return sps, secs
 
 
-def measure(name, device, rank, world, args, barrier, precision=None, plugin=False):
+def measure(name, device, rank, world, args, barrier, precision=None, plugin=False, layout=None):
     """build + time one workload; returns the result block"""
     import torch
     from cnrma_amd import sparse as S
@@ -555,7 +569,7 @@ def measure(name, device, rank, world, args, barrier, precision=None, plugin=Fal
         S.CONV_PRECISION = precision
     try:
         log(f"workload {name}{' (' + precision + ' conv)' if precision else ''}: generating {args.scenes} scenes")
-        wl = Workload(name, device, rank, world, args, plugin=plugin)
+        wl = Workload(name, device, rank, world, args, plugin=plugin, layout=layout)
         log("calibrating + capturing the scene graphs")
         wl.build()
         log("timing")
@@ -569,6 +583,10 @@ def measure(name, device, rank, world, args, barrier, precision=None, plugin=Fal
                      window_s=med, plan_violations=bad, distinct_scenes=len(wl.scenes), input_GB=wl.input_bytes / 1e9,
                      host_cpu_cores_busy=round(((c1.user - c0.user) + (c1.system - c0.system)) / max(sum(secs), 1e-9), 2))
         block.update(wl.sizes())
+        if world > 1:
+            block["per_rank_window_s"] = wl.per_rank_window_s            # [window][rank]: what every rank's clock saw
+        n_nodes = getattr(wl.slots[0], "n_nodes", None) if wl.slots else None
+        block["graph_nodes_per_scene"] = n_nodes
         log(f"{name}: {block['value']:.1f} scenes/s, {block['ms_per_scene']:.2f} ms/scene, windows "
             f"{[round(x, 1) for x in block['windows_scenes_per_s']]}, {sps} scenes/step, violations {bad}")
         return wl, block
@@ -686,9 +704,13 @@ def main():
         "value": main_block["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (sparse convolutions f16x3: 22-bit operands, fp32 accumulate; block f32_conv = exact fp32)", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}, NCHW fp32 as the 2D "
-                               f"backbone writes them; the layout pass to channels-last is inside the timed path), grid "
-                               f"{dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000 (device sampler: "
+        "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}, fp32 [V,C,H,W], " +
+                               ("channels-last in memory -- what the plugin's 2D stack, run in torch.channels_last, hands over "
+                                "(MultiViewBase.channels_last_2d) --, read in place by reference; block `nchw_input` = the same maps "
+                                "handed over NCHW, layout pass inside the timed path" if wl.layout == "channels_last" else
+                                "NCHW as the reference's 2D backbone writes them; the layout pass to channels-last is inside the timed "
+                                "path") +
+                               f"), grid {dims[0]}x{dims[1]}x{dims[2]} @0.04m, N=300 steps, thr=0.05, max_points=500000 (device sampler: "
                                f"a uniformly random subset like np.random.choice, other random stream), FCAF3D MinkResNet34 + "
                                f"head (18 classes); {main_block['distinct_scenes']} distinct scenes per GPU rotated "
                                f"({main_block['input_GB']:.1f} GB of inputs), one HIP graph per scene, {len(wl.slots) or 1} in flight",
@@ -699,8 +721,15 @@ def main():
                                  "`f32_conv` = the same run with exact-fp32 MFMA convolutions",
                    "host_cores": os.cpu_count()},
     }
-    for k in ("scenes_per_step", "ms_per_scene", "windows_scenes_per_s", "window_s", "plan_violations", "host_cpu_cores_busy"):
+    for k in ("scenes_per_step", "ms_per_scene", "windows_scenes_per_s", "window_s", "plan_violations", "host_cpu_cores_busy",
+              "graph_nodes_per_scene"):
         result[k] = main_block[k]
+    result["feature_layout"] = wl.layout
+    if world > 1:
+        # what the process group itself reports (a SCALE run can verify that N ranks took part over RCCL) + every rank's own
+        # clock around each window (value uses the MAX over ranks)
+        result["dist"] = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), rank=dist.get_rank(),
+                              per_rank_window_s=main_block.get("per_rank_window_s"))
     for k in ("M_rows", "M_selected", "M_unique", "level_rows", "head_rows"):
         result["config"][k] = main_block[k]
 
@@ -710,6 +739,7 @@ def main():
         for k in ("kernels", "stage_ms", "conv", "conv_layers", "algorithmic_GB_per_scene", "whole_path_hbm"):
             result[k] = main_block[k]
     Ms_full = main_block["M_selected"]
+    main_layout = wl.layout
     del wl
     torch.cuda.empty_cache()
 
@@ -722,9 +752,12 @@ def main():
         result["through_plugin"] = {k: bp[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step",
                                                         "windows_scenes_per_s", "plan_violations", "host_cpu_cores_busy")}
         result["through_plugin"]["ratio_to_value"] = bp["value"] / main_block["value"]
-        result["through_plugin"]["note"] = ("the same workload through projects.mvsdetection RayMarching: model(return_loss=False, "
-                                            "features=[..], projection=[..], tsdf=.., offset=[..], scene=[..]) per scene, "
-                                            "{scene}_bbox_raw.npz written per scene (tmpfs), model.flush() inside the window")
+        result["through_plugin"]["note"] = ("the same workload through projects.mvsdetection RayMarching built from "
+                                            "projects/configs/mvsdetection/ray_marching_scannet.py's model section (no sampler / "
+                                            "graph-path keywords; 2D + Atlas networks not built: their outputs are the inputs; grid "
+                                            "and stride of the workload): model(return_loss=False, features=[..], projection=[..], "
+                                            "tsdf=.., offset=[..], scene=[..]) per scene, {scene}_bbox_raw.npz written per scene "
+                                            "by the writer thread (tmpfs), model.flush() inside the window")
         import shutil
         shutil.rmtree(wlp.save_dir, ignore_errors=True)
         del wlp
@@ -735,8 +768,19 @@ def main():
         result["f32_conv"] = {k: b32[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step", "windows_scenes_per_s",
                                                   "plan_violations")}
         result["f32_conv"]["note"] = "CONV_PRECISION='f32': v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain"
+        # first-class: the same workload at the reference's own arithmetic (exact fp32 products in the sparse convolutions)
+        result["value_f32_conv"] = b32["value"]
         del wl32
         torch.cuda.empty_cache()
+        if main_layout == "channels_last":
+            # ---- the same workload with the maps handed over NCHW (the reference's layout): layout pass inside the timed path
+            wln, bn = measure(args.workload, device, rank, world, args, barrier, layout="nchw")
+            result["nchw_input"] = {k: bn[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step", "windows_scenes_per_s",
+                                                       "plan_violations")}
+            result["nchw_input"]["note"] = ("feature maps resident as NCHW [V,C,H,W]: cnrma_nchw_to_nhwc_march_f32 (layout pass + march in "
+                                            "one launch) runs per scene inside the timed region")
+            del wln
+            torch.cuda.empty_cache()
         if args.workload != "S":
             wls, bs = measure("S", device, rank, world, args, barrier)
             if rank == 0 and not args.no_profile:

@@ -17,6 +17,7 @@ SIGNATURES = {
     "cnrma_abi_version": (c_int, []),
     "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
     "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
+    "cnrma_backproject_accum_ref_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
     "cnrma_debug_dense_tuning": (c_int, [P, I]),
     "cnrma_backproject_backward_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, P, P]),
     "cnrma_backproject_index_f32": (c_int, [P, I, I, I, I, I, F, F, F, F, P, P, P, P]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "cnrma_rma_neus_march_f32": (c_int, [P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
     "cnrma_nchw_to_nhwc_march_f32": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
     "cnrma_rma_neus_emit_rows_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, P, I, P, L, P, P, F, F, F, P, I, P, I, P, I, P, P]),
+    "cnrma_rma_neus_emit_rows_ref_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, P, I, P, L, P, P, F, F, F, P, I, P, I, P, I, P, P]),
     "cnrma_sample_workspace_bytes": (c_size_t, []),
     "cnrma_sample_mask": (c_int, [P, L, I, ctypes.c_uint32, P, P, P, P]),
     "cnrma_topk_mask_f32": (c_int, [P, P, L, I, P, P, P]),
@@ -51,6 +53,8 @@ SIGNATURES = {
     "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, P]),
     "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, P]),
     "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
+    "cnrma_sparse_conv_plan": (c_int, [L, I, I, I, I, I, c_size_t, P]),
+    "cnrma_debug_conv_tuning": (c_int, [P, I]),
     "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_conv_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights": (c_int, [P, I, I, I, P, P]),

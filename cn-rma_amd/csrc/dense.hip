@@ -403,12 +403,16 @@ __device__ __forceinline__ void accum_block(const DenseParams& p, const float* _
 }
 
 template <int LPV, int PIPE, int EPI, int LOCK>
-__global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe_kernel(DenseParams p, const float* __restrict__ feat,
+__global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe_kernel(DenseParams p, const float* feat,
                                                                      const float* __restrict__ proj,
                                                                      float* __restrict__ volume,
                                                                      int32_t* __restrict__ count, int chunk_blocks,
                                                                      int64_t n_phys, SlabOrder ord,
-                                                                     unsigned int* __restrict__ bar) {
+                                                                     unsigned int* __restrict__ bar,
+                                                                     const float* const* __restrict__ feat_ref) {
+  // feat_ref != NULL: the feature maps are handed over BY REFERENCE -- a device word holds their address (one scalar load);
+  // a captured launch sequence can then read whatever tensor the producer wrote, with no copy into a static buffer
+  if (feat_ref != nullptr) feat = *feat_ref;
   __shared__ float lds[EPI ? 4 * (4 * LPV) * 65 : 1];
   float* lds_wave = lds + (EPI ? (threadIdx.x >> 6) * (4 * LPV) * 65 : 0);
   if constexpr (LOCK != 0) {
@@ -614,8 +618,9 @@ static DenseTune g_tune;
 
 template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
-                      unsigned int* bar, hipStream_t st) {
+                      unsigned int* bar, hipStream_t st, const float* const* feat_ref = nullptr) {
   const DenseTune t = g_tune;
+  if (feat_ref != nullptr && t.variant != 1) return CNRMA_EINVAL;      // by-reference hand-off: the product kernel only
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   int64_t nb = ceil_div(G, 256);
   // one chunk = the blocks of one x-plane (at least 32: keeps a group's L2 working set a compact slab piece)
@@ -663,10 +668,10 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   do {                                                                                                                     \
     if (lock)                                                                                                              \
       hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 1>), grid, dim3(256), 0, st, p, feat, proj, volume, \
-                         count, (int)cb, gx, ord, bar);                                                                    \
+                         count, (int)cb, gx, ord, bar, feat_ref);                                                          \
     else                                                                                                                   \
       hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, PIPE, EPI, 0>), grid, dim3(256), (size_t)t.ldspad * 1024, st, p,  \
-                         feat, proj, volume, count, (int)cb, gx, ord, bar);                                               \
+                         feat, proj, volume, count, (int)cb, gx, ord, bar, feat_ref);                                     \
   } while (0)
   if (t.pipe == 2) { if (t.epi) CNRMA_DENSE_LAUNCH(2, 1); else CNRMA_DENSE_LAUNCH(2, 0); }
   else             { if (t.epi) CNRMA_DENSE_LAUNCH(1, 1); else CNRMA_DENSE_LAUNCH(1, 0); }
@@ -713,22 +718,40 @@ extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
   return 0;
 }
 
-extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
-                                           int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
-                                           float* volume, int32_t* count, void* workspace, int64_t workspace_bytes,
-                                           void* stream) {
+static int backproject_accum_any(const float* feat_nhwc, const float* const* feat_ref, const float* proj, int V, int C, int H,
+                                 int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz, float* volume,
+                                 int32_t* count, void* workspace, int64_t workspace_bytes, void* stream) {
   if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
   DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
   hipStream_t st = as_stream(stream);
   unsigned int* bar = (workspace != nullptr && workspace_bytes >= CNRMA_DENSE_WORKSPACE_BYTES) ? static_cast<unsigned int*>(workspace) : nullptr;
   const int l = g_tune.lpv;
-  if (l == 16 && C % 64 == 0) return launch_accum_coop<16>(p, feat_nhwc, proj, volume, count, bar, st);
-  if (l == 4 && C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st);
-  if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, bar, st);
-  if (C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st);
-  if (C % 8 == 0) return launch_accum_coop<2>(p, feat_nhwc, proj, volume, count, bar, st);
-  if (C % 4 == 0) return launch_accum_coop<1>(p, feat_nhwc, proj, volume, count, bar, st);
+  if (l == 16 && C % 64 == 0) return launch_accum_coop<16>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
+  if (l == 4 && C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
+  if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
+  if (C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
+  if (C % 8 == 0) return launch_accum_coop<2>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
+  if (C % 4 == 0) return launch_accum_coop<1>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
+  if (feat_ref != nullptr) return CNRMA_EINVAL;
   return launch_accum<1>(p, feat_nhwc, proj, volume, count, st);
+}
+
+extern "C" int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
+                                           int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                           float* volume, int32_t* count, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
+  if (feat_nhwc == nullptr) return CNRMA_EINVAL;
+  return backproject_accum_any(feat_nhwc, nullptr, proj, V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz, volume, count, workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int cnrma_backproject_accum_ref_f32(const float* const* feat_nhwc_ref, const float* proj, int V, int C, int H, int W,
+                                               int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                               float* volume, int32_t* count, void* workspace, int64_t workspace_bytes,
+                                               void* stream) {
+  if (feat_nhwc_ref == nullptr || C % 4 != 0) return CNRMA_EINVAL;
+  return backproject_accum_any(nullptr, feat_nhwc_ref, proj, V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz, volume, count,
+                               workspace, workspace_bytes, stream);
 }
 
 // Backward of the accumulate + mean w.r.t. the feature maps (training): volume[c][g] = sum_v feat[v][pix_v(g)][c] / count[g],

@@ -382,9 +382,10 @@ __global__ __launch_bounds__(256) void neus_scatter_records_kernel(int64_t R, co
 
 template <int LPR>
 __global__ __launch_bounds__(256) void neus_emit_rows_kernel(MarchParams p, int C, const float* __restrict__ proj_inv,
-                                                            const float* __restrict__ feat, int64_t n_rows,
-                                                            const int32_t* __restrict__ n_rows_dev,
+                                                            const float* feat, const float* const* __restrict__ feat_ref,
+                                                            int64_t n_rows, const int32_t* __restrict__ n_rows_dev,
                                                             const int4* __restrict__ rec, EmitDst dst) {
+  if (feat_ref != nullptr) feat = *feat_ref;         // feature maps handed over by reference (see cnrma_backproject_accum_ref_f32)
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t j = t / LPR;
   const int sub = (int)(t % LPR);
@@ -691,14 +692,15 @@ extern "C" int cnrma_nchw_to_nhwc_march_f32(const float* feat_nchw, float* feat_
   return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, feat_nchw, feat_nhwc, C, as_stream(stream));
 }
 
-extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
+static int neus_emit_rows_any(const float* proj_inv, const float* feat_nhwc, const float* const* feat_ref, int V, int C, int H, int W,
                                             int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
                                             const int32_t* n_out_dev, const void* kept, int cap,
                                             const int32_t* sel_index, int64_t sel_cap, void* records,
                                             const float* w_div, float addx, float addy, float addz, float* out_xyz,
                                             int xyz_stride, float* out_w, int w_stride, float* out_feat,
                                             int feat_stride, int32_t* out_sample, void* stream) {
-  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || n_out <= 0 || kept == nullptr || cap <= 0 || records == nullptr)
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || n_out <= 0 || kept == nullptr || cap <= 0 || records == nullptr ||
+      (feat_nhwc == nullptr && feat_ref == nullptr && out_feat != nullptr))
     return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, 1, 1, 1, 1.0f, 0.f, 0.f, 0.f, n_steps, t_one, 0.0f);
   EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, out_sample, nullptr, w_div, addx, addy, addz};
@@ -709,16 +711,41 @@ extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* 
                      reinterpret_cast<const int2*>(kept), cap, sel_index, sel_cap, n_out, rec);
   if (C % 256 == 0) {      // one wave copies a row's 1-KiB channel vector per instruction
     hipLaunchKernelGGL((neus_emit_rows_kernel<64>), dim3((unsigned)ceil_div(n_out * 64, 256)), dim3(256), 0, st, p, C,
-                       proj_inv, feat_nhwc, n_out, n_out_dev, rec, d);
+                       proj_inv, feat_nhwc, feat_ref, n_out, n_out_dev, rec, d);
   } else if (C % 32 == 0) {
     hipLaunchKernelGGL((neus_emit_rows_kernel<8>), dim3((unsigned)ceil_div(n_out * 8, 256)), dim3(256), 0, st, p, C,
-                       proj_inv, feat_nhwc, n_out, n_out_dev, rec, d);
+                       proj_inv, feat_nhwc, feat_ref, n_out, n_out_dev, rec, d);
   } else {
     hipLaunchKernelGGL((neus_emit_rows_kernel<2>), dim3((unsigned)ceil_div(n_out * 2, 256)), dim3(256), 0, st, p, C,
-                       proj_inv, feat_nhwc, n_out, n_out_dev, rec, d);
+                       proj_inv, feat_nhwc, feat_ref, n_out, n_out_dev, rec, d);
   }
   CNRMA_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
+                                            int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
+                                            const int32_t* n_out_dev, const void* kept, int cap,
+                                            const int32_t* sel_index, int64_t sel_cap, void* records,
+                                            const float* w_div, float addx, float addy, float addz, float* out_xyz,
+                                            int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                                            int feat_stride, int32_t* out_sample, void* stream) {
+  return neus_emit_rows_any(proj_inv, feat_nhwc, nullptr, V, C, H, W, n_steps, t_one, row_offset, n_out, n_out_dev, kept, cap,
+                            sel_index, sel_cap, records, w_div, addx, addy, addz, out_xyz, xyz_stride, out_w, w_stride, out_feat,
+                            feat_stride, out_sample, stream);
+}
+
+extern "C" int cnrma_rma_neus_emit_rows_ref_f32(const float* proj_inv, const float* const* feat_nhwc_ref, int V, int C, int H,
+                                                int W, int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
+                                                const int32_t* n_out_dev, const void* kept, int cap,
+                                                const int32_t* sel_index, int64_t sel_cap, void* records,
+                                                const float* w_div, float addx, float addy, float addz, float* out_xyz,
+                                                int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                                                int feat_stride, int32_t* out_sample, void* stream) {
+  if (feat_nhwc_ref == nullptr) return CNRMA_EINVAL;
+  return neus_emit_rows_any(proj_inv, nullptr, feat_nhwc_ref, V, C, H, W, n_steps, t_one, row_offset, n_out, n_out_dev, kept, cap,
+                            sel_index, sel_cap, records, w_div, addx, addy, addz, out_xyz, xyz_stride, out_w, w_stride, out_feat,
+                            feat_stride, out_sample, stream);
 }
 
 // Backward of the emission w.r.t. the feature maps (the only differentiable input: the weights are computed under

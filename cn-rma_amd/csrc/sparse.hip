@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) void kernel_map_strided_kernel(const int32_t* 
 // ================================================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
+constexpr int64_t CONV_PF2_ROWS = 0;      // output capacities below this run the two-stage prefetch variant (0: off until measured)
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == 1) return v > 0.0f ? v : 0.0f;
@@ -386,6 +387,8 @@ struct ConvArgs {
   // pair-list mode (cnrma_sparse_conv_pairs_f16x3): the rows are (output, input) pairs grouped by kernel offset in runs
   // padded to 128 rows; tile_tap[row / 128] = the offset whose weights the run uses, w_taps = offsets in the image
   const int32_t* tile_tap; int w_taps;
+  int ablate;        // diagnostic kernels only (ABL = true; cnrma_debug_conv_tuning): bit 0 no MFMAs, 1 no A loads, 2 no B loads,
+                     // 3 no LDS stores, 4 no barriers -- after the first stage; results are then meaningless, only the time counts
 };
 
 // exact 3-way split by truncation: h = top 8 significant bits of a, m = next 8, l = last 8 (a == h + m + l)
@@ -750,7 +753,27 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ i
 // bounds check and no select
 __host__ __device__ inline int conv_cout_padded(int Cout) { return (Cout + 127) & ~127; }
 
-// W fp32 [K][Cin][Cout] -> Wt fp16 [2 planes][K][Cout_p][Cin] scaled by f16_scale_for(*amax), + trailer float = *amax
+// element t of a prepared weight image -> (offset k, output column co, input channel cin).  Image order per plane:
+// [K][Cin / 32][Cout_p][32] -- the 32-channel slice of ALL columns of one offset is contiguous (Cin % 32 == 0: the only
+// case the MFMA kernels take; other channel counts keep the plain [K][Cout_p][Cin] order and are never read)
+__device__ __forceinline__ void weight_image_coords(int64_t t, int Cin, int Cp, int* k, int* co, int* cin) {
+  if ((Cin & (BK - 1)) == 0) {
+    const int c32 = (int)(t & (BK - 1));
+    const int64_t q = t / BK;
+    *co = (int)(q % Cp);
+    const int64_t q2 = q / Cp;
+    const int ns = Cin / BK;
+    *cin = (int)(q2 % ns) * BK + c32;
+    *k = (int)(q2 / ns);
+  } else {
+    *cin = (int)(t % Cin);
+    const int64_t q = t / Cin;
+    *co = (int)(q % Cp);
+    *k = (int)(q / Cp);
+  }
+}
+
+// W fp32 [K][Cin][Cout] -> Wt fp16 [2 planes][K][Cin/32][Cout_p][32] scaled by f16_scale_for(*amax), + trailer float = *amax
 __global__ __launch_bounds__(256) void prep_weights_f16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int K,
                                                                int Cin, int Cout, const float* __restrict__ amax) {
   const int Cp = conv_cout_padded(Cout);
@@ -759,10 +782,8 @@ __global__ __launch_bounds__(256) void prep_weights_f16_kernel(const float* __re
   const float sc = f16_scale_for(am);
   if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(wt + 2 * total) = am;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int cin = (int)(t % Cin);
-    const int64_t q = t / Cin;
-    const int co = (int)(q % Cp);
-    const int k = (int)(q / Cp);
+    int cin, co, k;
+    weight_image_coords(t, Cin, Cp, &k, &co, &cin);
     uint16_t hh, mm;
     split2_f16(co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] * sc : 0.0f, hh, mm);
     wt[t] = hh;
@@ -793,16 +814,14 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float* __rest
   q[2] = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
 
-// W fp32 [K][Cin][Cout] -> Wt bf16 [3 planes][K][Cout][Cin]
+// W fp32 [K][Cin][Cout] -> Wt bf16 [3 planes][K][Cin/32][Cout_p][32]
 __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
                                                            int Cin, int Cout) {
   const int Cp = conv_cout_padded(Cout);
   const int64_t total = (int64_t)K * Cin * Cp;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int cin = (int)(t % Cin);
-    const int64_t q = t / Cin;
-    const int co = (int)(q % Cp);
-    const int k = (int)(q / Cp);
+    int cin, co, k;
+    weight_image_coords(t, Cin, Cp, &k, &co, &cin);
     const float a = co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] : 0.0f;
     uint16_t hh, mm, ll;
     split3_trunc(a, hh, mm, ll);
@@ -813,16 +832,14 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
   }
 }
 
-// W fp32 [K][Cin][Cout] -> Wt bf16 [K][Cout_p][Cin], round to nearest (MODE 2)
+// W fp32 [K][Cin][Cout] -> Wt bf16 [K][Cin/32][Cout_p][32], round to nearest (MODE 2)
 __global__ __launch_bounds__(256) void prep_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
                                                                 int Cin, int Cout) {
   const int Cp = conv_cout_padded(Cout);
   const int64_t total = (int64_t)K * Cin * Cp;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int cin = (int)(t % Cin);
-    const int64_t q = t / Cin;
-    const int co = (int)(q % Cp);
-    const int k = (int)(q / Cp);
+    int cin, co, k;
+    weight_image_coords(t, Cin, Cp, &k, &co, &cin);
     wt[t] = (__bf16)(co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] : 0.0f);
   }
 }
@@ -909,7 +926,11 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
 
 // MODE 0 = bf16x6 (3 planes, 6 products), MODE 1 = f16x3 (2 planes, 3 products, power-of-two operand scales),
 // MODE 2 = bf16 (1 plane, 1 product: the autocast training precision -- bf16 operands, fp32 accumulation)
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT, int MODE>
+// PF = global-load stages in flight beyond the one being multiplied: 1 = the loads of stage s + 1 fly during the MFMAs of
+// stage s (every variant); 2 = two register sets, stages s + 1 and s + 2 in flight (short layers: a block of a < 16 k-row
+// layer walks a chain of 16-48 stages with at most 3 blocks per CU -- each stage then costs one whole L2 round trip,
+// not its 384 MFMA cycles; the second set costs 24-32 registers, irrelevant at that occupancy)
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, bool IN_SPLIT, int MODE, int PF = 1, bool ABL = false>
 __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   constexpr int NP = MODE == 0 ? 3 : (MODE == 1 ? 2 : 1);
@@ -953,9 +974,10 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
     __syncthreads();
     unsigned local = 0;
     const int32_t* nb = p.nbr + tile0 * K;
-    for (int i = tid; i < rows_here * K; i += 256) {
-      const int k = i % K;
-      if (k >= k_lo && k < k_hi && nb[i] >= 0) local |= 1u << k;
+    const int kr = k_hi - k_lo;                  // only this block's offsets are looked at (a split block owns 2-3 of 27)
+    for (int i = tid; i < rows_here * kr; i += 256) {
+      const int row = i / kr, k = k_lo + (i - row * kr);
+      if (nb[row * K + k] >= 0) local |= 1u << k;
     }
     if (local) atomicOr(&mask_s, local);
     __syncthreads();
@@ -982,53 +1004,40 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-  AStageRegs<IN_SPLIT, A_ITERS> areg;
+  typedef AStageRegs<IN_SPLIT, A_ITERS> ARegs;
+  ARegs areg;
   u32x4_t rb[B_ITERS];                            // first-class vectors (HIP's uint4 struct arrays end up in scratch)
   const int G8 = Cin >> 3;
   const float* in_f32 = p.in;
   const uint16_t* in_sp = p.in_split;
   const int64_t in_zero = p.in_zero_row;
-  auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
-    areg.load(in_f32, in_sp, in_zero, tid, srcs, cin0, G8, Cin);
-    const __bf16* Wk = Wz + (int64_t)k * Cout_p * Cin + cin0;
+  auto load_stage = [&](ARegs& ar, u32x4_t* br, int k, int cin0, const int32_t* srcs, int skip = 0) {
+    if (!ABL || !(skip & 2)) ar.load(in_f32, in_sp, in_zero, tid, srcs, cin0, G8, Cin);
+    if (ABL && (skip & 4)) return;
+    // image order [offset][32-channel slice][output column][32]: the B tile of a stage is ONE contiguous run of whole
+    // 128-byte lines (with [offset][column][Cin] every stage fetched the 64-byte half of a line and left the other half
+    // to the next stage: the B operand moved twice through the L2 -> L1 path, which is what bounds this kernel)
+    const __bf16* Wk = Wz + ((int64_t)k * (Cin / BK) + cin0 / BK) * Cout_p * BK;
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       int idx = tid + i * 256;                         // over [plane][row][chunk]; the lane part is loop invariant
       idx = idx < B_CHUNKS ? idx : 0;
       const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
-      rb[i] = *reinterpret_cast<const u32x4_t*>(Wk + pl * plane_elems + (int64_t)(cout0 + row) * Cin + chunk * 8);
+      br[i] = *reinterpret_cast<const u32x4_t*>(Wk + pl * plane_elems + (int64_t)(cout0 + row) * BK + chunk * 8);
     }
   };
-  auto store_stage = [&]() {
-    areg.template store<MODE>(tid, &As[0][0], &As[1][0], &As[NP - 1][0], a_scale);
+  auto store_stage = [&](const ARegs& ar, const u32x4_t* br) {
+    ar.template store<MODE>(tid, &As[0][0], &As[1][0], &As[NP - 1][0], a_scale);
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i) {
       const int idx = tid + i * 256;
       if (idx < B_CHUNKS) {
         const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
-        *reinterpret_cast<u32x4_t*>(&Bs[pl][lds_slot(row, chunk)]) = rb[i];
+        *reinterpret_cast<u32x4_t*>(&Bs[pl][lds_slot(row, chunk)]) = br[i];
       }
     }
   };
-
-  auto next_active = [&](int k) { const unsigned rest = mask & ~((2u << k) - 1u); return rest ? __ffs(rest) - 1 : -1; };
-  int k = mask ? __ffs(mask) - 1 : -1;
-  int cin0 = 0;
-  load_src(k, src_cur);
-  load_src(k >= 0 ? next_active(k) : -1, src_nxt);
-  if (k >= 0) load_stage(k, 0, src_cur);
-  while (k >= 0) {
-    store_stage();
-    __syncthreads();
-    int nk = k, ncin = cin0 + BK;
-    if (ncin >= Cin) {
-      ncin = 0;
-      nk = next_active(k);
-#pragma unroll
-      for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
-      if (nk >= 0) load_src(next_active(nk), src_nxt);
-    }
-    if (nk >= 0) load_stage(nk, ncin, src_cur);
+  auto mfma_stage = [&]() {
     const int a_row = wr * (32 * TM) + (lane & 31), b_row = wc * (32 * TN) + (lane & 31), fhalf = lane >> 5;
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
@@ -1087,9 +1096,88 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
           }
       }
     }
-    __syncthreads();
-    k = nk;
-    cin0 = ncin;
+  };
+
+  auto next_active = [&](int k) { const unsigned rest = mask & ~((2u << k) - 1u); return rest ? __ffs(rest) - 1 : -1; };
+  int k = mask ? __ffs(mask) - 1 : -1;
+  int cin0 = 0;
+  load_src(k, src_cur);
+  load_src(k >= 0 ? next_active(k) : -1, src_nxt);
+  if constexpr (ABL) {
+    // diagnostic build of the PF = 1 loop: stage components switched off by p.ablate after the first stage
+    const int ab = p.ablate;
+    if (k >= 0) load_stage(areg, rb, k, 0, src_cur);
+    bool first = true;
+    while (k >= 0) {
+      if (first || !(ab & 8)) store_stage(areg, rb);
+      if (first || !(ab & 16)) __syncthreads();
+      int nk = k, ncin = cin0 + BK;
+      if (ncin >= Cin) {
+        ncin = 0;
+        nk = next_active(k);
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
+        if (nk >= 0) load_src(next_active(nk), src_nxt);
+      }
+      if (nk >= 0) load_stage(areg, rb, nk, ncin, src_cur, ab);
+      if (first || !(ab & 1)) mfma_stage();
+      if (first || !(ab & 16)) __syncthreads();
+      k = nk;
+      cin0 = ncin;
+      first = false;
+    }
+  } else if constexpr (PF == 1) {
+    if (k >= 0) load_stage(areg, rb, k, 0, src_cur);
+    while (k >= 0) {
+      store_stage(areg, rb);
+      __syncthreads();
+      int nk = k, ncin = cin0 + BK;
+      if (ncin >= Cin) {
+        ncin = 0;
+        nk = next_active(k);
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
+        if (nk >= 0) load_src(next_active(nk), src_nxt);
+      }
+      if (nk >= 0) load_stage(areg, rb, nk, ncin, src_cur);
+      mfma_stage();
+      __syncthreads();
+      k = nk;
+      cin0 = ncin;
+    }
+  } else {
+    // two register sets: while stage s is multiplied, the loads of s + 1 AND s + 2 are in flight.  (k, cin0) is the LOAD
+    // frontier here; the stages are multiplied in the order they were loaded.  Needs Cin >= 2 BK: the neighbour indices of
+    // an offset are fetched one offset ahead of the frontier, i.e. at least two stages before their gathers are issued.
+    ARegs areg2;
+    u32x4_t rb2[B_ITERS];
+    int todo = __popc(mask) * (Cin / BK);            // stages not yet multiplied
+    auto advance = [&]() {
+      cin0 += BK;
+      if (cin0 >= Cin) {
+        cin0 = 0;
+        k = next_active(k);
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
+        if (k >= 0) load_src(next_active(k), src_nxt);
+      }
+    };
+    if (k >= 0) { load_stage(areg, rb, k, cin0, src_cur); advance(); }
+    if (k >= 0) { load_stage(areg2, rb2, k, cin0, src_cur); advance(); }
+    while (todo > 0) {
+      store_stage(areg, rb);
+      __syncthreads();
+      if (k >= 0) { load_stage(areg, rb, k, cin0, src_cur); advance(); }
+      mfma_stage();
+      __syncthreads();
+      if (--todo == 0) break;
+      store_stage(areg2, rb2);
+      __syncthreads();
+      if (k >= 0) { load_stage(areg2, rb2, k, cin0, src_cur); advance(); }
+      mfma_stage();
+      __syncthreads();
+      --todo;
+    }
   }
 
   if (p.out_split && p.splits <= 1 && blockIdx.x == 0 && blockIdx.y == 0 && zs == 0) {
@@ -1208,6 +1296,54 @@ int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes
   return s < 2 ? 1 : s;
 }
 
+// Debug / A-B switches of the convolution launcher (cnrma_debug_conv_tuning: scripts/conv_sweep.py and the tests that force a
+// variant).  Product code never changes them; -1 = the launcher's own choice.
+struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; };
+static ConvTune g_conv_tune;
+
+enum ConvShape { T128x128, T128x64, T64x64, T128x32, T64x128, N_CONV_SHAPES };
+struct ConvPlan { int shape, bm, bn, splits, k_per_split, pf; };
+
+// tile shape, split count over the kernel offsets and prefetch depth of one launch: a pure function of the layer's
+// sizes (the CAPACITY of the output, not its live row count), so a captured launch sequence replays the same kernels
+ConvPlan plan_conv(int64_t no_cap, int Cin, int Cout, int K, int mode, bool six, int slices, bool has_ws, size_t ws_bytes) {
+  static const int bms[] = {128, 128, 64, 128, 64}, bns[] = {128, 64, 64, 32, 128};
+  // tile choice, measured per layer class and precision on MI355X at the ScanNet shape (see DESIGN.md): f16x3 tiles
+  // need fewer registers and less LDS (4-7 blocks per CU), which moves the optimum to 64-row tiles almost everywhere
+  int sh;
+  if (Cout <= 32) sh = T128x32;
+  else if (six && mode >= 1) {
+    if (Cout >= 128) sh = no_cap >= 16384 && no_cap < 40000 ? T128x128 : (no_cap < 1000 && Cout < 256 ? T64x64 : T64x128);
+    else sh = no_cap >= 200000 && Cin > 32 ? T128x64 : T64x64;
+  }
+  else if (six && no_cap < 1000 && Cout >= 256) sh = T64x128;
+  else if (no_cap < 4000) sh = T64x64;
+  else if (no_cap < 16384) sh = six ? T128x64 : T64x64;
+  else if (Cout >= 128) sh = T128x128;
+  else if (six && Cin <= 32) sh = T64x64;
+  else sh = T128x64;
+  const ConvTune t = g_conv_tune;
+  if (t.shape >= 0 && t.shape < N_CONV_SHAPES && (six || t.shape != T64x128)) sh = t.shape;
+  ConvPlan pl{sh, bms[sh], bns[sh], 1, K, 1};
+  if (slices == 1 && has_ws) {
+    pl.splits = choose_splits(no_cap, Cout, K, pl.bm, pl.bn, ws_bytes);
+    if (t.splits > 0) {
+      pl.splits = t.splits > K ? K : t.splits;
+      const size_t per = (size_t)no_cap * Cout * sizeof(float);
+      if (per > 0 && (size_t)pl.splits * per > ws_bytes) pl.splits = (int)(ws_bytes / per);
+    }
+    pl.k_per_split = (int)ceil_div(K, pl.splits > 0 ? pl.splits : 1);
+    pl.splits = (int)ceil_div(K, pl.k_per_split);
+    if (pl.splits < 2) { pl.splits = 1; pl.k_per_split = K; }
+  }
+  // two stages of loads in flight where a block is a chain of latency-bound stages: short f16x3 layers (Cin >= 64: the
+  // neighbour indices must be two stages ahead of their gathers)
+  const bool pf2_ok = six && mode == 1 && Cin >= 2 * BK && sh != T128x32 && sh != T128x128;    // 128x128 would spill
+  if (pf2_ok && K > 1) pl.pf = no_cap < CONV_PF2_ROWS ? 2 : 1;
+  if (t.pf > 0 && pf2_ok) pl.pf = t.pf >= 2 ? 2 : 1;
+  return pl;
+}
+
 int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float* weight, int Cout, const float* scale,
                 const float* shift, const float* residual, int act, float* out, int64_t no_cap, const int32_t* no_dev,
                 int slices, void* workspace, size_t ws_bytes, hipStream_t st, const void* weight_split = nullptr,
@@ -1227,32 +1363,12 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
                                               2 * (int64_t)(slices > 1 ? slices : 1) * (tile_tap ? w_taps : K) * Cin *
                                                   conv_cout_padded(Cout));
   }
-  int bm, bn;
-  // tile choice, measured per layer class and precision on MI355X at the ScanNet shape (see DESIGN.md): f16x3 tiles
-  // need fewer registers and less LDS (4-7 blocks per CU), which moves the optimum to 64-row tiles almost everywhere
-  enum { T128x128, T128x64, T64x64, T128x32, T64x128 } shape;
   const bool six = weight_split != nullptr && Cin % 32 == 0;
-  auto pick = [&](int sh) {
-    static const int bms[] = {128, 128, 64, 128, 64}, bns[] = {128, 64, 64, 32, 128};
-    shape = (decltype(shape))sh; bm = bms[sh]; bn = bns[sh];
-  };
-  if (Cout <= 32) pick(T128x32);
-  else if (six && mode >= 1) {
-    if (Cout >= 128) pick(no_cap >= 16384 && no_cap < 40000 ? T128x128 : (no_cap < 1000 && Cout < 256 ? T64x64 : T64x128));
-    else pick(no_cap >= 200000 && Cin > 32 ? T128x64 : T64x64);
-  }
-  else if (six && no_cap < 1000 && Cout >= 256) pick(T64x128);
-  else if (no_cap < 4000) pick(T64x64);
-  else if (no_cap < 16384) pick(six ? T128x64 : T64x64);
-  else if (Cout >= 128) pick(T128x128);
-  else if (six && Cin <= 32) pick(T64x64);
-  else pick(T128x64);
-  if (slices == 1 && workspace != nullptr) {
-    p.splits = choose_splits(no_cap, Cout, K, bm, bn, ws_bytes);
-    p.k_per_split = (int)ceil_div(K, p.splits);
-    p.splits = (int)ceil_div(K, p.k_per_split);
-    if (p.splits < 2) { p.splits = 1; p.k_per_split = K; }
-  }
+  const ConvPlan pl = plan_conv(no_cap, Cin, Cout, K, mode, six, slices, workspace != nullptr, ws_bytes);
+  const int shape = pl.shape, bm = pl.bm, bn = pl.bn;
+  p.ablate = g_conv_tune.ablate;
+  p.splits = pl.splits;
+  p.k_per_split = pl.k_per_split;
   dim3 grid((unsigned)ceil_div(no_cap, bm), (unsigned)ceil_div(Cout, bn), (unsigned)(slices > 1 ? slices : p.splits));
   const bool fast = (Cin % 32 == 0) && (Cout % 4 == 0);
   const bool has_res = residual != nullptr && p.splits == 1;   // split layers add the residual in the reduce kernel
@@ -1264,6 +1380,12 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 2>), grid, dim3(256), 0, st, p, wt);  \
     else if (mode == 2)                                                                                            \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 2>), grid, dim3(256), 0, st, p, wt); \
+    else if (mode == 1 && !has_res && g_conv_tune.ablate != 0)                                                     \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 1, 1, true>), grid, dim3(256), 0, st, p, wt); \
+    else if (mode == 1 && has_res && pl.pf == 2)                                                                   \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 1, (TM_ * TN_ <= 2 ? 2 : 1)>), grid, dim3(256), 0, st, p, wt);  \
+    else if (mode == 1 && pl.pf == 2)                                                                              \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 1, (TM_ * TN_ <= 2 ? 2 : 1)>), grid, dim3(256), 0, st, p, wt); \
     else if (mode == 1 && has_res)                                                                                      \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 1>), grid, dim3(256), 0, st, p, wt);  \
     else if (mode == 1)                                                                                            \
@@ -1953,6 +2075,29 @@ extern "C" size_t cnrma_sparse_conv_workspace_bytes(int64_t no_cap, int Cout, in
   // room for a full split over the kernel offsets of a short layer; long layers are never split
   if (K <= 1 || no_cap >= 65536) return 0;
   return (size_t)K * (size_t)no_cap * (size_t)Cout * sizeof(float);
+}
+
+extern "C" int cnrma_debug_conv_tuning(const int* v, int n) {
+  // v = {tile shape (0 128x128, 1 128x64, 2 64x64, 3 128x32, 4 64x128), splits over the kernel offsets, prefetch depth}; -1 or
+  // missing = the launcher's own choice; n == 0 restores the product configuration.  Host-side global state: A/B runs only.
+  ConvTune t;
+  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate};
+  if (n < 0 || n > 4 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  for (int i = 0; i < n; ++i) *f[i] = v[i];
+  g_conv_tune = t;
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_plan(int64_t no_cap, int Cin, int Cout, int K, int mode, int slices, size_t workspace_bytes,
+                                      int* out6) {
+  // what launch_conv will run for these sizes: out6 = {tile rows, tile columns, splits, offsets per split, prefetch depth,
+  // shape id}; mode 0 fp32 / bf16x6 weights absent = fp32 MFMA kernel, 1 = f16x3, 2 = bf16, 3 = bf16x6
+  if (out6 == nullptr || Cin <= 0 || Cout <= 0 || K <= 0 || K > 27 || no_cap <= 0 || mode < 0 || mode > 3) return CNRMA_EINVAL;
+  const bool six = mode != 0 && Cin % 32 == 0;
+  const ConvPlan pl = plan_conv(no_cap, Cin, Cout, K, mode == 3 ? 0 : mode, six, slices > 1 ? slices : 1, workspace_bytes > 0,
+                                workspace_bytes);
+  out6[0] = pl.bm; out6[1] = pl.bn; out6[2] = pl.splits; out6[3] = pl.k_per_split; out6[4] = pl.pf; out6[5] = pl.shape;
+  return 0;
 }
 
 extern "C" int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight,

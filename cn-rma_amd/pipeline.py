@@ -38,6 +38,40 @@ class SceneConfig:
         self.sample_seed = sample_seed        # device sampler: fixed seed (None = a fresh subset per call)
 
 
+def graph_node_count(graph):
+    """number of nodes of a captured torch.cuda.CUDAGraph (hipGraphGetNodes on its raw handle; the graph must have been
+    created with keep_graph=True); None when the runtime does not give it"""
+    import ctypes
+    import os
+    try:
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        n = ctypes.c_size_t(0)
+        hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+        hip.hipGraphGetNodes.restype = ctypes.c_int
+        if hip.hipGraphGetNodes(ctypes.c_void_p(graph.raw_cuda_graph()), None, ctypes.byref(n)) != 0:
+            return None
+        return int(n.value)
+    except Exception:       # noqa: BLE001 -- a diagnostic: never fatal
+        return None
+
+
+def weight_tensors(*modules):
+    """every parameter and buffer of the modules, as a list (built once per captured context)"""
+    import itertools
+    return [t for m in modules for t in itertools.chain(m.parameters(), m.buffers())]
+
+
+def weights_tag(tensors):
+    """cheap fingerprint of a model's weights: (count, sum of in-place version counters, first storage address).  Optimiser
+    steps, load_state_dict() and every other in-place write bump a version; a moved / re-created model changes the
+    address.  (Writes through `.data` bump nothing: call the owner's reset after those.)  A captured graph replays
+    prepared weight images, so its owner compares this tag before each replay."""
+    v = 0
+    for t in tensors:
+        v += t._version
+    return (len(tensors), v, tensors[0].data_ptr() if tensors else 0)
+
+
 def _offset_list(offset):
     if offset is None:
         return (0.0, 0.0, 0.0)
@@ -173,6 +207,7 @@ class StaticNet:
         """calibrate eagerly on (coords [M,3], feats [M,C]), then trace statically at point capacity `cap` (default M)
         and capture.  Returns the eager result dict(bboxes, scores)."""
         _lib.require_gpu()
+        self._enter(coords, feats)
         with torch.cuda.stream(self.stream), torch.no_grad():
             plan = P.Plan(self.margin)
             with P.using(plan):
@@ -212,10 +247,18 @@ class StaticNet:
         self.plan.end_static()
         return out
 
-    def run(self, coords, feats):
+    def _enter(self, *inputs):
+        """order self.stream behind the caller's stream (which produced the inputs) and keep their memory from being recycled
+        while self.stream still reads it"""
         cur = torch.cuda.current_stream(self.device)
         if cur != self.stream:
             self.stream.wait_stream(cur)
+            for t in inputs:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.stream)
+
+    def run(self, coords, feats):
+        self._enter(coords, feats)
         with torch.cuda.stream(self.stream):
             self._load(coords, feats)
             if self.graph is not None:
@@ -250,12 +293,23 @@ class StaticScene:
         self.plan = None
         self.out = None
         self._copied = None
+        self.check_weights = True          # compare the weights' fingerprint before every replay (~20 us of host time)
+        self._weights = weight_tensors(backbone, head)
+        self._tag = None
 
     # ---- inputs --------------------------------------------------------------------------------------------------
     def _alloc_inputs(self, features_nchw, tsdf):
         V, C, H, W = features_nchw.shape
         dev = self.device
-        self.nhwc = torch.empty((V, H, W, C), dtype=torch.float32, device=dev)
+        self.shape_nhwc = (V, H, W, C)
+        # The kernels of the trace read the feature maps BY REFERENCE (feat_ref: a device word with their address, written per
+        # scene): maps that are channels-last in memory -- what the 2D network hands over when it runs in
+        # torch.channels_last -- are read where they lie; NCHW maps go through the layout pass into `nhwc`, a buffer that is
+        # only allocated when the first such scene arrives (12.6 GB at the north-star shape).
+        self.nhwc = None
+        self.feat_ref = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._pin_ref = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+        self._held = None
         self.proj_scaled = torch.empty((V, 3, 4), dtype=torch.float32, device=dev)
         self.proj_inv = torch.empty((V, 4, 4), dtype=torch.float32, device=dev)
         self.tsdf = torch.empty(tuple(self.cfg.dims), dtype=torch.float32, device=dev)
@@ -266,13 +320,24 @@ class StaticScene:
         # the march runs with the layout pass, in _load (one launch), into buffers the graph reads
         self.march = self.march_out = None
         if cfg.ray_marching_type == "neus":
-            self.march = rma._March(self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps,
-                                    cfg.thr, "neus", 0)
+            self.march = rma._March(None, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps,
+                                    cfg.thr, "neus", 0, shape=self.shape_nhwc, device=dev, feat_ref=self.feat_ref)
             if self.march.kept_cap() <= 0:
                 raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
             self.march_out = self.march.march_buffers()
+        else:
+            self._nhwc_buffer()                  # depth mode: its emission kernel reads the static channels-last copy
         self._pin_proj = torch.empty((V, 3, 4), dtype=torch.float32, pin_memory=True)
         self._pin_inv = torch.empty((V, 4, 4), dtype=torch.float32, pin_memory=True)
+
+    def _nhwc_buffer(self):
+        """the slot's own channels-last feature buffer [V,H,W,C] (layout-pass target for NCHW inputs; producers may also write
+        their output straight into it and call run(None, ...))"""
+        if self.nhwc is None:
+            self.nhwc = torch.empty(self.shape_nhwc, dtype=torch.float32, device=self.device)
+            if self.march is not None:
+                self.march.feat = self.nhwc
+        return self.nhwc
 
     def _load(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
         """stage one scene's inputs into the static buffers (on self.stream, which must be current).  proj_inv: the
@@ -292,17 +357,30 @@ class StaticScene:
         else:
             self._pin_off.copy_(torch.as_tensor(offset, dtype=torch.float32).detach().reshape(3).cpu())
         self.offset_dev.copy_(self._pin_off, non_blocking=True)
-        # layout pass (NCHW -> the static channels-last buffer) and march in ONE launch; features_nchw None = the caller's
-        # own layout pass already wrote self.nhwc; a tensor that is channels-last in memory is copied as it is
-        if features_nchw is not None and features_nchw.permute(0, 2, 3, 1).is_contiguous():
-            self.nhwc.copy_(features_nchw.permute(0, 2, 3, 1), non_blocking=True)
-            features_nchw = None
+        # where the trace reads the feature maps from: features_nchw None = the caller already wrote _nhwc_buffer(); maps that
+        # are channels-last in memory are read in place (NeuS mode); everything else goes through the layout pass (NCHW ->
+        # the slot's buffer, in ONE launch with the march)
+        layout_from = None
+        if features_nchw is None:
+            addr = self._nhwc_buffer().data_ptr()
+        elif rma.is_channels_last(features_nchw) and self.march is not None:
+            assert tuple(features_nchw.shape) == (self.shape_nhwc[0], self.shape_nhwc[3], self.shape_nhwc[1], self.shape_nhwc[2])
+            addr = features_nchw.data_ptr()
+            self._held = features_nchw           # alive until this slot takes its next scene
+        elif rma.is_channels_last(features_nchw):
+            self._nhwc_buffer().copy_(features_nchw.permute(0, 2, 3, 1), non_blocking=True)
+            addr = self.nhwc.data_ptr()
+        else:
+            addr = self._nhwc_buffer().data_ptr()
+            layout_from = features_nchw
+        self._pin_ref[0] = addr
+        self.feat_ref.copy_(self._pin_ref, non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()                    # the pinned staging buffers are free again once this point has executed
         if self.march is not None:
-            self.march.march(layout_from=features_nchw, into=self.march_out)
-        elif features_nchw is not None:          # depth mode: the layout pass alone (its two small kernels run inside the trace)
-            rma.to_nhwc(features_nchw, out=self.nhwc)
+            self.march.march(layout_from=layout_from, into=self.march_out)
+        elif layout_from is not None:            # depth mode: the layout pass alone (its two small kernels run inside the trace)
+            rma.to_nhwc(layout_from, out=self.nhwc)
 
     def _enter(self, *inputs):
         """order self.stream behind the caller's stream (the 2D backbone / Atlas head that produced the inputs ran
@@ -332,15 +410,16 @@ class StaticScene:
                     side = self._side
                     side.wait_stream(main)
                 with torch.cuda.stream(side if side is not None else main):
-                    out["volume"], out["count"] = rma.backproject_accum(self.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin,
-                                                                        cfg.stride, proj_scaled=self.proj_scaled)
+                    out["volume"], out["count"] = rma.backproject_accum(None, None, cfg.dims, cfg.voxel_size, cfg.origin,
+                                                                        cfg.stride, proj_scaled=self.proj_scaled,
+                                                                        feat_ref=self.feat_ref, shape=self.shape_nhwc)
             fixed = cfg.sample_seed is not None          # a fixed seed: every replay draws the same subset (as forward_scene)
             coords, feats, n_sel, info = rma.aggregate_points_static(
                 self.nhwc, self.proj_inv, self.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                 max_points=cfg.max_points, seed=cfg.sample_seed if fixed else 0x5EED,
                 seed_dev=None if fixed else self.seed_dev,
                 marched=(self.march, self.march_out) if self.march is not None else None,
-                mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0)
+                mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0, feat_ref=self.feat_ref, shape=self.shape_nhwc)
             moved = coords + self.offset_dev     # ray_marching.py:364 (one fp32 add per coordinate, as the reference)
             out.update(trace_net(plan, self.backbone, self.head, moved, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
                                  extra_counts=[info["M"], n_sel]))
@@ -383,16 +462,22 @@ class StaticScene:
             self.out = self._trace()                         # plain static run: creates the trace's constants
             self.stream.synchronize()
             if capture:
-                self.graph = torch.cuda.CUDAGraph()
+                self.graph = torch.cuda.CUDAGraph(keep_graph=True)
                 with torch.cuda.graph(self.graph, stream=self.stream):
                     self.out = self._trace()
+                self.n_nodes = graph_node_count(self.graph)      # launches per scene inside the graph (bench: graph_nodes_per_scene)
+                self.graph.instantiate()
                 self.stream.synchronize()
+        self._tag = weights_tag(self._weights)
         return eager
 
     def run(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
         """enqueue one scene on self.stream (ordered behind the caller's current stream, which produced the inputs);
         returns the static output dict (device tensors, valid until the next run; consumers on another stream wait on
         `self.done` first -- detections() does)."""
+        if self.graph is not None and self.check_weights and weights_tag(self._weights) != self._tag:
+            raise _lib.CnrmaError("the model's weights changed since this scene graph was captured (optimiser step, "
+                                  "load_state_dict, .to()): the graph replays prepared weight images -- rebuild() it")
         self._enter(features_nchw, tsdf)
         with torch.cuda.stream(self.stream):
             self._load(features_nchw, projections, tsdf, proj_inv, offset)
@@ -494,6 +579,13 @@ class StaticBatch:
         _lib.require_gpu()
         assert len(scenes) == self.B
         self.plan = plan.scaled(self.B)
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:                              # inputs written on the caller's stream just before build()
+            self.stream.wait_stream(cur)
+            for sc_ in scenes:
+                for t_ in (sc_[0], sc_[2]):
+                    if torch.is_tensor(t_) and t_.is_cuda:
+                        t_.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             for h, sc_ in zip(self.holders, scenes):
                 h._alloc_inputs(sc_[0], sc_[2])
@@ -519,13 +611,13 @@ class StaticBatch:
             fixed = cfg.sample_seed is not None
             for b, h in enumerate(self.holders):                  # the geometric half, scene by scene
                 if self.dense:
-                    vols.append(rma.backproject_accum(h.nhwc, None, cfg.dims, cfg.voxel_size, cfg.origin, cfg.stride,
-                                                      proj_scaled=h.proj_scaled))
+                    vols.append(rma.backproject_accum(None, None, cfg.dims, cfg.voxel_size, cfg.origin, cfg.stride,
+                                                      proj_scaled=h.proj_scaled, feat_ref=h.feat_ref, shape=h.shape_nhwc))
                 coords, feats, n_sel, info = rma.aggregate_points_static(
                     h.nhwc, h.proj_inv, h.tsdf, cfg.dims, cfg.voxel_size, cfg.origin, cfg.n_steps, cfg.thr,
                     max_points=cfg.max_points, seed=(cfg.sample_seed if fixed else 0x5EED) + 7919 * b * (0 if fixed else 1),
                     seed_dev=None if fixed else h.seed_dev, marched=(h.march, h.march_out) if h.march is not None else None,
-                    mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0)
+                    mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0, feat_ref=h.feat_ref, shape=h.shape_nhwc)
                 pts.append((coords + h.offset_dev, feats, n_sel))
                 Ms += [info["M"].view(1), n_sel.view(1)]
                 if not fixed:

@@ -54,6 +54,10 @@ class Plan:
         self._reset()
         self._consts = []          # device constants of the static trace, created by the first (un-captured) static run
         self.workspaces = {}       # grow-only scratch buffers of the static trace (kept alive with the plan)
+        self._kept = {}            # id -> tensor: buffers the captured launches read through raw pointers but that the
+                                   # modules may drop at any time (prepared weight images, folded BatchNorm vectors, fused head
+                                   # weights: all cached per module and invalidated on train() / load_state_dict()) -- a graph
+                                   # must never replay a pointer into freed allocator memory
 
     def _reset(self):
         self._i = self._j = self._c = 0
@@ -129,6 +133,12 @@ class Plan:
     def watch(self, n_dev, lo, hi):
         """assumption of the static trace: lo <= n_dev[0] <= hi"""
         self._watch.append((n_dev.view(-1)[:1], int(lo), int(hi)))
+
+    def keep(self, *tensors):
+        """pin tensors whose device pointers the static trace hands to kernels for as long as this plan (= its graph) lives"""
+        for t in tensors:
+            if t is not None:
+                self._kept[id(t)] = t
 
     def const(self, builder):
         """a small device constant of the static trace: built by the first static run (outside graph capture, where a

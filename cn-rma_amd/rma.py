@@ -57,7 +57,14 @@ def to_nhwc(features, out=None):
     return out
 
 
-def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stride, proj_scaled=None):
+def is_channels_last(features):
+    """[V,C,H,W] fp32 on the GPU whose MEMORY is channels-last (what a 2D network run in torch.channels_last writes): the
+    hot path reads such maps in place"""
+    return (torch.is_tensor(features) and features.dim() == 4 and features.dtype == torch.float32 and features.is_cuda
+            and features.permute(0, 2, 3, 1).is_contiguous())
+
+
+def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stride, proj_scaled=None, feat_ref=None, shape=None):
     """Dense unprojection of all views + mean (ray_marching.py:21-69, :220-257) in one kernel.
 
     features_nhwc [V,H,W,C] device fp32; projections [V,3,4] full-resolution (scaled here by `stride`), or
@@ -66,16 +73,25 @@ def backproject_accum(features_nhwc, projections, dims, voxel_size, origin, stri
     the reference's `valid` is `count > 0`.
     """
     _lib.require_gpu()
-    V, H, W, C = features_nhwc.shape
     X, Y, Z = dims
-    dev = features_nhwc.device
+    if feat_ref is not None:
+        # by reference: feat_ref = device int64 [1] holding the address of the [V,H,W,C] maps (shape given explicitly)
+        V, H, W, C = shape
+        dev = feat_ref.device
+    else:
+        V, H, W, C = features_nhwc.shape
+        dev = features_nhwc.device
     proj = proj_scaled if proj_scaled is not None else _f32(scale_projection(projections.to(torch.float32), stride)).to(dev)
     volume = torch.empty((C, X, Y, Z), dtype=torch.float32, device=dev)
     count = torch.empty((X, Y, Z), dtype=torch.int32, device=dev)
     st = stream()
     ws = _dense_workspace(dev, st)
-    call("cnrma_backproject_accum_f32", ptr(features_nhwc), ptr(proj), V, C, H, W, X, Y, Z, float(voxel_size),
-         float(origin[0]), float(origin[1]), float(origin[2]), ptr(volume), ptr(count), ptr(ws), ws.numel() * 4, st)
+    if feat_ref is not None:
+        call("cnrma_backproject_accum_ref_f32", ptr(feat_ref), ptr(proj), V, C, H, W, X, Y, Z, float(voxel_size),
+             float(origin[0]), float(origin[1]), float(origin[2]), ptr(volume), ptr(count), ptr(ws), ws.numel() * 4, st)
+    else:
+        call("cnrma_backproject_accum_f32", ptr(features_nhwc), ptr(proj), V, C, H, W, X, Y, Z, float(voxel_size),
+             float(origin[0]), float(origin[1]), float(origin[2]), ptr(volume), ptr(count), ptr(ws), ws.numel() * 4, st)
     return volume, count
 
 
@@ -84,8 +100,9 @@ _DENSE_KEYS = ("variant", "slab", "st", "zt", "tt", "zi", "chunk", "persist", "l
 
 
 def _dense_workspace(dev, st):
-    """the zeroed barrier words of the dense kernel's lockstep schedule: one per (device, stream) -- calls on one stream
-    run one after the other and the kernel leaves the words zero"""
+    """arrival counters of the dense kernel's lockstep schedules (debug / A-B only; the product schedule ignores them):
+    one zeroed block per (device, stream).  The counters are monotonic -- never reset -- so calls on one stream simply
+    keep counting"""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), st)
     ws = _DENSE_WS.get(key)
     if ws is None:
@@ -176,10 +193,14 @@ def ray_params(proj_inv, H, W):
 class _March:
     """Argument pack shared by the count / emit calls of one scene."""
 
-    def __init__(self, features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids):
+    def __init__(self, features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, mode, select_grids, shape=None,
+                 device=None, feat_ref=None):
+        """features_nhwc [V,H,W,C], or None with `shape` = (V,H,W,C) and `device`: the maps then come by reference
+        (feat_ref: device int64 [1] holding their address) or are bound later (bind_features)"""
         self.feat = features_nhwc
-        self.V, self.H, self.W, self.C = features_nhwc.shape
-        self.dev = features_nhwc.device
+        self.feat_ref = feat_ref
+        self.V, self.H, self.W, self.C = features_nhwc.shape if features_nhwc is not None else shape
+        self.dev = features_nhwc.device if features_nhwc is not None else torch.device(device)
         self.pinv = _f32(proj_inv).to(self.dev)
         self.tsdf = _f32(tsdf).to(self.dev)
         self.X, self.Y, self.Z = dims
@@ -231,7 +252,7 @@ class _March:
                 self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow_all), stream())
         if layout_from is not None:
             src = _f32(layout_from)
-            assert tuple(src.shape) == (self.V, self.C, self.H, self.W) and self.feat.is_contiguous()
+            assert tuple(src.shape) == (self.V, self.C, self.H, self.W) and self.feat is not None and self.feat.is_contiguous()
             call("cnrma_nchw_to_nhwc_march_f32", ptr(src), ptr(self.feat), self.C, *tail)
         else:
             call("cnrma_rma_neus_march_f32", *tail)
@@ -248,7 +269,9 @@ class _March:
                   feat_stride, out_sample=None, n_out_dev=None):
         """n_out = rows of the output buffers; n_out_dev = device word with the live row count (None: all n_out)"""
         rec = torch.empty((int(n_out), 4), dtype=torch.int32, device=self.dev)
-        call("cnrma_rma_neus_emit_rows_f32", ptr(self.pinv), ptr(self.feat), self.V, self.C, self.H, self.W, self.N,
+        by_ref = self.feat_ref is not None
+        call("cnrma_rma_neus_emit_rows_ref_f32" if by_ref else "cnrma_rma_neus_emit_rows_f32", ptr(self.pinv),
+             ptr(self.feat_ref) if by_ref else ptr(self.feat), self.V, self.C, self.H, self.W, self.N,
              self.t_one, ptr(row_offset), int(n_out), ptr(n_out_dev), ptr(kept), kept.shape[1], ptr(sel_index),
              sel_index.numel() if sel_index is not None else 0, ptr(rec), ptr(w_div), float(add[0]),
              float(add[1]), float(add[2]), out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, ptr(out_sample),
@@ -429,7 +452,7 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
 
 def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05,
                             offset=(0.0, 0.0, 0.0), max_points=None, seed=0, seed_dev=None, reference_quirks=True,
-                            marched=None, mode="neus", select_grids=0):
+                            marched=None, mode="neus", select_grids=0, feat_ref=None, shape=None):
     """aggregate_points() without a device->host read (the static trace of plan.Plan; NeuS single-march only): the row
     count M stays on the device, the selection always goes through the device sampler (it keeps every row when
     M <= max_points) and the outputs are capacity-sized.  Returns (coords [cap,3], feats [cap,C], n_dev int32 [1], info);
@@ -444,7 +467,8 @@ def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, ori
         m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, 0.0, "depth", select_grids)
         cnt, wsum = m.count()
     else:
-        m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0)
+        m = _March(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps, thr, "neus", 0, shape=shape,
+                   device=proj_inv.device, feat_ref=feat_ref)
         if m.kept_cap() <= 0:
             raise _lib.CnrmaError("the static trace needs the single-march NeuS path (thr > 1/62)")
         cnt, wsum, kept, overflow = m.march()

@@ -487,13 +487,21 @@ def invalidate_weight_cache(module_or_tensor=None):
         _WEIGHT_CACHE.pop(module_or_tensor, None)
 
 
+def _pinned(ws):
+    """inside a static trace the prepared image is pinned to the plan: the graph replays its raw pointer, while the weak
+    cache drops the image on train() / load_state_dict() / when the weight tensor dies"""
+    if P.static():
+        P.current().keep(ws)
+    return ws
+
+
 def split_weights_f16(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> fp16 [2,K,Cout,Cin] (hi / lo pieces of weight * 2^s) + a trailer word
     holding max|weight| (the kernel derives s from it).  Cached on the weight tensor like split_weights()."""
     tag = (weight._version, weight.data_ptr(), weight.device)
     hit = _cache_get(weight, "_cnrma_split_f16")
     if hit is not None and hit[0] == tag:
-        return hit[1]
+        return _pinned(hit[1])
     w = weight.detach().contiguous().float()
     if w.dim() == 2:
         w = w.unsqueeze(0)
@@ -501,7 +509,7 @@ def split_weights_f16(weight):
     ws = torch.empty(_lib.load().cnrma_sparse_conv_f16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights_f16", ptr(w), K, Cin, Cout, ptr(ws), stream())
     _cache_put(weight, "_cnrma_split_f16", (tag, ws))
-    return ws
+    return _pinned(ws)
 
 
 def weights_bf16(weight):
@@ -510,7 +518,7 @@ def weights_bf16(weight):
     tag = (weight._version, weight.data_ptr(), weight.device)
     hit = _cache_get(weight, "_cnrma_bf16")
     if hit is not None and hit[0] == tag:
-        return hit[1]
+        return _pinned(hit[1])
     w = weight.detach().contiguous().float()
     if w.dim() == 2:
         w = w.unsqueeze(0)
@@ -518,7 +526,7 @@ def weights_bf16(weight):
     ws = torch.empty(_lib.load().cnrma_sparse_conv_bf16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights_bf16", ptr(w), K, Cin, Cout, ptr(ws), stream())
     _cache_put(weight, "_cnrma_bf16", (tag, ws))
-    return ws
+    return _pinned(ws)
 
 
 def _precision(precision=None):
@@ -537,7 +545,7 @@ def split_weights(weight):
     tag = (weight._version, weight.data_ptr(), weight.device)
     hit = _cache_get(weight, "_cnrma_split")
     if hit is not None and hit[0] == tag:
-        return hit[1]
+        return _pinned(hit[1])
     w = weight.detach().contiguous().float()
     if w.dim() == 2:
         w = w.unsqueeze(0)
@@ -545,9 +553,39 @@ def split_weights(weight):
     ws = torch.empty(_lib.load().cnrma_sparse_conv_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
     call("cnrma_sparse_conv_prepare_weights", ptr(w), K, Cin, Cout, ptr(ws), stream())
     _cache_put(weight, "_cnrma_split", (tag, ws))
-    return ws
+    return _pinned(ws)
 
 
+CONV_MODES = {"f32": 0, "f16x3": 1, "bf16": 2, "bf16x6": 3}
+CONV_SHAPES = ("128x128", "128x64", "64x64", "128x32", "64x128")
+
+
+def conv_plan(n_out, Cin, Cout, K, precision=None, slices=1):
+    """which kernel variant conv() launches for an output capacity of n_out rows: dict(tile=(rows, cols), splits,
+    k_per_split, prefetch, shape) -- cnrma_sparse_conv_plan, a pure host function (tests prove variant coverage with it)"""
+    import ctypes
+    prec = precision or CONV_PRECISION
+    mode = CONV_MODES[prec] if Cin % 32 == 0 else 0
+    ws = _lib.load().cnrma_sparse_conv_workspace_bytes(n_out, Cout, K) if slices == 1 else 0
+    out = (ctypes.c_int * 6)()
+    call("cnrma_sparse_conv_plan", int(n_out), int(Cin), int(Cout), int(K), mode, int(slices), ws, out)
+    return dict(tile=(out[0], out[1]), splits=out[2], k_per_split=out[3], prefetch=out[4], shape=CONV_SHAPES[out[5]])
+
+
+def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0):
+    """debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): force the tile shape ("128x128", ...), the split count
+    and the prefetch depth of every later convolution launch; no arguments = the product configuration"""
+    import ctypes
+    if shape is None and splits < 0 and pf < 0 and not ablate:
+        call("cnrma_debug_conv_tuning", None, 0)
+        return
+    # ablate (diagnostic kernels, timing only -- results are wrong): bit 0 no MFMAs, 1 no A loads, 2 no B loads, 3 no LDS
+    # stores, 4 no barriers after a block's first stage
+    arr = (ctypes.c_int * 4)(CONV_SHAPES.index(shape) if shape is not None else -1, int(splits), int(pf), int(ablate))
+    call("cnrma_debug_conv_tuning", arr, 4)
+
+
+PAIR_HDR_BYTES, PAIR_OVERFLOW_WORD = 512, 64 + 34      # csrc/sparse.hip: PAIR_HDR ints, hdr[64 + 34] = "an entry was dropped"
 PAIR_CONV = True     # pair-list kernel for stride-2 convolutions whose kernel map is nearly empty (the stem)
 # regrouping the table costs ~0.2 ms per 450 k output rows (count, plan, fill, reduce: MI355X); the tile kernel wastes
 # 27 x Cin / 32 stages per tile on empty offsets -- measured break-even between Cin = 32 (tile kernel 0.18 ms, pair list
@@ -592,6 +630,8 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
         ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(out_cs.n, Cout, K)
         ws = _workspace(ws_bytes, x.device) if ws_bytes else None
         prec = _precision(precision)
+        if P.static():       # the captured launches keep raw pointers: pin what the modules' caches may drop
+            P.current().keep(weight, w, scale, shift)
         if prec == "bf16" and Cin % 32 == 0:
             call("cnrma_sparse_conv_bf16", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(weights_bf16(weight)), Cout, ptr(scale),
                  ptr(shift), ptr(res), ACT[act], ptr(out), out_cs.n, ptr(out_cs.n_dev), ptr(ws), ws_bytes, stream())
@@ -606,6 +646,11 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
                 call("cnrma_sparse_conv_pairs_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
                      ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),
                      out_cs.n, ptr(out_cs.n_dev), pair_cap, ptr(pw), pw_bytes, stream())
+                if P.static():
+                    # the kernels flag pair entries dropped for want of capacity in word 98 of the workspace header (the
+                    # capacity above is the provable bound, so this never fires; a violated assumption must still never be
+                    # silent: the word joins the plan's status -- copied out, the workspace is reused by the next layer)
+                    P.current().watch(pw[:PAIR_HDR_BYTES].view(torch.int32)[PAIR_OVERFLOW_WORD:PAIR_OVERFLOW_WORD + 1].clone(), 0, 0)
                 return SparseTensor(out, out_cs, None, out_amax)
             call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
                  ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),
@@ -750,6 +795,8 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
     out_amax = None
     if n:
         prec = precision or CONV_PRECISION
+        if P.static():
+            P.current().keep(weight, w, scale, shift)
         if prec == "f16x3" and Cin % 32 == 0:
             out_amax = _amax_slot(x.device)
             call("cnrma_sparse_convtr_gen_f16x3", ptr(x.C), ptr(x.F.contiguous()), ptr(x.absmax()), n, ptr(x.cs.n_dev), Cin, half,
@@ -836,6 +883,8 @@ def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
             r0 += nb
         return SparseTensor(torch.cat(outs), x.cs)
     src = x.F.contiguous()
+    if P.static():
+        P.current().keep(w, b)
     if x.cs.n_batch <= 1:
         if n:
             call("cnrma_sparse_instnorm_f32", ptr(src), n, ptr(x.cs.n_dev), None, C, ptr(w), ptr(b), float(eps), int(relu),

@@ -73,15 +73,20 @@ def camera_projections(V, dims, voxel_size=0.04, img_hw=(480, 640), return_parts
     return (proj, K, np.stack(poses)) if return_parts else proj
 
 
-def make_scene(shape="S", seed=0, boxes=0, V=None, device=None):
+def make_scene(shape="S", seed=0, boxes=0, V=None, device=None, channels_last=False):
     """Returns dict(features[V,1,C,H,W], projection[V,1,3,4], tsdf[1,1,X,Y,Z], dims, voxel_size, origin, stride).
     device: draw the feature maps directly on that device (the north-star shape holds 12.6 GB of them per scene; the
-    values then come from the device generator's stream, not the CPU one -- geometry and TSDF are unchanged)."""
+    values then come from the device generator's stream, not the CPU one -- geometry and TSDF are unchanged).
+    channels_last (device draws only): the maps are channels-last IN MEMORY ([V,1,C,H,W] is a permuted view of a
+    [V,1,H,W,C] block), the layout a 2D network run in torch.channels_last hands over."""
     Vd, C, Hf, Wf, dims, stride = SHAPES[shape] if isinstance(shape, str) else shape
     V = V or Vd
     if device is not None and torch.device(device).type != "cpu":
         g = torch.Generator(device=device).manual_seed(seed)
-        feats = torch.randn(V, 1, C, Hf, Wf, generator=g, dtype=torch.float32, device=device)
+        if channels_last:
+            feats = torch.randn(V, 1, Hf, Wf, C, generator=g, dtype=torch.float32, device=device).permute(0, 1, 4, 2, 3)
+        else:
+            feats = torch.randn(V, 1, C, Hf, Wf, generator=g, dtype=torch.float32, device=device)
     else:
         g = torch.Generator().manual_seed(seed)
         feats = torch.randn(V, 1, C, Hf, Wf, generator=g, dtype=torch.float32)

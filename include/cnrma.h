@@ -44,15 +44,24 @@ int cnrma_nchw_to_nhwc_f32(const float* feat_nchw, float* feat_nhwc, int V, int 
  *           clear_3d_features()      ray_marching.py:247-257   (divide by count, zero unseen voxels)
  * proj[V][3][4]: rows 0-1 already divided by backbone2d_stride (ray_marching.py:238-239).
  * volume[C][X][Y][Z] (mean, 0 where count == 0), count[X][Y][Z] int32 (number of views that see the voxel).
- * workspace: NULL, or CNRMA_DENSE_WORKSPACE_BYTES of device memory, zeroed once by the caller before its first use and
- *   then left to the library (self-resetting barrier words of the lockstep schedule: a finished call leaves it ready
- *   for the next one; one workspace per call in flight).  With NULL the kernel runs in plain brick order (same
- *   results, lower L2 hit rate).
+ * workspace: NULL, or CNRMA_DENSE_WORKSPACE_BYTES of device memory zeroed once by the caller (one per call in flight).  It is
+ *   only used by the lockstep schedules behind cnrma_debug_dense_tuning (monotonic arrival counters of their group
+ *   barriers: never reset; a barrier that timed out or a change of the group size merely dephases later barriers -- a
+ *   performance effect, never a correctness one).  The product schedule (free-running brick order) ignores it.
  * ---------------------------------------------------------------------------------------------------------- */
 #define CNRMA_DENSE_WORKSPACE_BYTES 1024
 int cnrma_backproject_accum_f32(const float* feat_nhwc, const float* proj, int V, int C, int H, int W,
                                 int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
                                 float* volume, int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The same with the feature maps handed over BY REFERENCE: feat_nhwc_ref is a device word holding the address of the
+ * channels-last maps (read with one scalar load at kernel start).  A captured launch sequence (HIP graph) bakes its pointer
+ * arguments in; through the reference it reads whatever tensor the producer -- the 2D network of ray_marching.py:211-213,
+ * run in torch.channels_last -- has just written: the caller stores that tensor's address into the word (an 8-byte copy
+ * on the same stream) and replays.  No layout pass, no copy of V x C x H' x W' floats into a static buffer.  C % 4 == 0. */
+int cnrma_backproject_accum_ref_f32(const float* const* feat_nhwc_ref, const float* proj, int V, int C, int H, int W,
+                                    int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
+                                    float* volume, int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Debug / A-B aid (scripts/dense_ab.py, tests of the alternative voxel orders): overrides the dense kernel's schedule
  * switches {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups, ldspad} (host-side global state; n = 0
@@ -148,6 +157,13 @@ int cnrma_rma_neus_rows_backward_f32(const float* grad_out_feat, int grad_stride
 /* n_out = capacity of the output (rows of `records`, grid size); n_out_dev (may be NULL) = device word with the live number of
  * output rows (the n_sel of cnrma_mask_to_index); sel_cap = entries of sel_index (rows >= sel_cap are dropped). */
 int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
+                                 int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
+                                 const int32_t* n_out_dev, const void* kept, int cap, const int32_t* sel_index,
+                                 int64_t sel_cap, void* records, const float* w_div, float addx, float addy, float addz,
+                                 float* out_xyz, int xyz_stride, float* out_w, int w_stride, float* out_feat,
+                                 int feat_stride, int32_t* out_sample, void* stream);
+/* ... with the feature maps by reference (see cnrma_backproject_accum_ref_f32) */
+int cnrma_rma_neus_emit_rows_ref_f32(const float* proj_inv, const float* const* feat_nhwc_ref, int V, int C, int H, int W,
                                  int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
                                  const int32_t* n_out_dev, const void* kept, int cap, const int32_t* sel_index,
                                  int64_t sel_cap, void* records, const float* w_div, float addx, float addy, float addz,
@@ -286,10 +302,23 @@ int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, in
                           float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Which kernel variant a convolution of these sizes launches (pure host function; the choice depends on the output
+ * CAPACITY no_cap, never on live row counts, so a captured launch sequence replays the same kernels): out6 = {tile rows,
+ * tile columns, splits over the kernel offsets, offsets per split, load stages in flight (1 | 2), tile shape id}.
+ * mode: 0 = fp32 MFMA kernel (cnrma_sparse_conv_f32), 1 = f16x3, 2 = bf16, 3 = bf16x6.  Tests use it to prove which
+ * variants a parity case covered (fcaf3d_backbone.py:59-107 / fcaf3d_head.py:61-139 run through all of them). */
+int cnrma_sparse_conv_plan(int64_t no_cap, int Cin, int Cout, int K, int mode, int slices, size_t workspace_bytes, int* out6);
+/* Debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): overrides {tile shape id, splits, load stages in flight,
+ * ablation mask} of every later convolution launch (-1 = the launcher's choice; n = 0 restores the product configuration).
+ * A non-zero ablation mask routes f16x3 launches to a DIAGNOSTIC kernel that leaves stage components out (timing
+ * experiments: its results are meaningless).  Host-side global state; product code never calls it and nothing reads the
+ * environment. */
+int cnrma_debug_conv_tuning(const int* values, int n);
+
 /* fp32-grade convolution on the bf16 matrix cores ("bf16x6": each fp32 operand split exactly into 3 bf16 pieces, the 6
  * significant partial products accumulated in fp32; relative error ~2^-23 per product, i.e. that of an fp32 fma chain;
  * 2.67x fewer matrix-pipe cycles than the fp32 MFMA path).  Needs Cin % 32 == 0.
- * cnrma_sparse_conv_prepare_weights: weight fp32 [K][Cin][Cout] -> weight_split bf16 [3][K][Cout_p][Cin], Cout_p = Cout
+ * cnrma_sparse_conv_prepare_weights: weight fp32 [K][Cin][Cout] -> weight_split bf16 [3][K][Cin/32][Cout_p][32], Cout_p = Cout
  * rounded up to 128 with zero rows (cnrma_sparse_conv_weight_bytes bytes), done once per layer.  Same arguments /
  * epilogue as cnrma_sparse_conv_f32 otherwise. */
 size_t cnrma_sparse_conv_weight_bytes(int K, int Cin, int Cout);
@@ -338,7 +367,7 @@ int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float* in_amax, i
  * 64-byte line, whose maximum is the bound (blocks publish into the slot their index hashes to: same-address atomics
  * would serialise).  in_amax: bound >= max|in_feats| (cnrma_absmax_f32, or the out_amax of the producing convolution);
  * out_amax (may be NULL): zeroed by the caller, receives max|out_feats|.
- * cnrma_sparse_conv_prepare_weights_f16: weight fp32 [K][Cin][Cout] -> fp16 [2][K][Cout_p][Cin] of weight * 2^s + a trailer
+ * cnrma_sparse_conv_prepare_weights_f16: weight fp32 [K][Cin][Cout] -> fp16 [2][K][Cin/32][Cout_p][32] of weight * 2^s + a trailer
  * holding max|weight| (cnrma_sparse_conv_f16_weight_bytes bytes in all), done once per layer. */
 size_t cnrma_amax_bytes(void);
 int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out_amax, void* stream);
@@ -357,7 +386,7 @@ int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feat
 /* bf16 convolution (one bf16 piece per operand, round to nearest, fp32 accumulation: `v_mfma_f32_32x32x16_bf16`) -- the
  * precision of the reference's autocast training configuration (BASELINE configs[4]); NOT within the 1e-4 of the
  * inference path, which stays on f16x3 / f32.  Needs Cin % 32 == 0; weights prepared once:
- * fp32 [K][Cin][Cout] -> bf16 [K][Cout_p][Cin].  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
+ * fp32 [K][Cin][Cout] -> bf16 [K][Cin/32][Cout_p][32].  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
 size_t cnrma_sparse_conv_bf16_weight_bytes(int K, int Cin, int Cout);
 int cnrma_sparse_conv_prepare_weights_bf16(const float* weight, int K, int Cin, int Cout, void* weight_bf16, void* stream);
 int cnrma_sparse_conv_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const void* weight_bf16, int Cout,

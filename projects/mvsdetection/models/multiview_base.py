@@ -16,6 +16,12 @@ from ..registry import build_backbone, build_head
 
 
 class MultiViewBase(nn.Module):
+    # The 2D feature extractor runs in torch.channels_last: its output [V,C,H',W'] is then channels-last IN MEMORY, which is
+    # the layout the aggregation kernels gather from (one 128-byte line per pixel and 32 channels) -- the hot path reads it
+    # in place (cnrma_amd.rma.is_channels_last), no NCHW -> NHWC pass (25 GB of traffic at the north-star shape).  The
+    # tensor's logical shape and every value are unchanged (reference: backbone2d.py:28-67 / ray_marching.py:211-213).
+    channels_last_2d = True
+
     def __init__(self, pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin,
                  backbone2d_stride, backbone2d, feature_2d, backbone_3d, tsdf_head, save_path):
         super().__init__()
@@ -26,6 +32,10 @@ class MultiViewBase(nn.Module):
         self.feature_2d = build_backbone(feature_2d) if feature_2d is not None else None
         self.backbone3d = build_backbone(backbone_3d) if backbone_3d is not None else None
         self.tsdf_head = build_head(tsdf_head) if tsdf_head is not None else None
+        if self.channels_last_2d:
+            for m in (self.fpn, self.feature_2d):
+                if m is not None:
+                    m.to(memory_format=torch.channels_last)
         self.pixel_mean = torch.Tensor(pixel_mean).view(-1, 1, 1)
         self.pixel_std = torch.Tensor(pixel_std).view(-1, 1, 1)
         self.voxel_size, self.n_scales = voxel_size, n_scales
@@ -47,7 +57,10 @@ class MultiViewBase(nn.Module):
         return (x - self.pixel_mean.type_as(x)) / self.pixel_std.type_as(x)
 
     def backbone2d(self, image):
-        return self.feature_2d(self.fpn(image))
+        if not self.channels_last_2d:
+            return self.feature_2d(self.fpn(image))
+        y = self.feature_2d(self.fpn(image.contiguous(memory_format=torch.channels_last)))
+        return y.contiguous(memory_format=torch.channels_last)      # a no-op when the network kept the format (it does)
 
     def init_weights(self):
         """called by the reference's train.py:219; every sub-module initialises itself at construction"""

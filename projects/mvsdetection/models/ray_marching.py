@@ -12,6 +12,8 @@ When their configs are None the detector takes their OUTPUTS as inputs: `feature
 `tsdf` (scene_tsdf_004, [B,1,X,Y,Z]) -- that is the synthetic-scene contract of bench.py.
 """
 import os
+import threading
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -57,7 +59,7 @@ class RayMarching(MultiViewBase):
                  voxel_size_fcaf3d=0.01, use_batchnorm_train=True, use_batchnorm_test=True, max_points=None,
                  train_cfg=None, test_cfg=None, pretrained=None, use_feature_transform=True,
                  ray_marching_type="neus", depth_points=None, neus_threshold=None, middle_save_path=None,
-                 middle_visualize_path=None, point_sampler="numpy", static_test=True, static_slots=3, static_calibration=2):
+                 middle_visualize_path=None, point_sampler="device", static_test=True, static_slots=3, static_calibration=2):
         super().__init__(pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin, backbone2d_stride,
                          backbone2d, feature_2d, backbone_3d, tsdf_head, save_path)
         self.detection_backbone = build_backbone(detection_backbone)
@@ -80,13 +82,20 @@ class RayMarching(MultiViewBase):
             assert depth_points in [1, 2, 3, 4]
         self.middle_save_path = middle_save_path
         self.middle_visualize_path = middle_visualize_path
+        # max_points subset of switch_pointcloud (:360-405): "device" (default) draws it on the GPU -- the same distribution as
+        # the reference's np.random.choice from another random stream, no host RNG and no row count on the host, which is
+        # what lets the shipped configs take the graph path below unmodified; "numpy" = the reference's global-RNG draw bit
+        # for bit (parity switch: 45 ms of host time per ScanNet scene, ~1 s at the north-star shape, eager path only)
+        if point_sampler not in ("device", "numpy"):
+            raise ValueError(f"point_sampler must be 'device' or 'numpy', got {point_sampler!r}")
         self.point_sampler = point_sampler
         # inference fast path (forward_test): scenes of a repeating shape run as replayed HIP graphs, `static_slots` in
         # flight, the first `static_calibration` scenes eagerly (they size the graphs); see _forward_test_static
         self.static_test, self.static_slots, self.static_calibration = static_test, int(static_slots), int(static_calibration)
+        self.static_margin = 1.2          # capacity = recorded size x margin (+ slack) of the graphs' size plan
         self._static = {}
+        self._writer = None
         import atexit
-        import weakref
         ref = weakref.ref(self)
 
         def _flush_at_exit():
@@ -102,6 +111,31 @@ class RayMarching(MultiViewBase):
     def initialize_volume(self):
         super().initialize_volume()
         self.points_detection = []
+
+    # ---- the captured graphs hold raw pointers to prepared weight images: anything that may change the weights drops them ----
+    def _reset_static(self):
+        """write the results still in flight, then forget every captured graph (they are re-calibrated and re-captured by the
+        next test scenes).  Called by train() / load_state_dict(): a train -> validate -> train loop, or a checkpoint load
+        after the first test scene, must never replay weight images from build time."""
+        if self.__dict__.get("_static"):
+            try:
+                self.flush()
+            finally:
+                self._static = {}
+            self.__dict__["_lazy_points"] = None
+
+    def train(self, mode=True):
+        if mode != self.training or mode:
+            self._reset_static()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._reset_static()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._reset_static()
+        return super().load_state_dict(*args, **kwargs)
 
     @property
     def points_detection(self):
@@ -121,6 +155,23 @@ class RayMarching(MultiViewBase):
     def points_detection(self, value):
         self.__dict__["_points"] = value
         self.__dict__["_lazy_points"] = None
+
+    @property
+    def valid(self):
+        """[B,1,X,Y,Z] bool, `count > 0` of the dense unprojection (reference :247-257); after a graph replay it is derived
+        from the slot's count volume on first access"""
+        lazy = self.__dict__.get("_lazy_valid")
+        if lazy is not None:
+            count, done = lazy
+            torch.cuda.current_stream(count.device).wait_event(done)
+            self.__dict__["_valid"] = (count > 0).view(1, 1, *count.shape)
+            self.__dict__["_lazy_valid"] = None
+        return self.__dict__.get("_valid", 0)
+
+    @valid.setter
+    def valid(self, value):
+        self.__dict__["_valid"] = value
+        self.__dict__["_lazy_valid"] = None
 
     # ---- ray marching (reference :260-307, :687-956) ---------------------------------------------------------------
     def _rows(self, projection, features, tsdf, mode, thr=None, k=0, grids=300):
@@ -281,9 +332,9 @@ class RayMarching(MultiViewBase):
         """forward_test (reference :456-521) without a host round trip per stage: feature maps [V,C,H',W'] are used where
         they lie (no stack copy, one layout pass inside the slot), the projections come to the host once, the TSDF is
         either an input or the Atlas network's output on the dense volume, and aggregation + FCAF3D + decode of the scene
-        are ONE graph replay on one of `static_slots` streams.  The {scene}_bbox_raw.npz of a scene is written when its
-        slot is needed again (or at flush()): up to static_slots scenes are in flight, so the device never waits for the
-        host between scenes."""
+        are ONE graph replay on one of `static_slots` streams.  Up to static_slots scenes are in flight, so the device never
+        waits for the host between scenes; a writer thread puts {scene}_bbox_raw.npz on disk as soon as the scene's graph
+        has finished (flush() waits for the ones still in flight)."""
         from cnrma_amd import pipeline
         self.voxel_dim = self.voxel_dim_test
         if self.fpn is None:
@@ -302,12 +353,19 @@ class RayMarching(MultiViewBase):
         dense_in_graph = self.backbone3d is None
         key = (tuple(feats.shape), tuple(self.voxel_dim), dense_in_graph, str(feats.device))
         ctx = self._static.get(key)
+        if ctx is not None and ctx["built"] and ctx["tag"] != pipeline.weights_tag(ctx["weights"]):
+            # an optimiser step / in-place weight update since the capture: the graphs would replay stale weight images
+            self.flush()
+            del self._static[key]
+            ctx = None
         if ctx is None:
             cfg = pipeline.SceneConfig(self.voxel_dim, self.voxel_size, org, self.backbone2d_stride, 300,
                                        self.neus_threshold if self.ray_marching_type == "neus" else 0.05,
                                        self.max_points, self.voxel_size_fcaf3d, self.ray_marching_type, self.depth_points, "device")
-            first = pipeline.StaticScene(cfg, self.detection_backbone, self.detection_head, feats.device, dense=dense_in_graph)
-            ctx = dict(cfg=cfg, slots=[first], pending=[None] * max(1, self.static_slots), seen=0, k=0, built=False)
+            first = pipeline.StaticScene(cfg, self.detection_backbone, self.detection_head, feats.device, margin=self.static_margin,
+                                         dense=dense_in_graph)
+            ctx = dict(cfg=cfg, slots=[first], pending=[None] * max(1, self.static_slots), seen=0, k=0, built=False,
+                       weights=pipeline.weight_tensors(self.detection_backbone, self.detection_head), tag=None, grown=0)
             self._static[key] = ctx
         if not ctx["built"]:
             # calibration scenes: the eager path produces their results (files, module state) exactly as before; a second,
@@ -318,13 +376,7 @@ class RayMarching(MultiViewBase):
             first.calibrate(feats, proj, tsdf, offset=offset)
             ctx["seen"] += 1
             if ctx["seen"] >= max(1, self.static_calibration):
-                first.build(feats, proj, tsdf)
-                for _ in range(1, max(1, self.static_slots)):
-                    st = pipeline.StaticScene(ctx["cfg"], self.detection_backbone, self.detection_head, feats.device,
-                                              dense=dense_in_graph)
-                    st.build(feats, proj, tsdf, plan=first.plan)
-                    ctx["slots"].append(st)
-                ctx["built"] = True
+                self._build_slots(ctx, feats, proj, tsdf, dense_in_graph)
             return
         i = ctx["k"] % len(ctx["slots"])
         ctx["k"] += 1
@@ -334,8 +386,11 @@ class RayMarching(MultiViewBase):
         if not dense_in_graph:
             # the Atlas 3D network sits between the two halves (:313-318): dense volume (one kernel) -> torch modules -> TSDF.
             # The layout pass writes straight into the static buffer of the slot this scene runs on.
-            nhwc = rma.to_nhwc(feats, out=st.nhwc)
-            loaded = True
+            if rma.is_channels_last(feats):                  # the 2D network's own layout: read in place, nothing to convert
+                nhwc = rma.to_nhwc(feats)
+            else:
+                nhwc = rma.to_nhwc(feats, out=st._nhwc_buffer())
+                loaded = True
             vol, cnt = rma.backproject_accum(nhwc, proj, self.voxel_dim, self.voxel_size, org, self.backbone2d_stride)
             self.volume, self.valid = vol.unsqueeze(0), (cnt > 0).view(1, 1, *cnt.shape)
             recon_result, _ = self.tsdf_head(self.backbone3d(self.volume), inputs.get("tsdf_list"))
@@ -347,43 +402,140 @@ class RayMarching(MultiViewBase):
         tsdf = tsdf.reshape(tuple(self.voxel_dim))
         out = st.run(None if loaded else feats, proj, tsdf, offset=offset)
         if dense_in_graph:
-            self.volume, self.valid = out["volume"].unsqueeze(0), None
+            # module state as the eager path leaves it (:247-257): volume [B,C,X,Y,Z], valid [B,1,X,Y,Z] = count > 0 (lazily:
+            # one elementwise kernel on the slot's stream when somebody reads it)
+            self.volume = out["volume"].unsqueeze(0)
+            self.__dict__["_lazy_valid"] = (out["count"], out["done"])
         self.__dict__["_lazy_points"] = out["points"] + (out["done"],)
-        ctx["pending"][i] = (st, out, scene, feats, proj, tsdf, offset)
+        item = dict(st=st, out=out, scene=scene, inputs=(feats, proj, tsdf, offset), finished=threading.Event(), status=None,
+                    result=None)
+        ctx["pending"][i] = item
+        self._writer_queue().put(item)                          # {scene}_bbox_raw.npz is written as soon as the scene has left the GPU
         if recon_result is not None and self.save_path is not None:
             self.save_reconstruction(recon_result, inputs)
 
+    def _build_slots(self, ctx, feats, proj, tsdf, dense_in_graph, first_is_built=False):
+        """capture the `static_slots` scene graphs at the plan's capacities (the first slot calibrated / re-planned them)"""
+        from cnrma_amd import pipeline
+        first = ctx["slots"][0]
+        if not first_is_built:
+            first.build(feats, proj, tsdf)
+        ctx["slots"] = [first]
+        for _ in range(1, max(1, self.static_slots)):
+            st = pipeline.StaticScene(ctx["cfg"], self.detection_backbone, self.detection_head, feats.device, margin=first.margin,
+                                      dense=dense_in_graph)
+            st.build(feats, proj, tsdf, plan=first.plan)
+            ctx["slots"].append(st)
+        ctx["built"], ctx["grown"] = True, 0
+        ctx["tag"] = pipeline.weights_tag(ctx["weights"])
+
+    # ---- results leave the device on a writer thread: a scene's file exists as soon as its graph has finished ---------------
+    def _writer_queue(self):
+        """Lazily started daemon thread: waits for a scene's `done` event (blocking only itself), reads the detections with ONE
+        device->host copy on its own stream and writes {scene}_bbox_raw.npz (fcaf3d_head.py:266-271 writes it inside
+        forward_test; here it lands a few hundred microseconds after the scene's last kernel instead of at slot reuse, so a
+        crash loses at most the scenes still on the GPU).  Plan violations are left to the main thread (_drain)."""
+        if self._writer is None or not self._writer[1].is_alive():
+            import queue
+            q = queue.Queue()
+            t = threading.Thread(target=self._writer_loop, args=(q, weakref.ref(self)), name="cnrma-result-writer", daemon=True)
+            t.start()
+            self._writer = (q, t)
+        return self._writer[0]
+
+    @staticmethod
+    def _writer_loop(q, ref):
+        from cnrma_amd import _lib, pipeline
+        stream = None
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            try:
+                out = item["out"]
+                dev = out["bboxes"].device
+                torch.cuda.set_device(dev)
+                if stream is None:
+                    stream = torch.cuda.Stream(device=dev)
+                out["done"].synchronize()                        # blocks this thread only
+                with torch.cuda.stream(stream), torch.no_grad():
+                    b, s, _ = pipeline.StaticScene.detections(out)
+                    b, s = b.cpu(), s.cpu()
+                model = ref()
+                if model is not None:
+                    model._write_raw(b.numpy(), s.numpy(), item["scene"])
+                item["result"], item["status"] = (b, s), "ok"
+            except _lib.CnrmaError:
+                item["status"] = "violation"                     # outgrew the size plan: the main thread re-runs it eagerly
+            except Exception as e:                              # noqa: BLE001 -- reported by _drain on the main thread
+                item["status"], item["error"] = "error", e
+            finally:
+                item["finished"].set()
+
     def _drain(self, ctx, i):
+        """the slot's previous scene has left its static buffers (its file is written) -- or, if it outgrew the size plan,
+        is re-run eagerly here; after 4 such scenes the plan is enlarged by their sizes and the graphs are captured again"""
         item = ctx["pending"][i]
         if item is None:
             return
         ctx["pending"][i] = None
-        from cnrma_amd import _lib, pipeline
-        st, out, scene, feats, proj, tsdf, offset = item
-        try:
-            with torch.cuda.stream(st.stream):
-                b, s, _ = pipeline.StaticScene.detections(out)
-        except _lib.CnrmaError:                                 # the scene outgrew the size plan: eager re-run (sizes read back)
-            self.static_fallbacks = getattr(self, "static_fallbacks", 0) + 1
+        from cnrma_amd import pipeline
+        from cnrma_amd import plan as P
+        item["finished"].wait()
+        if item["status"] == "ok":
+            b, s = item["result"]
+            self.last_detections = [(b, s)]
+            return
+        if item["status"] == "error":
+            raise item["error"]
+        self.static_fallbacks = getattr(self, "static_fallbacks", 0) + 1
+        feats, proj, tsdf, offset = item["inputs"]
+        st = item["st"]
+        grown = P.Plan(st.margin)
+        with P.using(grown):                                    # the eager pass reads the true sizes back and records them
             e = pipeline.forward_scene(ctx["cfg"], self.detection_backbone, self.detection_head, feats, proj, tsdf,
-                                       offset=pipeline._offset_list(offset), dense=False)
-            b, s = e["bboxes"], e["scores"]
-        self._save_raw(b, s, scene)
+                                       offset=pipeline._offset_list(offset), dense=st.dense)
+        self._save_raw(e["bboxes"], e["scores"], item["scene"])
+        prev = ctx.get("outgrown")
+        same = prev is not None and len(prev.sizes) == len(grown.sizes) and len(prev.flags) == len(grown.flags)
+        ctx["outgrown"] = prev.merge(grown) if same else grown
+        ctx["grown"] += 1
+        if ctx["grown"] >= 4:                                   # a deployment whose scenes grew: stop paying replay + eager per scene
+            for j in range(len(ctx["pending"])):
+                if j != i:
+                    self._drain_no_rebuild(ctx, j)
+            first = ctx["slots"][0]
+            first.outgrown, first.n_outgrown = ctx.pop("outgrown"), ctx["grown"]
+            first.rebuild(feats, proj, tsdf)
+            self._build_slots(ctx, feats, proj, tsdf, st.dense, first_is_built=True)
+            self.static_rebuilds = getattr(self, "static_rebuilds", 0) + 1
+
+    def _drain_no_rebuild(self, ctx, j):
+        g, ctx["grown"] = ctx["grown"], -10 ** 6               # scenes drained on the way to a rebuild never trigger another one
+        try:
+            self._drain(ctx, j)
+        finally:
+            ctx["grown"] = g
 
     def flush(self):
-        """write the detections of the scenes still in flight (called when the eager path takes over, at interpreter exit,
-        and by callers that read the result files right after the loop)"""
+        """wait until the detections of every scene still in flight are written (called when the eager path takes over, on
+        train() / load_state_dict(), at interpreter exit, and by callers that read the result files right after the loop)"""
         for ctx in self._static.values():
             for i in range(len(ctx["pending"])):
                 self._drain(ctx, i)
 
-    def _save_raw(self, bboxes, scores, scene):
-        self.last_detections = [(bboxes, scores)]
+    def _write_raw(self, bboxes, scores, scene):
         if self.save_path is not None and scene is not None:
             d = os.path.join(self.save_path, scene)
             os.makedirs(d, exist_ok=True)
-            np.savez(os.path.join(d, scene + "_bbox_raw.npz"), bboxes=bboxes.detach().cpu().numpy(),
-                     scores=scores.detach().cpu().numpy())                                   # fcaf3d_head.py:266-271
+            final = os.path.join(d, scene + "_bbox_raw.npz")
+            tmp = final + f".tmp{os.getpid()}.npz"
+            np.savez(tmp, bboxes=bboxes, scores=scores)          # fcaf3d_head.py:266-271; renamed into place: a reader (or a crash)
+            os.replace(tmp, final)                               # never sees a half-written file
+
+    def _save_raw(self, bboxes, scores, scene):
+        self.last_detections = [(bboxes, scores)]
+        self._write_raw(bboxes.detach().cpu().numpy(), scores.detach().cpu().numpy(), scene)
 
     def save_middle_result(self, scene_id, coords, offset, save_path, visualize_path=None):
         """dump the aggregated points of a scene ([M, 3 + C], coordinates moved by `offset`, at most max_points rows drawn

@@ -5,8 +5,9 @@ import torch, bench
 from cnrma_amd import pipeline, rma, synth
 from cnrma_amd import sparse as S
 dev = torch.device("cuda:0")
-V, C, H, W, dims, stride = synth.SHAPES["S"]
-sc = synth.make_scene("S", seed=0)
+WL = sys.argv[1] if len(sys.argv) > 1 else "S"
+V, C, H, W, dims, stride = synth.SHAPES[WL]
+sc = synth.make_scene(WL, seed=0, boxes=3, device=dev)
 feat, proj, tsdf = sc["features"][:, 0].to(dev), sc["projection"][:, 0], sc["tsdf"][0, 0].to(dev)
 backbone, head = bench.build_model(C, dev)
 cfg = pipeline.SceneConfig(dims, stride=stride, max_points=500000, sampler="device")
@@ -20,7 +21,7 @@ def hook(self, out_set, k, off, method="auto"):
 S.CoordSet.neighbours = hook
 pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf)
 for nbr, nin, nout, s_in, s_out in seen:
-    for BM in (128, 256):
+    for BM in (64, 128):
         n = nbr.shape[0]
         nt = (n + BM - 1) // BM
         pad = torch.full((nt * BM - n, 27), -1, dtype=nbr.dtype, device=dev)

@@ -57,3 +57,24 @@ def test_frozen_stages_have_no_trainable_parameters_and_load_batchnorm_checkpoin
         if k.endswith("running_var") and k[:-11] + "num_batches_tracked" not in sd:
             sd[k[:-11] + "num_batches_tracked"] = torch.tensor(0)
     fpn.load_state_dict(sd, strict=True)
+
+
+def test_channels_last_2d_stack_gives_the_same_maps_in_the_layout_the_hot_path_reads():
+    """the plugin runs the 2D stack in torch.channels_last (MultiViewBase.channels_last_2d): same values as the reference's
+    NCHW run (golden fixture, same tolerance), and the output's MEMORY is channels-last -- the hand-off layout of the
+    aggregation kernels, consumed without a layout pass"""
+    z = np.load(os.path.join(HERE, "golden", "backbone2d.npz"))
+    fpn, head = _build()
+    fill_state_deterministic(fpn)
+    fill_state_deterministic(head)
+    fpn.to(memory_format=torch.channels_last)
+    head.to(memory_format=torch.channels_last)
+    x = torch.from_numpy(z["x"]).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = head(fpn(x))
+    assert y.shape == z["y"].shape
+    assert np.abs(y.numpy() - z["y"]).max() <= 2e-4 * np.abs(z["y"]).max()
+    assert y.permute(0, 2, 3, 1).is_contiguous()                      # one contiguous channel vector per pixel
+    # the detector base class does exactly this
+    from projects.mvsdetection.models.multiview_base import MultiViewBase
+    assert MultiViewBase.channels_last_2d

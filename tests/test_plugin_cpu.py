@@ -213,3 +213,52 @@ def test_host_tensors_are_rejected_before_they_reach_a_kernel():
     with pytest.raises(_lib.CnrmaError, match="must live on the GPU"):
         _lib.ptr(torch.zeros(4))
     assert _lib.ptr(None) is None
+
+
+def test_integration_md_ctypes_stub_matches_the_abi():
+    """the ctypes stub INTEGRATION.md tells a maintainer to paste was an ABI-v2 one.  The fenced snippet is
+    executed here against a recording stand-in of the library: every `argtypes` list it declares must equal the binding
+    table (cnrma_amd._lib.SIGNATURES, itself checked against include/cnrma.h), and every call in its function body must
+    pass exactly that many arguments"""
+    import ast
+    import ctypes
+    import re
+    from cnrma_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = [b for b in blocks if "ctypes.CDLL" in b]
+    assert len(stub) == 1
+    code = stub[0]
+
+    class Fn:
+        def __init__(self, name):
+            self.name, self.argtypes = name, None
+
+        def __call__(self, *a):
+            return _lib.ABI_VERSION if self.name == "cnrma_abi_version" else 0
+
+    class Lib:
+        def __init__(self):
+            self.fns = {}
+
+        def __getattr__(self, name):
+            return self.__dict__["fns"].setdefault(name, Fn(name))
+    lib = Lib()
+    real_cdll = ctypes.CDLL
+    ctypes.CDLL = lambda path: lib
+    try:
+        exec(compile(code, "INTEGRATION.md", "exec"), {})
+    finally:
+        ctypes.CDLL = real_cdll
+    declared = {n: f.argtypes for n, f in lib.fns.items() if f.argtypes is not None}
+    assert {"cnrma_nchw_to_nhwc_f32", "cnrma_backproject_accum_f32"} <= set(declared)
+    for name, args in declared.items():
+        assert list(args) == list(_lib.SIGNATURES[name][1]), name
+    calls = [n for n in ast.walk(ast.parse(code)) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)
+             and isinstance(n.func.value, ast.Name) and n.func.value.id == "lib" and n.func.attr.startswith("cnrma_")]
+    seen = set()
+    for c in calls:
+        assert not any(isinstance(a, ast.Starred) for a in c.args)
+        assert len(c.args) == len(_lib.SIGNATURES[c.func.attr][1]), c.func.attr
+        seen.add(c.func.attr)
+    assert {"cnrma_nchw_to_nhwc_f32", "cnrma_backproject_accum_f32", "cnrma_abi_version"} <= seen

@@ -98,6 +98,38 @@ def test_conv_vs_oracle(device, cin, cout, k, stride, ts, precision):
     assert out.cs.stride == ts * stride
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (256, 512)])
+def test_forced_tile_shapes_and_prefetch_depths_are_bit_identical(device, cin, cout):
+    """every tile shape x prefetch depth of the f16x3 kernel (sparse.conv_tuning) computes a row with the same products
+    in the same (offset, channel-slice) order: bit-identical outputs without a split, 1e-6 with one (slab sums reorder)"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + cout)
+    c, f = rand_sparse(rng, n=6000, span=14, C=cin, ts=1)
+    W = torch.from_numpy((rng.randn(27, cin, cout) / np.sqrt(cin * 27)).astype(np.float32)).to(device)
+    x = to_st(c, f, 1, device)
+    try:
+        S.conv_tuning("64x64", 1, 1)
+        ref = S.conv(x, W, 3, 1, act="relu").F.clone()
+        seen = set()
+        for shape in ("64x64", "128x64", "64x128", "128x128"):
+            for pf in (1, 2):
+                S.conv_tuning(shape, 1, pf)
+                plan = S.conv_plan(x.cs.n, cin, cout, 27)
+                assert plan["shape"] == shape and plan["splits"] == 1
+                seen.add((plan["shape"], plan["prefetch"]))
+                assert torch.equal(S.conv(x, W, 3, 1, act="relu").F, ref), (shape, pf)
+        assert ("64x128", 2) in seen and ("128x64", 2) in seen and ("128x128", 1) in seen
+        for splits in (3, 9, 27):
+            S.conv_tuning("64x128", splits, 2)
+            assert S.conv_plan(x.cs.n, cin, cout, 27)["splits"] == splits
+            got = S.conv(x, W, 3, 1, act="relu").F
+            assert torch.allclose(got, ref, rtol=1e-5, atol=5e-6 * float(ref.abs().max()))
+    finally:
+        S.conv_tuning()
+    oc, of = SO.conv(c, f, W.cpu().numpy(), 3, 1, 1)
+    check(S.SparseTensor(ref, x.cs), oc, np.maximum(of, 0.0), tol=2e-6)
+
+
 def test_presplit_companions_give_identical_results(device):
     """bf16x6 with pre-split feature companions (read + written by the conv epilogue) == bf16x6 splitting in the loop"""
     from cnrma_amd import sparse as S

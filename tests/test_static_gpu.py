@@ -284,3 +284,39 @@ def test_static_depth_mode_vs_reference_golden(device, k):
     b1, s1 = _sorted(b.cpu().numpy(), s.cpu().numpy())
     np.testing.assert_allclose(b1, b0, rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(s1, s0, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", ["tiny", "S"])
+def test_channels_last_maps_are_read_in_place_with_identical_results(device, shape):
+    """feature maps that are channels-last IN MEMORY (what the plugin's 2D stack hands over) reach the kernels by reference
+    (cnrma_backproject_accum_ref_f32 / cnrma_rma_neus_emit_rows_ref_f32): no layout pass, no copy into the slot -- and bit
+    for bit the results of the NCHW hand-off (ray_marching.py:211-244: the values are the same, only the strides differ);
+    the slot's own channels-last buffer is never allocated, and scenes of both layouts can alternate on one graph"""
+    from cnrma_amd import pipeline, rma
+    sc, feat, proj, tsdf = _scene(shape, 3, device, boxes=2)
+    sc2, feat2, proj2, tsdf2 = _scene(shape, 4, device, boxes=1)
+    backbone, head = _model(feat.shape[1], device)
+    cfg = pipeline.SceneConfig(sc["dims"], stride=sc["stride"], max_points=20000 if shape == "tiny" else 500000, sample_seed=77)
+    cl = feat.contiguous(memory_format=torch.channels_last)
+    cl2 = feat2.contiguous(memory_format=torch.channels_last)
+    assert rma.is_channels_last(cl) and not rma.is_channels_last(feat) and torch.equal(cl, feat)
+    st = pipeline.StaticScene(cfg, backbone, head, device)
+    st.build(cl, proj, tsdf)
+    assert st.graph is not None and st.nhwc is None                      # built and captured without a channels-last copy
+
+    def run(f, p, t):
+        out = st.run(f, p, t)
+        b, s, info = pipeline.StaticScene.detections(out)
+        return out["volume"].clone(), out["count"].clone(), out["points"][0].clone(), out["points"][1].clone(), b.clone(), s.clone(), info
+    a = run(cl, proj, tsdf)
+    assert st.nhwc is None
+    other = run(cl2, proj2, tsdf2)                                        # another producer tensor: only the reference changes
+    b = run(feat, proj, tsdf)                                             # NCHW on the same graph: layout pass into the slot's buffer
+    assert st.nhwc is not None
+    c = run(cl, proj, tsdf)
+    for x, y, z in zip(a[:6], b[:6], c[:6]):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    assert a[6] == b[6] == c[6]
+    assert not torch.equal(a[0], other[0])
+    eager = pipeline.forward_scene(cfg, backbone, head, cl, proj, tsdf)
+    assert torch.equal(eager["volume"], a[0]) and torch.equal(eager["count"], a[1])
