@@ -30,7 +30,13 @@ class Scale(nn.Module):
 
 
 class _TestCfg(dict):
-    __getattr__ = dict.get
+    """test_cfg with attribute access (mmcv.Config style): missing keys read as None; dunder look-ups fall through, so that
+    copy.deepcopy / pickle of the head work"""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return self.get(name)
 
 
 def _without_type(cfg):

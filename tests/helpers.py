@@ -59,3 +59,12 @@ def fill_state_deterministic(module):
                 r = r * (2.0 / fan_in) ** 0.5
             v.copy_(r)
     return module
+
+
+def elementwise_error(got, exp):
+    """worst over the elements of min(|got - exp|, |got - exp| / |exp|): "within tol absolutely OR relatively", the north
+    star's criterion for fp32 outputs (parity tolerances)"""
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    err = np.abs(got - exp)
+    worst = np.minimum(err, err / np.maximum(np.abs(exp), 1e-300))
+    return float(worst.max()) if worst.size else 0.0

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import SCENES, load_golden, t
+from helpers import SCENES, elementwise_error, load_golden, t
 from oracle import rma_oracle as RO
 from oracle import sparse_oracle as SO
 
@@ -414,6 +414,10 @@ def test_fcaf3d_forward_vs_oracle(device, n_cls, n_reg, yaw):
         outs = backbone(x)
         for o, (c, f, ts) in zip(outs, levels):
             check(o, c, f, tol=2e-4, same_order=False)      # Morton row order on the device, first-occurrence in the oracle
+            c1, f1 = sort_rows(o.C.cpu().numpy().astype(np.int64), o.F.cpu().numpy())
+            # ... and every element within 3e-4 absolutely or relatively (achieved 2.5e-4: |f| ~ 2e2 with these random weights;
+            # head outputs / boxes below hold 1e-4, as do the features of the benchmark's model at full size)
+            assert elementwise_error(f1, sort_rows(c, f)[1]) <= 3e-4
             assert o.cs.stride == ts
         cen, box, cls, points = map(list, head(outs))
     for i in range(4):
@@ -435,8 +439,8 @@ def test_fcaf3d_forward_vs_oracle(device, n_cls, n_reg, yaw):
                     e_ = np.concatenate((np.log(e_[:, :6]), e_[:, 6:]), axis=1)
                 fin = np.isfinite(e_) & (np.abs(e_) < 80)
                 g_, e_ = g_[fin], e_[fin]
-            # north star: box regressions / head outputs within 1e-4 (relative to the tensor's scale) of the fp64 oracle
-            np.testing.assert_allclose(g_, e_, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(e_).max()))
+            # north star: box regressions / head outputs within 1e-4 of the fp64 oracle, element-wise (absolute or relative)
+            assert elementwise_error(g_, e_) <= TOL, (i, key, elementwise_error(g_, e_))
     # decode: compare the boxes of level 3 (no top-k ambiguity at this size)
     b_got = head._bbox_pred_to_bbox(points[3][0], box[3][0]).cpu().numpy()
     b_exp = SO.decode_boxes(torch.from_numpy(exp[3]["points"]), torch.from_numpy(exp[3]["bbox_pred"]), yaw).numpy()
@@ -444,7 +448,7 @@ def test_fcaf3d_forward_vs_oracle(device, n_cls, n_reg, yaw):
     o2 = np.lexsort(np.round(exp[3]["points"] / 0.01).T)
     ok = np.isfinite(b_exp[o2]).all(axis=1) & (np.abs(b_exp[o2]).max(axis=1) < 1e4)
     assert ok.sum() > 0
-    np.testing.assert_allclose(b_got[o1][ok], b_exp[o2][ok], rtol=1e-3, atol=1e-3)
+    assert elementwise_error(b_got[o1][ok], b_exp[o2][ok]) <= TOL, elementwise_error(b_got[o1][ok], b_exp[o2][ok])   # boxes at 1e-4
 
 
 def _amax(t):
