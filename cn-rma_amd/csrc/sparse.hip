@@ -1443,6 +1443,341 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   return 0;
 }
 
+// ================================================================================================================
+// "Gather-once" convolution (round 4).  What the per-(offset, 32-channel slice) stage structure above costs was measured
+// with the diagnostic kernels (cnrma_debug_conv_tuning ablation masks, scripts/conv_sweep.py): on the 277 k-row 64 -> 64
+// layer the MFMAs + fragment reads take 100 us of 356, the loads 110, the LDS stores 30-60, and the bare loop skeleton
+// (two barriers, index bookkeeping per 384 MFMA cycles) 92 -- added up, not overlapped.  The remedy is not a faster
+// stage but far fewer of them:
+//   * the rows a 64-row output tile gathers over its 27 offsets overlap heavily when the rows are a compact block of
+//     voxels (Morton order): ~200-270 DISTINCT input rows instead of 64 x ~20.  tile_union_kernel lists them once per
+//     (coordinate set, kernel) -- cached with the neighbour table -- in groups of offsets whose union fits the LDS image
+//     (one group for compact tiles; tiles without locality degrade gracefully to several groups);
+//   * per 32-channel slice the union rows are fetched ONCE, split into the two fp16 planes and stored in LDS; then the
+//     offsets of the group run back to back WITHOUT barriers, LDS stores or index loads: the A fragment of output row r at
+//     offset k is an indexed LDS read (row lidx[r][k] of the image), the B fragment comes straight from memory in MFMA
+//     operand order (weight image [K][Cin/32][Cout_p/32][plane][k-step][lane][8]: one coalesced 1-KB load per wave and
+//     fragment, prefetched one offset ahead) and never touches LDS.
+// Barriers per tile: 2 per (slice, group) instead of 2 per (offset, slice); A traffic from L2 / Infinity Cache: one row
+// per union entry instead of one per (row, offset).  Sums run over (slice, group, offset) instead of (offset, slice): the
+// result differs from the stage kernel's in fp32 rounding order only.
+// ================================================================================================================
+constexpr int GO_BM = 64;            // output rows per tile
+constexpr int GO_UMAX = 320;         // union rows of one group held in LDS (+ 1 zero row): 2 planes x 64 B x 321 = 41 KB
+constexpr int GO_HASH = 1024;        // per-wave hash slots of the builder
+constexpr int GO_HDR = 84;           // ints per tile: [0] groups, then per group {offset mask, first entry, entries}
+constexpr int GO_ROWS = 27 * GO_BM;  // worst case entries per tile (every (row, offset) distinct)
+constexpr int GO_BQ = 4;             // offsets whose weight fragments are in flight / in registers per wave
+
+// one wave per tile: groups of offsets + sorted union lists + local indices
+__global__ __launch_bounds__(256) void tile_union_kernel(const int32_t* __restrict__ nbr, int64_t no_cap,
+                                                         const int32_t* __restrict__ no_dev, int K,
+                                                         int32_t* __restrict__ hdr, int32_t* __restrict__ rows,
+                                                         uint16_t* __restrict__ lidx) {
+  __shared__ int32_t hkey[4][GO_HASH];
+  __shared__ int16_t hval[4][GO_HASH];
+  __shared__ int32_t ulist[4][GO_UMAX];
+  __shared__ int16_t uslot[4][GO_UMAX];
+  __shared__ int32_t ucnt[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t n_live = live_rows(no_cap, no_dev);
+  const int64_t tile0 = tile * GO_BM;
+  if (tile0 >= n_live) return;
+  const int rows_here = (int)min((int64_t)GO_BM, n_live - tile0);
+  int32_t* hk = hkey[wave];
+  int16_t* hv = hval[wave];
+  int32_t* ul = ulist[wave];
+  int16_t* us = uslot[wave];
+  int32_t* th = hdr + tile * GO_HDR;
+  int32_t* tr = rows + tile * GO_ROWS;
+  uint16_t* tl = lidx + tile * (GO_BM * 27);
+  const int32_t* nb = nbr + tile0 * K;
+  auto clear = [&]() {
+    for (int i = lane; i < GO_HASH; i += 64) { hk[i] = -1; hv[i] = -1; }
+    if (lane == 0) ucnt[wave] = 0;
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto find = [&](int32_t v) -> int {                       // slot of v (present)
+    unsigned s = (unsigned)v * 2654435761u >> 22;             // 10 bits
+    while (hk[s] != v) s = (s + 1) & (GO_HASH - 1);
+    return (int)s;
+  };
+  int n_groups = 0, u_begin = 0;
+  unsigned gmask = 0;
+  // close the current group: ranks in ascending row order (neighbours of consecutive Morton rows are then mostly
+  // consecutive image rows: the indexed fragment reads stay nearly conflict-free), rows, local indices, header
+  auto finalize = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    const int un = ucnt[wave];
+    for (int i = lane; i < un; i += 64) {
+      const int32_t v = ul[i];
+      int rank = 0;
+      for (int j = 0; j < un; ++j) rank += ul[j] < v ? 1 : 0;
+      hv[us[i]] = (int16_t)rank;
+      tr[u_begin + rank] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < K; ++k) {
+      if (!((gmask >> k) & 1u)) continue;
+      const int32_t v = lane < rows_here ? nb[lane * K + k] : -1;
+      tl[lane * 27 + k] = v >= 0 ? (uint16_t)hv[find(v)] : (uint16_t)GO_UMAX;
+    }
+    if (lane == 0) { th[1 + 3 * n_groups] = (int)gmask; th[2 + 3 * n_groups] = u_begin; th[3 + 3 * n_groups] = un; }
+    u_begin += un;
+    ++n_groups;
+    gmask = 0;
+  };
+  clear();
+  for (int k = 0; k < K; ++k) {
+    const int32_t v = lane < rows_here ? nb[lane * K + k] : -1;
+    const int nvalid = __popcll(__ballot(v >= 0));
+    if (nvalid == 0) { tl[lane * 27 + k] = (uint16_t)GO_UMAX; continue; }
+    if (ucnt[wave] + nvalid > GO_UMAX && gmask != 0u) { finalize(); clear(); }
+    // phase 1: claim slots (no waiting inside a wave: lanes that lose a race find the key in phase 3)
+    int slot = -1;
+    bool won = false;
+    if (v >= 0) {
+      unsigned s = (unsigned)v * 2654435761u >> 22;
+      while (true) {
+        const int32_t prev = atomicCAS(&hk[s], -1, v);
+        if (prev == -1) { won = true; break; }
+        if (prev == v) break;
+        s = (s + 1) & (GO_HASH - 1);
+      }
+      slot = (int)s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (won) {                                              // phase 2: the winner numbers the new entry
+      const int idx = atomicAdd(&ucnt[wave], 1);
+      ul[idx] = v;
+      us[idx] = (int16_t)slot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    gmask |= 1u << k;
+  }
+  if (gmask != 0u) finalize();
+  if (lane == 0) th[0] = n_groups;
+}
+
+struct GoArgs {
+  const int32_t* hdr; const int32_t* rows; const uint16_t* lidx;
+  int slices_per_split;      // 32-channel slices per blockIdx.z (splits > 1: partial slabs, reduced by conv_reduce_kernel)
+};
+
+// W fp32 [K][Cin][Cout] -> fp16 fragment-order image [2 planes interleaved below][...]: element order
+//   [k][slice][column tile of 32][plane][k-step (2)][lane (64)][8]   with lane = 32 * (kk / 8 % 2) + column % 32,
+//   kk = channel inside the slice = 16 * k-step + 8 * (lane / 32) + j  -- exactly the B operand registers of
+//   v_mfma_f32_32x32x16_f16, so that a wave fetches one fragment with one contiguous 1-KB load.  Trailer: max|W|.
+__global__ __launch_bounds__(256) void prep_weights_f16_frag_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int K,
+                                                                    int Cin, int Cout, const float* __restrict__ amax) {
+  const int Cp = conv_cout_padded(Cout);
+  const int64_t total = (int64_t)K * Cin * Cp;              // elements per plane
+  const float am = read_amax(amax);
+  const float sc = f16_scale_for(am);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<float*>(wt + 2 * total) = am;
+  const int ns = Cin / BK, nt = Cp / 32;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    // t enumerates [k][slice][tile][ks][lane][j] (one plane); the two planes of a (k, slice, tile) are adjacent
+    const int j = (int)(t & 7), lane = (int)((t >> 3) & 63), ks = (int)((t >> 9) & 1);
+    int64_t q = t >> 10;
+    const int tile = (int)(q % nt); q /= nt;
+    const int slice = (int)(q % ns);
+    const int k = (int)(q / ns);
+    const int cin = slice * BK + ks * 16 + (lane >> 5) * 8 + j, co = tile * 32 + (lane & 31);
+    uint16_t hh, mm;
+    split2_f16(co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] * sc : 0.0f, hh, mm);
+    const int64_t base = (((int64_t)k * ns + slice) * nt + tile) * 2048 + ks * 512 + lane * 8 + j;    // 2 planes x 1024 per tile
+    wt[base] = hh;
+    wt[base + 1024] = mm;
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  static_assert(BM == GO_BM && WAVES_M * WAVES_N == 4, "tile shape");
+  __shared__ __attribute__((aligned(16))) __bf16 Us[2][(GO_UMAX + 1) * LDK];      // fp16 bit patterns; row GO_UMAX = zeros
+  __shared__ uint16_t Ls[GO_BM * 27];
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int64_t tile = blockIdx.x, tile0 = tile * BM;
+  if (tile0 >= n_live) return;
+  const int cout0 = blockIdx.y * BN, zs = blockIdx.z;
+  const int Cin = p.Cin, Cout = p.Cout;
+  const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid / WAVES_N, wc = wid % WAVES_N;
+  const float a_scale = f16_scale_for(read_amax(p.in_amax));
+  const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
+  const int32_t* th = g.hdr + tile * GO_HDR;
+  const int32_t* tr = g.rows + tile * GO_ROWS;
+  for (int i = tid; i < GO_BM * 27; i += 256) Ls[i] = g.lidx[tile * (GO_BM * 27) + i];
+  if (tid < 16) {                                            // the zero row of both planes (64 bytes each)
+    reinterpret_cast<uint32_t*>(&Us[0][GO_UMAX * LDK])[tid] = 0u;
+    reinterpret_cast<uint32_t*>(&Us[1][GO_UMAX * LDK])[tid] = 0u;
+  }
+  const int n_groups = th[0];
+  int s_lo = 0, s_hi = ns;
+  if (p.splits > 1) { s_lo = zs * g.slices_per_split; s_hi = min(ns, s_lo + g.slices_per_split); }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+  const int a_row0 = wr * (32 * TM) + (lane & 31), fhalf = lane >> 5;
+  // B fragments of one (offset, slice): [TN][plane][k-step] x 16 bytes per lane, straight from the fragment-order image
+  auto load_b = [&](u32x4_t (&bf)[TN][2][2], int k, int slice) {
+    const uint16_t* base = wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc * TN) * 2048 + lane * 8;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          bf[b][pl][ks] = *reinterpret_cast<const u32x4_t*>(base + b * 2048 + pl * 1024 + ks * 512);
+  };
+  auto mfma_k = [&](const u32x4_t (&bf)[TN][2][2], int k) {
+    int li[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) li[a] = Ls[(a_row0 + a * 32) * 27 + k];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8_t af[TM][2];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          af[a][pl] = *reinterpret_cast<const f16x8_t*>(&Us[pl][lds_slot(li[a], ks * 2 + fhalf)]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          const f16x8_t bh = __builtin_bit_cast(f16x8_t, bf[b][0][ks]), bm = __builtin_bit_cast(f16x8_t, bf[b][1][ks]);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][1], bh, c, 0, 0, 0);    // m*h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bm, c, 0, 0, 0);    // h*m
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bh, c, 0, 0, 0);    // h*h
+          acc[a][b] = c;
+        }
+    }
+  };
+
+  for (int slice = s_lo; slice < s_hi; ++slice) {
+    const int cin0 = slice * BK;
+    for (int grp = 0; grp < n_groups; ++grp) {
+      const unsigned mask = (unsigned)th[1 + 3 * grp];
+      const int ub = th[2 + 3 * grp], un = th[3 + 3 * grp];
+      // a ring of GO_BQ offsets' weights in flight (an L2 round trip under load is ~1400 cycles, one offset's MFMAs 192-384:
+      // with the single prefetched offset of the first build every offset waited for its weights -- noMFMA / noB ablations
+      // each removed a third of the kernel); the first ones fly while the union rows are staged
+      u32x4_t bq[GO_BQ][TN][2][2];
+      int kq[GO_BQ];
+      unsigned rest = mask;
+#pragma unroll
+      for (int d = 0; d < GO_BQ; ++d) {
+        kq[d] = -1;
+        if (rest) { kq[d] = __ffs(rest) - 1; rest &= rest - 1u; load_b(bq[d], kq[d], slice); }
+      }
+      __syncthreads();                                       // the previous group's fragment reads are done
+      // ---- the union rows of this group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight
+      const int tasks = un * 8;
+      for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = t0 + i * 256 + tid;
+          const int u = t < tasks ? (t >> 3) : 0;
+          const int32_t src = tr[ub + u];
+          v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src * Cin + cin0 + (t & 7) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int t = t0 + i * 256 + tid;
+          if (t < tasks) {
+            const int u = t >> 3, kc = t & 7;
+            uint2 h, m;
+            split2(v[i], a_scale, h, m);
+            const int o = lds_slot(u, kc >> 1) + (kc & 1) * 4;
+            *reinterpret_cast<uint2*>(&Us[0][o]) = h;
+            *reinterpret_cast<uint2*>(&Us[1][o]) = m;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- the group's offsets back to back: no barrier, no LDS store, no index load from memory
+      const int ab = p.ablate;                               // diagnostic switches (0 in product launches): 1 no MFMAs, 4 no B loads
+      bool more = true;
+      while (more) {
+#pragma unroll
+        for (int d = 0; d < GO_BQ; ++d) {
+          const int k = kq[d];
+          if (k < 0) { more = false; break; }
+          if (!(ab & 1)) mfma_k(bq[d], k);
+          kq[d] = -1;
+          if (rest) {
+            kq[d] = __ffs(rest) - 1;
+            rest &= rest - 1u;
+            if (!(ab & 4)) load_b(bq[d], kq[d], slice);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue (as the stage kernel)
+  const bool partial = p.splits > 1;
+  float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
+  const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
+  const int act = partial ? 0 : p.act;
+  float mx = 0.0f;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
+    const bool col_ok = col < Cout;
+    const int colc = col_ok ? col : 0;
+    const float sc = use_scale ? p.scale[colc] : 1.0f;
+    const float sh = use_shift ? p.shift[colc] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float res[4];
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q + 8 * rg;
+            const int64_t rc = row < n_live ? row : n_live - 1;
+            res[q] = p.residual[rc * Cout + colc];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = row0 + q + 8 * rg;
+          float v = acc[a][b][rg * 4 + q];
+          v = v * out_scale;
+          v = v * sc;
+          v = v + sh;
+          if constexpr (HAS_RES) v = v + res[q];
+          v = apply_act(v, act);
+          if (col_ok && row < n_live) {
+            dst[row * Cout + col] = v;
+            mx = fmaxf(mx, fabsf(v));
+          }
+        }
+      }
+    }
+  }
+  if (!partial && p.out_amax != nullptr) {
+    __syncthreads();
+    block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(&Us[0][0]));
+  }
+}
+
 // children coordinates of the generative transposed conv: out[k*n + i] = in[i] + off_k * half, k with x fastest
 __global__ __launch_bounds__(256) void convtr_coords_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
                                                             const int32_t* __restrict__ n_dev, int half,
@@ -2367,6 +2702,104 @@ extern "C" int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float*
   if (rb > 16384) rb = 16384;
   if (K == 27) hipLaunchKernelGGL(pairs_reduce_kernel<27>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);
   else hipLaunchKernelGGL(pairs_reduce_kernel<0>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- gather-once convolution: tile unions, fragment-order weights, launcher -----------------------------------------------
+static size_t go_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t cnrma_sparse_tile_union_bytes(int64_t no_cap) {
+  if (no_cap <= 0) return 0;
+  const size_t tiles = (size_t)ceil_div(no_cap, GO_BM);
+  return go_align(tiles * GO_HDR * 4) + go_align(tiles * GO_ROWS * 4) + go_align(tiles * GO_BM * 27 * 2);
+}
+
+extern "C" int cnrma_sparse_tile_union_build(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K, void* tile_union,
+                                             void* stream) {
+  if (nbr == nullptr || tile_union == nullptr || no_cap <= 0 || K != 27) return CNRMA_EINVAL;
+  const size_t tiles = (size_t)ceil_div(no_cap, GO_BM);
+  char* w = reinterpret_cast<char*>(tile_union);
+  int32_t* hdr = reinterpret_cast<int32_t*>(w);      w += go_align(tiles * GO_HDR * 4);
+  int32_t* rows = reinterpret_cast<int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
+  uint16_t* lidx = reinterpret_cast<uint16_t*>(w);
+  hipLaunchKernelGGL(tile_union_kernel, dim3((unsigned)ceil_div((int64_t)tiles, 4)), dim3(256), 0, as_stream(stream), nbr, no_cap,
+                     no_dev, K, hdr, rows, lidx);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_f16_frag(const float* weight, int K, int Cin, int Cout, void* weight_frag,
+                                                          void* stream) {
+  if (K <= 0 || Cin <= 0 || Cin % BK != 0 || Cout <= 0 || weight_frag == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int64_t total_src = (int64_t)K * Cin * Cout;
+  const int64_t total = (int64_t)K * Cin * conv_cout_padded(Cout);
+  uint16_t* wt = reinterpret_cast<uint16_t*>(weight_frag);
+  float* amax = reinterpret_cast<float*>(wt + 2 * total) + 16;       // slot scratch behind the 64-byte trailer
+  hipError_t e = cnrma_fill_bytes(amax, 0, sizeof(float) * AMAX_SLOTS * AMAX_STRIDE, st);
+  if (e != hipSuccess) return -(int)e;
+  int64_t blocks = ceil_div(total_src / 4 + 1, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, total_src, nullptr, 1, amax);
+  blocks = ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_f16_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, wt, K, Cin, Cout, amax);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int Cin, const void* tile_union,
+                                          const void* weight_frag, int Cout, const float* scale, const float* shift,
+                                          const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
+                                          const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  if (in_feats == nullptr || in_amax == nullptr || tile_union == nullptr || weight_frag == nullptr || out_feats == nullptr ||
+      Cin <= 0 || Cin % BK != 0 || Cout < 64 || no_cap <= 0)
+    return CNRMA_EINVAL;
+  const int K = 27;
+  hipStream_t st = as_stream(stream);
+  const size_t tiles = (size_t)ceil_div(no_cap, GO_BM);
+  const char* w = reinterpret_cast<const char*>(tile_union);
+  GoArgs g;
+  g.hdr = reinterpret_cast<const int32_t*>(w);      w += go_align(tiles * GO_HDR * 4);
+  g.rows = reinterpret_cast<const int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
+  g.lidx = reinterpret_cast<const uint16_t*>(w);
+  ConvArgs p{in_feats, Cin, nullptr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1, 1, K,
+             reinterpret_cast<float*>(workspace), nullptr, 0, nullptr, 0, in_amax, nullptr, out_amax, nullptr, 0};
+  p.ablate = g_conv_tune.ablate;
+  const uint16_t* wfrag = reinterpret_cast<const uint16_t*>(weight_frag);
+  p.w_amax = reinterpret_cast<const float*>(wfrag + 2 * (int64_t)K * Cin * conv_cout_padded(Cout));
+  const int bn = Cout >= 128 ? 128 : 64;
+  const int ns = Cin / BK;
+  // short layers: split over the 32-channel slices (every block still runs all 27 offsets of its slices); partial slabs are
+  // reduced by conv_reduce_kernel in a fixed order
+  int splits = 1;
+  const int64_t blocks = (int64_t)tiles * ceil_div(Cout, bn);
+  const int force = g_conv_tune.splits;
+  if (workspace != nullptr && ns > 1 && (blocks < 384 || force > 0)) {
+    splits = force > 0 ? force : (int)ceil_div(768, blocks);
+    if (splits > ns) splits = ns;
+    const size_t per = (size_t)no_cap * Cout * sizeof(float);
+    if (per > 0 && (size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+    if (splits < 2) splits = 1;
+  }
+  g.slices_per_split = (int)ceil_div(ns, splits);
+  splits = (int)ceil_div(ns, g.slices_per_split);
+  p.splits = splits;
+  const bool has_res = residual != nullptr && splits == 1;
+  dim3 grid((unsigned)tiles, (unsigned)ceil_div(Cout, bn), (unsigned)splits);
+  if (bn == 128) {
+    if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
+    else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
+  } else {
+    if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
+    else hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
+  }
+  if (splits > 1) {
+    int64_t rb = ceil_div(no_cap * Cout / 4 + 1, 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
+  }
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

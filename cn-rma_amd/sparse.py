@@ -102,6 +102,7 @@ class CoordSet:
         self._counts_dev = None
         self._map = cmap
         self._nbr = {}        # (kernel_size, id(out CoordSet)) -> nbr table
+        self._union = {}      # same key -> tile unions of that table (gather-once convolution)
         self._children = {}   # new_stride -> CoordSet
         self._offsets = {}
 
@@ -227,6 +228,19 @@ class CoordSet:
                      ptr(offs), K, ptr(nbr), stream())
             self._nbr[key] = (nbr, out_set)   # keep out_set alive so that id() stays unique
         return self._nbr[key][0]
+
+
+def tile_union(in_cs, out_set, kernel_size, offset_stride):
+    """per 64-row output tile: the distinct input rows its 27 offsets read + local indices (cnrma_sparse_tile_union_build);
+    cached on the input coordinate set next to the neighbour table it is derived from"""
+    key = (kernel_size, offset_stride, id(out_set))
+    tu = in_cs._union.get(key)
+    if tu is None:
+        nbr = in_cs.neighbours(out_set, kernel_size, offset_stride)
+        tu = torch.empty(_lib.load().cnrma_sparse_tile_union_bytes(out_set.n), dtype=torch.uint8, device=in_cs.device)
+        call("cnrma_sparse_tile_union_build", ptr(nbr), out_set.n, ptr(out_set.n_dev), nbr.shape[1], ptr(tu), stream())
+        in_cs._union[key] = tu
+    return tu
 
 
 class SparseTensor:
@@ -512,6 +526,21 @@ def split_weights_f16(weight):
     return _pinned(ws)
 
 
+def split_weights_f16_frag(weight):
+    """weight fp32 [27,Cin,Cout] -> the fp16 hi / lo image in MFMA-fragment order (gather-once convolution), cached like
+    split_weights_f16()"""
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    hit = _cache_get(weight, "_cnrma_frag_f16")
+    if hit is not None and hit[0] == tag:
+        return _pinned(hit[1])
+    w = weight.detach().contiguous().float()
+    K, Cin, Cout = w.shape
+    ws = torch.empty(_lib.load().cnrma_sparse_conv_f16_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+    call("cnrma_sparse_conv_prepare_weights_f16_frag", ptr(w), K, Cin, Cout, ptr(ws), stream())
+    _cache_put(weight, "_cnrma_frag_f16", (tag, ws))
+    return _pinned(ws)
+
+
 def weights_bf16(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [K,Cout_p,Cin] (round to nearest) for the "bf16" convolutions;
     cached on the weight tensor like the other prepared images"""
@@ -585,6 +614,9 @@ def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0):
     call("cnrma_debug_conv_tuning", arr, 4)
 
 
+GO_CONV = False      # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): built, parity-tested, measured
+                     # 1.0-1.2x per backbone layer but its tile-union builds (30-600 us per coordinate set) cost more than that:
+                     # S 184 vs 203 scenes/s -- off by default (DESIGN.md "Gather-once convolution")
 PAIR_HDR_BYTES, PAIR_OVERFLOW_WORD = 512, 64 + 34      # csrc/sparse.hip: PAIR_HDR ints, hdr[64 + 34] = "an entry was dropped"
 PAIR_CONV = True     # pair-list kernel for stride-2 convolutions whose kernel map is nearly empty (the stem)
 # regrouping the table costs ~0.2 ms per 450 k output rows (count, plan, fill, reduce: MI355X); the tile kernel wastes
@@ -651,6 +683,15 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
                     # capacity above is the provable bound, so this never fires; a violated assumption must still never be
                     # silent: the word joins the plan's status -- copied out, the workspace is reused by the next layer)
                     P.current().watch(pw[:PAIR_HDR_BYTES].view(torch.int32)[PAIR_OVERFLOW_WORD:PAIR_OVERFLOW_WORD + 1].clone(), 0, 0)
+                return SparseTensor(out, out_cs, None, out_amax)
+            if GO_CONV and K == 27 and stride == 1 and Cout >= 64:
+                # gather-once kernel: a tile's distinct input rows staged once per channel slice, offsets run from LDS
+                go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < 65536 else 0
+                go_ws = _workspace(go_ws_bytes, x.device) if go_ws_bytes else None
+                call("cnrma_sparse_conv_go_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin,
+                     ptr(tile_union(in_cs, out_cs, kernel_size, in_cs.stride)), ptr(split_weights_f16_frag(weight)), Cout,
+                     ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax), out_cs.n, ptr(out_cs.n_dev),
+                     ptr(go_ws), go_ws_bytes, stream())
                 return SparseTensor(out, out_cs, None, out_amax)
             call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
                  ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),

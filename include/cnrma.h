@@ -378,6 +378,22 @@ int cnrma_sparse_conv_f16x3(const float* in_feats, const float* in_amax, int Cin
                             const void* weight_split, int Cout, const float* scale, const float* shift,
                             const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
                             const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
+/* "Gather-once" form of cnrma_sparse_conv_f16x3 for 3x3x3 stride-1 convolutions (fcaf3d_backbone.py:59-87 BasicBlock
+ * convolutions, fcaf3d_head.py:61-83 out / up blocks): same operands, same epilogue, same result up to fp32 rounding order.
+ * cnrma_sparse_tile_union_build lists, per 64-row output tile of a neighbour table nbr[no_cap][27], the DISTINCT input rows
+ * the tile reads (in groups of kernel offsets whose union fits the LDS image) and the local index of every (row, offset)
+ * in that list -- once per (coordinate set, kernel), into cnrma_sparse_tile_union_bytes(no_cap) bytes, reusable by every
+ * convolution on that pair.  The convolution then stages a tile's union rows once per 32-channel slice and runs the
+ * offsets from LDS without barriers; weights come in MFMA-fragment order (cnrma_sparse_conv_prepare_weights_f16_frag,
+ * cnrma_sparse_conv_f16_weight_bytes bytes).  Cin % 32 == 0, Cout >= 64.  workspace: as cnrma_sparse_conv_f32 (slabs of the
+ * split over channel slices that short layers use). */
+size_t cnrma_sparse_tile_union_bytes(int64_t no_cap);
+int cnrma_sparse_tile_union_build(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K, void* tile_union, void* stream);
+int cnrma_sparse_conv_prepare_weights_f16_frag(const float* weight, int K, int Cin, int Cout, void* weight_frag, void* stream);
+int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int Cin, const void* tile_union,
+                               const void* weight_frag, int Cout, const float* scale, const float* shift,
+                               const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
+                               const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
 int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax, int64_t n_cap,
                                   const int32_t* n_dev, int Cin, int half_stride, const void* weight_split, int Cout,
                                   const float* scale, const float* shift, int act, int32_t* out_coords,

@@ -17,6 +17,8 @@ from cnrma_amd import sparse as S
 
 REPS = 20
 dev = torch.device("cuda:0")
+if os.environ.get("GO") is not None:                 # GO=0 / GO=1: the gather-once kernel off / on for this run
+    S.GO_CONV = os.environ["GO"] != "0"
 wl = sys.argv[1] if len(sys.argv) > 1 else "S"
 V, C, H, W, dims, stride = synth.SHAPES[wl]
 sc = synth.make_scene(wl, seed=0, boxes=3, device=dev)

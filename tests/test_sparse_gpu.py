@@ -130,6 +130,61 @@ def test_forced_tile_shapes_and_prefetch_depths_are_bit_identical(device, cin, c
     check(S.SparseTensor(ref, x.cs), oc, np.maximum(of, 0.0), tol=2e-6)
 
 
+@pytest.mark.parametrize("cin,cout,n,span", [(64, 64, 6000, 14), (128, 128, 9000, 20), (256, 512, 1500, 9), (64, 128, 20000, 14)])
+def test_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n, span):
+    """the gather-once form of the 3x3x3 stride-1 convolution (sparse.GO_CONV: per 64-row tile the distinct input rows are
+    staged once per channel slice, the 27 offsets run from LDS; weights in MFMA-fragment order) against the fp64 oracle
+    (2e-6) and the stage kernel (same products, another summation order), with residual + ReLU epilogue, with a split over
+    channel slices (short layer) and on a dense point set in random row order (no locality: every tile needs several offset
+    groups).  Also checks the tile unions themselves: every (row, offset) entry resolves to the neighbour table's row."""
+    from cnrma_amd import _lib
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + n)
+    c, f = rand_sparse(rng, n=n, span=span, C=cin, ts=1)
+    W = torch.from_numpy((rng.randn(27, cin, cout) / np.sqrt(cin * 27)).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.randn(len(c), cout).astype(np.float32)).to(device)
+    x = to_st(c, f, 1, device)
+    prev = S.GO_CONV
+    try:
+        S.GO_CONV = False
+        ref = S.conv(x, W, 3, 1, residual=res, act="relu").F.clone()
+        S.GO_CONV = True
+        got = S.conv(x, W, 3, 1, residual=res, act="relu")
+        plain = S.conv(x, W, 3, 1).F
+    finally:
+        S.GO_CONV = prev
+    assert torch.allclose(got.F, ref, rtol=1e-5, atol=5e-6 * float(ref.abs().max()))
+    oc, of = SO.conv(c, f, W.cpu().numpy(), 3, 1, 1)
+    check(S.SparseTensor(plain, x.cs), oc, of, tol=2e-6)
+    assert float(got.amax.max()) == float(got.F.abs().max())                     # the magnitude bound travels as before
+    # ---- the tile unions
+    nbr = x.cs.neighbours(x.cs, 3, 1).cpu().numpy()
+    tu = S.tile_union(x.cs, x.cs, 3, 1).cpu()
+    n_t = (len(c) + 63) // 64
+    al = lambda b: (b + 255) // 256 * 256
+    hdr = tu[:n_t * 84 * 4].view(torch.int32).view(n_t, 84).numpy()
+    rows = tu[al(n_t * 84 * 4):al(n_t * 84 * 4) + n_t * 1728 * 4].view(torch.int32).view(n_t, 1728).numpy()
+    o2 = al(n_t * 84 * 4) + al(n_t * 1728 * 4)
+    lidx = tu[o2:o2 + n_t * 1728 * 2].view(torch.int16).view(n_t, 64, 27).numpy().astype(np.int64) & 0xFFFF
+    for t in rng.choice(n_t, size=min(n_t, 12), replace=False):
+        seen = 0
+        for g in range(hdr[t, 0]):
+            mask, ub, un = int(hdr[t, 1 + 3 * g]) & 0xFFFFFFFF, hdr[t, 2 + 3 * g], hdr[t, 3 + 3 * g]
+            assert 0 < un <= 320 and (mask & seen) == 0
+            seen |= mask
+            u = rows[t, ub:ub + un]
+            assert (np.diff(u) > 0).all()                                       # distinct, ascending
+            for k in range(27):
+                if (mask >> k) & 1:
+                    for r in range(min(64, len(c) - 64 * t)):
+                        want = nbr[64 * t + r, k]
+                        assert (lidx[t, r, k] == 320) if want < 0 else (u[lidx[t, r, k]] == want)
+        live = nbr[64 * t:64 * t + 64]
+        assert all(((seen >> k) & 1) == int((live[:, k] >= 0).any()) for k in range(27))
+    if n >= 20000:
+        assert hdr[:, 0].max() > 1                                              # no locality: several groups per tile
+
+
 def test_presplit_companions_give_identical_results(device):
     """bf16x6 with pre-split feature companions (read + written by the conv epilogue) == bf16x6 splitting in the loop"""
     from cnrma_amd import sparse as S
