@@ -38,14 +38,16 @@ MFMA_F16_PEAK_TFLOPS = 2500.0
 # --pmc runs: FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM" -- + WRITE_SIZE)
 PMC_TRAFFIC = {
     # (workload, kernel) -> (bytes per launch, source): per-kernel sums of the passes / launches (profiles/README.md)
-    ("NS", "dense"): (60.4e9, "profiles/r03_ns_pmc_FETCH_SIZE.csv (x2) + r03_ns_pmc_WRITE_SIZE.csv: 25.87e6 KB x 2 + 7.26e6 KB per "
-                              "launch of backproject_accum_pipe_kernel; L2<->fabric traffic, i.e. Infinity Cache + HBM (TCC: 350 M hits / "
-                              "471 M misses incl. the 226 M 32-byte write pieces, r03_ns_pmc_TCC_HIT_MISS.csv; read hit rate 30 %; the "
-                              "replay simulation scripts/dense_l2sim.cpp puts the HBM share at ~19 GB of reads + 7.3 GB of writes)"),
-    ("NS", "conv"): (308.9e6, "profiles/r03_ns_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches"),
-    ("S", "dense"): (1.07e9, "profiles/r03_s_pmc_FETCH_SIZE.csv (x2) + r03_s_pmc_WRITE_SIZE.csv (TCC hit rate 75 %)"),
-    ("S", "conv"): (196.1e6, "profiles/r03_s_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches "
-                             "(10.0 GB per scene, L2<->fabric: the operands are Infinity-Cache resident)"),
+    ("NS", "dense"): (58.8e9, "profiles/r04_ns_pmc_FETCH_SIZE.csv (x2) + r04_ns_pmc_WRITE_SIZE.csv: 25.79e6 KB x 2 + 7.26e6 KB per "
+                              "launch of backproject_accum_pipe_kernel (the same kernel alone: r04_dense_alone_pmc_*.csv, 25.87e6 / "
+                              "7.26e6 KB); L2<->fabric traffic, i.e. Infinity Cache + HBM (TCC: 350 M hits / 471 M misses incl. the "
+                              "226 M 32-byte write pieces; read hit rate 30 %; the replay simulation scripts/dense_l2sim.cpp puts the "
+                              "HBM share at ~19 GB of reads + 7.3 GB of writes)"),
+    ("NS", "conv"): (295.3e6, "profiles/r04_ns_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches "
+                              "(15.06 GB per scene)"),
+    ("S", "dense"): (1.04e9, "profiles/r04_s_pmc_FETCH_SIZE.csv (x2) + r04_s_pmc_WRITE_SIZE.csv"),
+    ("S", "conv"): (190.2e6, "profiles/r04_s_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches "
+                             "(9.70 GB per scene, L2<->fabric: the operands are Infinity-Cache resident)"),
 }
 
 
