@@ -846,9 +846,9 @@ __global__ __launch_bounds__(256) void prep_weights_bf16_kernel(const float* __r
 
 // prefetch registers of the A operand + their staging code, one specialisation per input format (keeps the unused
 // format's registers out of the kernel; plain members instead of lambda-captured arrays so they stay in VGPRs)
-template <bool IN_SPLIT, int N> struct AStageRegs;
+template <bool IN_SPLIT, int N, int NT = 256> struct AStageRegs;     // NT = threads that share the staging work
 
-template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 channels) per task, split at the LDS store
+template <int N, int NT> struct AStageRegs<false, N, NT> {        // fp32 features: (row, 4 channels) per task, split at the LDS store
   float4 r[N];
   unsigned ok;
   __device__ __forceinline__ void load(const float* __restrict__ in, const uint16_t*, int64_t, int tid,
@@ -856,7 +856,7 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
     ok = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int kc = (tid + i * 256) & 7;
+      const int kc = (tid + i * NT) & 7;
       const int32_t src = srcs[i];
       r[i] = *reinterpret_cast<const float4*>(in + (int64_t)(src < 0 ? 0 : src) * Cin + cin0 + kc * 4);
       ok |= (src >= 0 ? 1u : 0u) << i;
@@ -866,7 +866,7 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
   __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2, float a_scale) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx >> 3, kc = idx & 7;
       float4 v = r[i];
       const bool k = (ok >> i) & 1u;
@@ -898,13 +898,13 @@ template <int N> struct AStageRegs<false, N> {        // fp32 features: (row, 4 
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // first-class vector: stays in VGPRs across the loop
 
-template <int N> struct AStageRegs<true, N> {         // pre-split companion: (row, 8 channels) per task, 3 x 16 B
+template <int N, int NT> struct AStageRegs<true, N, NT> {         // pre-split companion: (row, 8 channels) per task, 3 x 16 B
   u32x4_t h[N], m[N], l[N];
   __device__ __forceinline__ void load(const float*, const uint16_t* __restrict__ in_split, int64_t zero_row, int tid,
                                        const int32_t* srcs, int cin0, int G8, int) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int g = (tid + i * 256) & 3;
+      const int g = (tid + i * NT) & 3;
       const int32_t src = srcs[i];
       const int64_t srow = src < 0 ? zero_row : (int64_t)src;             // missing neighbour -> the all-zero row
       const u32x4_t* q = reinterpret_cast<const u32x4_t*>(in_split + (srow * G8 + (cin0 >> 3) + g) * 24);
@@ -915,7 +915,7 @@ template <int N> struct AStageRegs<true, N> {         // pre-split companion: (r
   __device__ __forceinline__ void store(int tid, __bf16* a0, __bf16* a1, __bf16* a2, float) const {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int row = idx >> 2, g = idx & 3;
       *reinterpret_cast<u32x4_t*>(a0 + lds_slot(row, g)) = h[i];
       *reinterpret_cast<u32x4_t*>(a1 + lds_slot(row, g)) = m[i];
@@ -1234,6 +1234,252 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   }
 }
 
+// ================================================================================================================
+// Warp-specialised form of the f16x3 stage kernel (round 4).  The ablation of the kernel above (diagnostic ABL build:
+// profiles/r04_conv_ablation_S.log) shows its phases ADD UP instead of overlapping -- on the 277 k-row 64 -> 64 layer: loop
+// skeleton (barriers + index bookkeeping) 92 us, global loads 110, LDS stores 30-60, fragment reads + MFMAs 100 of 356 --
+// because every wave of a block walks through all of them between two block-wide barriers.  Here a block is 8 waves with
+// fixed roles: waves 4-7 PRODUCE stages (neighbour indices, gathers, weight tiles, fp32 -> 2 x fp16 split, LDS stores)
+// into a ring of NSLOT LDS slots, waves 0-3 CONSUME them (fragment reads + MFMAs) and never execute a load, a conversion
+// or a store; the two sides meet only through per-slot counters in LDS (full / empty, monotonic), no s_barrier after
+// the prologue.  Same stage order, same products, same sums as the stage kernel: results are bit-identical.
+// ================================================================================================================
+__device__ __forceinline__ bool ws_wait(const int* cnt, int target) {
+  // bounded spin (a lost signal must never hang the GPU): ~0.5 s, then the caller flags the launch as failed
+  for (int spin = 0; spin < (1 << 24); ++spin) {
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int NSLOT, int NWP = 4>
+__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NWP), (WAVES_M * WAVES_N > 4 ? 3 : (TM * TN >= 4 ? 2 : 4)))
+void sparse_conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
+  constexpr int NWC = WAVES_M * WAVES_N, PT = 64 * NWP, NTHREADS = 64 * (NWC + NWP);      // consumer waves, producer threads
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N, NP = 2;
+  constexpr int A_ITERS = (BM << 3) / PT;
+  constexpr int B_CHUNKS = NP * BN * (BK / 8);
+  constexpr int B_ITERS = (B_CHUNKS + PT - 1) / PT;
+  constexpr int A_ELEMS = NP * BM * LDK, B_ELEMS = NP * BN * LDK, SLOT_ELEMS = A_ELEMS + B_ELEMS;
+  static_assert((BM << 3) % PT == 0 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
+  __bf16* ring = reinterpret_cast<__bf16*>(ws_lds);                       // [NSLOT][A planes | B planes]
+  int* ctl = reinterpret_cast<int*>(ws_lds + (size_t)NSLOT * SLOT_ELEMS * sizeof(__bf16));
+  int* full_cnt = ctl;                   // [NSLOT] producer waves that finished writing the slot (monotonic)
+  int* empty_cnt = ctl + NSLOT;          // [NSLOT] consumer waves that finished reading it
+  unsigned* mask_s = reinterpret_cast<unsigned*>(ctl + 2 * NSLOT);
+  int* done_cnt = ctl + 2 * NSLOT + 1;
+  float* amax_s = reinterpret_cast<float*>(ctl + 2 * NSLOT + 2);         // [NWC]
+
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int64_t tile0 = (int64_t)blockIdx.x * BM;
+  if (tile0 >= n_live) return;
+  const int cout0 = blockIdx.y * BN;
+  const int zs = blockIdx.z;
+  const int Cin = p.Cin, Cout = p.Cout, K = p.K;
+  const int Cout_p = conv_cout_padded(Cout);
+  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * (p.tile_tap ? p.w_taps : K) * Cin * Cout_p;
+  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout_p : 0) +
+                     (p.tile_tap ? (int64_t)p.tile_tap[tile0 >> 7] * Cin * Cout_p : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool producer = wid >= NWC;
+
+  int k_lo = 0, k_hi = K;
+  if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
+  const int rows_here = (int)min((int64_t)BM, n_live - tile0);
+  if (tid < 2 * NSLOT + 2) ctl[tid] = 0;
+  __syncthreads();
+  if (p.nbr == nullptr) {
+    if (tid == 0) *mask_s = 1u;
+  } else {
+    unsigned local = 0;
+    const int32_t* nb = p.nbr + tile0 * K;
+    const int kr = k_hi - k_lo;
+    for (int i = tid; i < rows_here * kr; i += NTHREADS) {
+      const int row = i / kr, k = k_lo + (i - row * kr);
+      if (nb[row * K + k] >= 0) local |= 1u << k;
+    }
+    if (local) atomicOr(mask_s, local);
+  }
+  __syncthreads();                          // the last block-wide barrier
+  const unsigned mask = *mask_s;
+  auto next_active = [&](int k) { const unsigned rest = mask & ~((2u << k) - 1u); return rest ? __ffs(rest) - 1 : -1; };
+
+  if (producer) {
+    // ---------------------------------------------------------------------------------------------- producers (waves 4-7)
+    const int ptid = tid - 64 * NWC;
+    const float a_scale = f16_scale_for(read_amax(p.in_amax));
+    int32_t src_cur[A_ITERS], src_nxt[A_ITERS];
+    auto load_src = [&](int k, int32_t* dst) {
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        const int row = (ptid + i * PT) >> 3;
+        int32_t v = -1;
+        if (row < rows_here && k >= 0) v = p.nbr ? p.nbr[(tile0 + row) * K + k] : (int32_t)(tile0 + row);
+        dst[i] = v;
+      }
+    };
+    typedef AStageRegs<false, A_ITERS, PT> ARegs;
+    ARegs areg;
+    u32x4_t rb[B_ITERS];
+    auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
+      areg.load(p.in, nullptr, 0, ptid, srcs, cin0, 0, Cin);
+      const __bf16* Wk = Wz + ((int64_t)k * (Cin / BK) + cin0 / BK) * Cout_p * BK;
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) {
+        int idx = ptid + i * PT;
+        idx = idx < B_CHUNKS ? idx : 0;
+        const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
+        rb[i] = *reinterpret_cast<const u32x4_t*>(Wk + pl * plane_elems + (int64_t)(cout0 + row) * BK + chunk * 8);
+      }
+    };
+    int k = mask ? __ffs(mask) - 1 : -1;
+    int cin0 = 0;
+    load_src(k, src_cur);
+    load_src(k >= 0 ? next_active(k) : -1, src_nxt);
+    if (k >= 0) load_stage(k, 0, src_cur);
+    for (int s = 0; k >= 0; ++s) {
+      const int slot = s % NSLOT, round = s / NSLOT;
+      __bf16* A = ring + (size_t)slot * SLOT_ELEMS;
+      __bf16* B = A + A_ELEMS;
+      if (round > 0 && !ws_wait(&empty_cnt[slot], NWC * round)) { if (lane == 0) *done_cnt = -1000; return; }
+      areg.template store<1>(ptid, A, A + BM * LDK, A + BM * LDK, a_scale);
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i) {
+        const int idx = ptid + i * PT;
+        if (idx < B_CHUNKS) {
+          const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
+          *reinterpret_cast<u32x4_t*>(&B[pl * BN * LDK + lds_slot(row, chunk)]) = rb[i];
+        }
+      }
+      // LDS executes one wave's operations in order: the counter update below lands behind the stores above
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      if (lane == 0) __hip_atomic_fetch_add(&full_cnt[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      cin0 += BK;
+      if (cin0 >= Cin) {
+        cin0 = 0;
+        k = next_active(k);
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
+        if (k >= 0) load_src(next_active(k), src_nxt);
+      }
+      if (k >= 0) load_stage(k, cin0, src_cur);
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------------------ consumers (waves 0-3)
+  const int wr = wid / WAVES_N, wc = wid % WAVES_N;
+  const float out_scale = 1.0f / (f16_scale_for(read_amax(p.in_amax)) * f16_scale_for(*p.w_amax));
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  const int n_stages = __popc(mask) * (Cin / BK);
+  const int a_row = wr * (32 * TM) + (lane & 31), b_row = wc * (32 * TN) + (lane & 31), fhalf = lane >> 5;
+  bool ok = true;
+  for (int s = 0; s < n_stages; ++s) {
+    const int slot = s % NSLOT, round = s / NSLOT;
+    const __bf16* A = ring + (size_t)slot * SLOT_ELEMS;
+    const __bf16* B = A + A_ELEMS;
+    if (!ws_wait(&full_cnt[slot], NWP * (round + 1))) { ok = false; break; }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      f16x8_t af[TM][2], bf[TN][2];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[a][pl] = *reinterpret_cast<const f16x8_t*>(&A[pl * BM * LDK + lds_slot(a_row + a * 32, (ks >> 3) + fhalf)]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bf[b][pl] = *reinterpret_cast<const f16x8_t*>(&B[pl * BN * LDK + lds_slot(b_row + b * 32, (ks >> 3) + fhalf)]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][1], bf[b][0], c, 0, 0, 0);    // m*h
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][1], c, 0, 0, 0);    // h*m
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][0], c, 0, 0, 0);    // h*h
+          acc[a][b] = c;
+        }
+    }
+    // the fragment reads have returned (the MFMAs above consumed them): the slot may be overwritten
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    if (lane == 0) __hip_atomic_fetch_add(&empty_cnt[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  if (!ok) return;
+
+  const bool partial = p.splits > 1;
+  float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
+  const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+  const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
+  const int act = partial ? 0 : p.act;
+  float mx = 0.0f;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
+    const bool col_ok = col < Cout;
+    const int colc = col_ok ? col : 0;
+    const float sc = use_scale ? p.scale[colc] : 1.0f;
+    const float sh = use_shift ? p.shift[colc] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float res[4];
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q + 8 * rg;
+            const int64_t rc = row < n_live ? row : n_live - 1;
+            res[q] = p.residual[(out_base + rc) * Cout + colc];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = row0 + q + 8 * rg;
+          float v = acc[a][b][rg * 4 + q];
+          v = v * out_scale;
+          v = v * sc;
+          v = v + sh;
+          if constexpr (HAS_RES) v = v + res[q];
+          v = apply_act(v, act);
+          if (col_ok && row < n_live) {
+            dst[(out_base + row) * Cout + col] = v;
+            mx = fmaxf(mx, fabsf(v));
+          }
+        }
+      }
+    }
+  }
+  if (!partial && p.out_amax != nullptr) {
+    // block maximum without a block barrier (the producer waves are gone): the consumer wave that arrives last publishes
+    mx = wave_max(mx);
+    if (lane == 0) amax_s[wid] = mx;
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    int arrived = 0;
+    if (lane == 0) arrived = __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    arrived = __shfl(arrived, 0, 64);
+    if (arrived == NWC - 1 && lane == 0) {
+      float m = amax_s[0];
+      for (int i = 1; i < NWC; ++i) m = fmaxf(m, amax_s[i]);
+      const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (AMAX_SLOTS - 1);
+      unsigned* d = reinterpret_cast<unsigned*>(p.out_amax + slot * AMAX_STRIDE);
+      const unsigned bits = __float_as_uint(m);
+      if (bits > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, bits);
+    }
+  }
+}
+
 // reduce the split-K slabs in a fixed order and apply the fused epilogue
 __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
@@ -1296,18 +1542,59 @@ int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes
   return s < 2 ? 1 : s;
 }
 
+template <int WM, int WN, int TM_, int TN_, int NSLOT>
+int launch_ws_one(bool has_res, dim3 grid, const ConvArgs& p, const __bf16* wt, hipStream_t st) {
+  constexpr int BM = 32 * TM_ * WM, BN = 32 * TN_ * WN, NWC = WM * WN, NWP = 4;
+  const size_t lds = (size_t)NSLOT * (BM + BN) * LDK * 2 * sizeof(uint16_t) + (2 * NSLOT + 2 + NWC) * sizeof(int);
+  if (lds > 160 * 1024) return CNRMA_EINVAL;
+  auto go = [&](auto kernel) -> int {
+    if (lds > 48 * 1024) {
+      static bool raised = false;           // per instantiation (the lambda is instantiated per kernel type)
+      if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        raised = true;
+      }
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * (NWC + NWP)), lds, st, p, wt);
+    return 0;
+  };
+  return has_res ? go(sparse_conv_ws_kernel<WM, WN, TM_, TN_, true, NSLOT>) : go(sparse_conv_ws_kernel<WM, WN, TM_, TN_, false, NSLOT>);
+}
+
+template <int NSLOT>
+int launch_ws_shape(int shape, bool has_res, dim3 grid, const ConvArgs& p, const __bf16* wt, hipStream_t st) {
+  switch (shape) {
+    case 0: return launch_ws_one<2, 2, 2, 2, NSLOT>(has_res, grid, p, wt, st);      // 128x128
+    case 1: return launch_ws_one<4, 1, 1, 2, NSLOT>(has_res, grid, p, wt, st);      // 128x64
+    case 2: return launch_ws_one<2, 2, 1, 1, NSLOT>(has_res, grid, p, wt, st);      // 64x64
+    case 4: return launch_ws_one<2, 2, 1, 2, NSLOT>(has_res, grid, p, wt, st);      // 64x128
+    case 5: return launch_ws_one<4, 2, 2, 2, NSLOT>(has_res, grid, p, wt, st);      // 256x128: 8 consumer waves of 64x64
+    case 6: return launch_ws_one<4, 2, 2, 1, NSLOT>(has_res, grid, p, wt, st);      // 256x64:  8 consumer waves of 64x32
+    default: return CNRMA_EINVAL;
+  }
+}
+
+int launch_conv_ws(int shape, int slots, bool has_res, dim3 grid, const ConvArgs& p, const __bf16* wt, hipStream_t st) {
+  if (slots >= 4 && shape != 0 && shape < 5) return launch_ws_shape<4>(shape, has_res, grid, p, wt, st);
+  if (slots >= 3 && (shape < 5 || shape == 6)) return launch_ws_shape<3>(shape, has_res, grid, p, wt, st);
+  return launch_ws_shape<2>(shape, has_res, grid, p, wt, st);
+}
+
+constexpr int CONV_WS_SLOTS = 0;       // product default of the warp-specialised kernel's ring (0: stage kernel) -- until measured
+
 // Debug / A-B switches of the convolution launcher (cnrma_debug_conv_tuning: scripts/conv_sweep.py and the tests that force a
 // variant).  Product code never changes them; -1 = the launcher's own choice.
-struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; };
+struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; int ws = -1; };   // ws: LDS ring slots of the warp-specialised kernel (0 = stage kernel)
 static ConvTune g_conv_tune;
 
-enum ConvShape { T128x128, T128x64, T64x64, T128x32, T64x128, N_CONV_SHAPES };
+enum ConvShape { T128x128, T128x64, T64x64, T128x32, T64x128, T256x128, T256x64, N_CONV_SHAPES };   // the last two: warp-specialised kernel only
 struct ConvPlan { int shape, bm, bn, splits, k_per_split, pf; };
 
 // tile shape, split count over the kernel offsets and prefetch depth of one launch: a pure function of the layer's
 // sizes (the CAPACITY of the output, not its live row count), so a captured launch sequence replays the same kernels
 ConvPlan plan_conv(int64_t no_cap, int Cin, int Cout, int K, int mode, bool six, int slices, bool has_ws, size_t ws_bytes) {
-  static const int bms[] = {128, 128, 64, 128, 64}, bns[] = {128, 64, 64, 32, 128};
+  static const int bms[] = {128, 128, 64, 128, 64, 256, 256}, bns[] = {128, 64, 64, 32, 128, 128, 64};
   // tile choice, measured per layer class and precision on MI355X at the ScanNet shape: f16x3 tiles
   // need fewer registers and less LDS (4-7 blocks per CU), which moves the optimum to 64-row tiles almost everywhere
   int sh;
@@ -1323,7 +1610,8 @@ ConvPlan plan_conv(int64_t no_cap, int Cin, int Cout, int K, int mode, bool six,
   else if (six && Cin <= 32) sh = T64x64;
   else sh = T128x64;
   const ConvTune t = g_conv_tune;
-  if (t.shape >= 0 && t.shape < N_CONV_SHAPES && (six || t.shape != T64x128)) sh = t.shape;
+  if (t.shape >= 0 && t.shape < N_CONV_SHAPES && (six || t.shape < T64x128) && (t.shape < T256x128 || (six && mode == 1 && t.ws >= 2)))
+    sh = t.shape;
   ConvPlan pl{sh, bms[sh], bns[sh], 1, K, 1};
   if (slices == 1 && has_ws) {
     pl.splits = choose_splits(no_cap, Cout, K, pl.bm, pl.bn, ws_bytes);
@@ -1338,7 +1626,7 @@ ConvPlan plan_conv(int64_t no_cap, int Cin, int Cout, int K, int mode, bool six,
   }
   // two stages of loads in flight where a block is a chain of latency-bound stages: short f16x3 layers (Cin >= 64: the
   // neighbour indices must be two stages ahead of their gathers)
-  const bool pf2_ok = six && mode == 1 && Cin >= 2 * BK && sh != T128x32 && sh != T128x128;    // 128x128 would spill
+  const bool pf2_ok = six && mode == 1 && Cin >= 2 * BK && sh != T128x32 && sh != T128x128 && sh < T256x128;    // 128x128 would spill
   if (pf2_ok && K > 1) pl.pf = no_cap < CONV_PF2_ROWS ? 2 : 1;
   if (t.pf > 0 && pf2_ok) pl.pf = t.pf >= 2 ? 2 : 1;
   return pl;
@@ -1399,12 +1687,19 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     else                                                                                                           \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 0>), grid, dim3(256), 0, st, p, wt); \
   } while (0)
+    const int ws_slots = mode == 1 && in_split == nullptr && shape != T128x32 ? (g_conv_tune.ws >= 0 ? g_conv_tune.ws : CONV_WS_SLOTS) : 0;
+    if (ws_slots >= 2 && g_conv_tune.ablate == 0) {
+      // warp-specialised kernel: 8 waves, dynamic LDS = ring + counters (above 64 KB the limit is raised per kernel)
+      const int rc = launch_conv_ws(shape, ws_slots, has_res, grid, p, wt, st);
+      if (rc != 0) return rc;
+    } else
     switch (shape) {
       case T128x128: CNRMA_CONV6_LAUNCH(2, 2, 2, 2); break;
       case T128x64: CNRMA_CONV6_LAUNCH(4, 1, 1, 2); break;
       case T64x64: CNRMA_CONV6_LAUNCH(2, 2, 1, 1); break;
       case T128x32: CNRMA_CONV6_LAUNCH(4, 1, 1, 1); break;
       case T64x128: CNRMA_CONV6_LAUNCH(2, 2, 1, 2); break;
+      default: return CNRMA_EINVAL;
     }
 #undef CNRMA_CONV6_LAUNCH
     if (p.splits > 1) {
@@ -2416,8 +2711,8 @@ extern "C" int cnrma_debug_conv_tuning(const int* v, int n) {
   // v = {tile shape (0 128x128, 1 128x64, 2 64x64, 3 128x32, 4 64x128), splits over the kernel offsets, prefetch depth}; -1 or
   // missing = the launcher's own choice; n == 0 restores the product configuration.  Host-side global state: A/B runs only.
   ConvTune t;
-  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate};
-  if (n < 0 || n > 4 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate, &t.ws};
+  if (n < 0 || n > 5 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_conv_tune = t;
   return 0;

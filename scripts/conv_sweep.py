@@ -66,14 +66,17 @@ if len(sys.argv) > 2:
     cfgs = []
     for spec in sys.argv[2:]:
         sh, sp, pf, ab = (spec.split(":") + ["0", "0", "0"])[:4]
-        cfgs.append((None if sh in ("auto", "") else sh, int(sp) or -1, int(pf) or -1, int(ab, 0)))
+        ws = -1
+        if ab.startswith("ws"):                      # 4th field "wsN": the warp-specialised kernel with an N-slot ring
+            ws, ab = int(ab[2:]), "0"
+        cfgs.append((None if sh in ("auto", "") else sh, int(sp) or -1, int(pf) or -1, int(ab, 0), ws))
 else:
-    cfgs = [(None, -1, -1, 0)]
+    cfgs = [(None, -1, -1, 0, -1)]
     for sh in ("64x64", "128x64", "64x128", "128x128"):
         for pf in (1, 2):
-            cfgs.append((sh, -1, pf, 0))
+            cfgs.append((sh, -1, pf, 0, -1))
     for sp in (1, 3, 9, 14, 27):
-        cfgs.append((None, sp, -1, 0))
+        cfgs.append((None, sp, -1, 0, -1))
 
 classes = {}
 for c in calls:
@@ -81,25 +84,31 @@ for c in calls:
     key = (c["n_out"], c["x"].F.shape[1], c["ref"].shape[1], K, c["stride"], c["residual"] is not None)
     classes.setdefault(key, c)
 print(f"{wl}: {len(calls)} convolutions, {len(classes)} classes; us per launch ({REPS} back to back)")
-hdr = ["rows", "Cin", "Cout", "K", "s", "res", "plan"] + [f"{a or 'auto'}:{b}:{c_}" + (f":{d:#x}" if d else "") for a, b, c_, d in cfgs]
+hdr = ["rows", "Cin", "Cout", "K", "s", "res", "plan"] + [f"{a or 'auto'}:{b}:{c_}" + (f":{d:#x}" if d else "") + (f":ws{e}" if e >= 0 else "")
+                                                         for a, b, c_, d, e in cfgs]
 print(" | ".join(hdr))
 tot = {i: 0.0 for i in range(len(cfgs))}
 best_tot = 0.0
+only = os.environ.get("ONLY")                         # ONLY=Cin,Cout,K,minrows: restrict the sweep to matching layer classes
 for key, c in sorted(classes.items(), key=lambda kv: -kv[0][0]):
     n_out, Cin, Cout, K, st, res = key
+    if only:
+        oc, oo, ok_, omin = (int(v) for v in only.split(","))
+        if (Cin, Cout, K) != (oc, oo, ok_) or n_out < omin:
+            continue
     mult = sum(1 for d in calls if (d["n_out"], d["x"].F.shape[1], d["ref"].shape[1], d["ks"] ** 3, d["stride"], d["residual"] is not None) == key)
     S.conv_tuning()
     plan = S.conv_plan(n_out, Cin, Cout, K) if Cin % 32 == 0 else None
     ref = run(c).clone()
     row, ts = [], []
-    for i, (sh, sp, pf, ab) in enumerate(cfgs):
+    for i, (sh, sp, pf, ab, ws) in enumerate(cfgs):
         if Cin % 32 != 0 and (sh == "64x128" or pf == 2):
             row.append("   -  ")
             ts.append(float("inf"))
             continue
         if Cout <= 32 and sh is not None:
             sh = None
-        S.conv_tuning(sh, sp, pf, ab)
+        S.conv_tuning(sh, sp, pf, ab, ws)
         try:
             t, out = timed(c)
             err = 0.0 if ab else float((out - ref).abs().max() / (ref.abs().max() + 1e-30))
@@ -115,5 +124,5 @@ for key, c in sorted(classes.items(), key=lambda kv: -kv[0][0]):
     best_tot += ts[b] * mult
     pl = f"{plan['shape']}/{plan['splits']}/{plan['prefetch']}" if plan else "f32"
     print(f"{n_out:7d} {Cin:4d} {Cout:4d} {K:2d} {st} {int(res)} x{mult:2d} {pl:14s} | " + " ".join(row) +
-          f" | best {cfgs[b][0] or 'auto'}:{cfgs[b][1]}:{cfgs[b][2]} {ts[b]:.1f}", flush=True)
+          f" | best {hdr[7 + b]} {ts[b]:.1f}", flush=True)
 print("sum over all launches (us):", " ".join(f"{tot[i]:8.0f}" for i in range(len(cfgs))), "| per-class best:", round(best_tot))

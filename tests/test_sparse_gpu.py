@@ -130,6 +130,44 @@ def test_forced_tile_shapes_and_prefetch_depths_are_bit_identical(device, cin, c
     check(S.SparseTensor(ref, x.cs), oc, np.maximum(of, 0.0), tol=2e-6)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (128, 128), (256, 512)])
+def test_warp_specialised_kernel_is_bit_identical_to_the_stage_kernel(device, cin, cout):
+    """sparse.conv_tuning(ws=N): the 8-wave producer / consumer form of the f16x3 kernel (N-slot LDS ring, per-slot counters
+    instead of block barriers) runs the same stages in the same order -- bit-identical outputs for every tile shape and
+    ring depth, with the fused epilogue (residual + ReLU), with a split over the offsets, on a stride-2 map and on the
+    identity map (K = 1)"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin * 3 + cout)
+    c, f = rand_sparse(rng, n=7000, span=13, C=cin, ts=1)
+    W = torch.from_numpy((rng.randn(27, cin, cout) / np.sqrt(cin * 27)).astype(np.float32)).to(device)
+    W1 = torch.from_numpy((rng.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)).to(device)
+    x = to_st(c, f, 1, device)
+    res = torch.from_numpy(rng.randn(len(c), cout).astype(np.float32)).to(device)
+    try:
+        for shape in ("64x64", "128x64", "64x128", "128x128"):
+            for splits in (1, 9):
+                S.conv_tuning(shape, splits, 1, 0, 0)
+                ref = S.conv(x, W, 3, 1, residual=res, act="relu").F.clone()
+                ref2 = S.conv(x, W, 3, 2).F.clone()
+                ref1 = S.conv(x, W1, 1, 1, act="elu").F.clone()
+                for slots in (2, 3, 4):
+                    S.conv_tuning(shape, splits, 1, 0, slots)
+                    for _ in range(2):
+                        assert torch.equal(S.conv(x, W, 3, 1, residual=res, act="relu").F, ref), (shape, splits, slots)
+                    assert torch.equal(S.conv(x, W, 3, 2).F, ref2), (shape, splits, slots, "stride 2")
+                    got1 = S.conv(x, W1, 1, 1, act="elu")
+                    assert torch.equal(got1.F, ref1), (shape, splits, slots, "K = 1")
+                    assert float(got1.amax.max()) == float(ref1.abs().max())
+                if shape == "128x128":                      # the 256-row tiles exist in the warp-specialised form only (8 consumer waves)
+                    for big in ("256x128", "256x64"):
+                        S.conv_tuning(big, splits, 1, 0, 2)
+                        assert S.conv_plan(x.cs.n, cin, cout, 27)["shape"] == big
+                        assert torch.equal(S.conv(x, W, 3, 1, residual=res, act="relu").F, ref), (big, splits)
+                        assert torch.equal(S.conv(x, W, 3, 2).F, ref2), (big, splits, "stride 2")
+    finally:
+        S.conv_tuning()
+
+
 @pytest.mark.parametrize("cin,cout,n,span", [(64, 64, 6000, 14), (128, 128, 9000, 20), (256, 512, 1500, 9), (64, 128, 20000, 14)])
 def test_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n, span):
     """the gather-once form of the 3x3x3 stride-1 convolution (sparse.GO_CONV: per 64-row tile the distinct input rows are
