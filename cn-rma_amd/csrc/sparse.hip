@@ -387,6 +387,8 @@ struct ConvArgs {
   // pair-list mode (cnrma_sparse_conv_pairs_f16x3): the rows are (output, input) pairs grouped by kernel offset in runs
   // padded to 128 rows; tile_tap[row / 128] = the offset whose weights the run uses, w_taps = offsets in the image
   const int32_t* tile_tap; int w_taps;
+  int xcd_tiles;     // > 0: number of row tiles; block b works on tile (b % 8) * ceil(tiles / 8) + b / 8 -- workgroups are dealt round-
+                     // robin over the 8 XCDs, so each XCD (private L2) then owns one contiguous eighth of the rows
   int ablate;        // diagnostic kernels only (ABL = true; cnrma_debug_conv_tuning): bit 0 no MFMAs, 1 no A loads, 2 no B loads,
                      // 3 no LDS stores, 4 no barriers -- after the first stage; results are then meaningless, only the time counts
 };
@@ -946,7 +948,13 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   __shared__ unsigned mask_s;
 
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
-  const int64_t tile0 = (int64_t)blockIdx.x * BM;
+  int64_t tile_id = blockIdx.x;
+  if (p.xcd_tiles > 0) {
+    const int per = (p.xcd_tiles + 7) >> 3;
+    tile_id = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile_id >= p.xcd_tiles) return;
+  }
+  const int64_t tile0 = tile_id * BM;
   if (tile0 >= n_live) return;
   const int cout0 = blockIdx.y * BN;
   const int zs = blockIdx.z;
@@ -1581,11 +1589,12 @@ int launch_conv_ws(int shape, int slots, bool has_res, dim3 grid, const ConvArgs
   return launch_ws_shape<2>(shape, has_res, grid, p, wt, st);
 }
 
+constexpr int CONV_XCD_ORDER = 0;      // product default of the XCD-aware tile order of the stage kernel -- until measured
 constexpr int CONV_WS_SLOTS = 0;       // product default of the warp-specialised kernel's ring (0: stage kernel) -- until measured
 
 // Debug / A-B switches of the convolution launcher (cnrma_debug_conv_tuning: scripts/conv_sweep.py and the tests that force a
 // variant).  Product code never changes them; -1 = the launcher's own choice.
-struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; int ws = -1; };   // ws: LDS ring slots of the warp-specialised kernel (0 = stage kernel)
+struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; int ws = -1; int xcd = -1; };   // ws: LDS ring slots of the warp-specialised kernel (0 = stage kernel)
 static ConvTune g_conv_tune;
 
 enum ConvShape { T128x128, T128x64, T64x64, T128x32, T64x128, T256x128, T256x64, N_CONV_SHAPES };   // the last two: warp-specialised kernel only
@@ -1658,6 +1667,12 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   p.splits = pl.splits;
   p.k_per_split = pl.k_per_split;
   dim3 grid((unsigned)ceil_div(no_cap, bm), (unsigned)ceil_div(Cout, bn), (unsigned)(slices > 1 ? slices : p.splits));
+  // XCD-aware tile order (stage kernel on prepared weights; the pair-list runs keep their tile_tap order)
+  const int xcd = g_conv_tune.xcd >= 0 ? g_conv_tune.xcd : CONV_XCD_ORDER;
+  if (xcd && weight_split != nullptr && Cin % 32 == 0 && tile_tap == nullptr && grid.x >= 64) {
+    p.xcd_tiles = (int)grid.x;
+    grid.x = (grid.x + 7u) / 8u * 8u;
+  }
   const bool fast = (Cin % 32 == 0) && (Cout % 4 == 0);
   const bool has_res = residual != nullptr && p.splits == 1;   // split layers add the residual in the reduce kernel
   if (weight_split != nullptr && Cin % 32 == 0) {
@@ -2711,8 +2726,8 @@ extern "C" int cnrma_debug_conv_tuning(const int* v, int n) {
   // v = {tile shape (0 128x128, 1 128x64, 2 64x64, 3 128x32, 4 64x128), splits over the kernel offsets, prefetch depth}; -1 or
   // missing = the launcher's own choice; n == 0 restores the product configuration.  Host-side global state: A/B runs only.
   ConvTune t;
-  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate, &t.ws};
-  if (n < 0 || n > 5 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate, &t.ws, &t.xcd};
+  if (n < 0 || n > 6 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_conv_tune = t;
   return 0;

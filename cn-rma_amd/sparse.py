@@ -601,18 +601,19 @@ def conv_plan(n_out, Cin, Cout, K, precision=None, slices=1):
     return dict(tile=(out[0], out[1]), splits=out[2], k_per_split=out[3], prefetch=out[4], shape=CONV_SHAPES[out[5]])
 
 
-def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1):
+def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1):
     """debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): force the tile shape ("128x128", ...), the split count
     and the prefetch depth of every later convolution launch; no arguments = the product configuration"""
     import ctypes
-    if shape is None and splits < 0 and pf < 0 and not ablate and ws < 0:
+    if shape is None and splits < 0 and pf < 0 and not ablate and ws < 0 and xcd < 0:
         call("cnrma_debug_conv_tuning", None, 0)
         return
     # ablate (diagnostic kernels, timing only -- results are wrong): bit 0 no MFMAs, 1 no A loads, 2 no B loads, 3 no LDS
     # stores, 4 no barriers after a block's first stage
     # ws: LDS ring slots of the warp-specialised f16x3 kernel (2..4; 0 = the stage kernel; -1 = the launcher's default)
-    arr = (ctypes.c_int * 5)(CONV_SHAPES.index(shape) if shape is not None else -1, int(splits), int(pf), int(ablate), int(ws))
-    call("cnrma_debug_conv_tuning", arr, 5)
+    # xcd: 1 = each XCD works on one contiguous eighth of the row tiles (0 = tiles dealt round-robin)
+    arr = (ctypes.c_int * 6)(CONV_SHAPES.index(shape) if shape is not None else -1, int(splits), int(pf), int(ablate), int(ws), int(xcd))
+    call("cnrma_debug_conv_tuning", arr, 6)
 
 
 GO_CONV = False      # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): built, parity-tested, measured

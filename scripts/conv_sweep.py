@@ -69,6 +69,8 @@ if len(sys.argv) > 2:
         ws = -1
         if ab.startswith("ws"):                      # 4th field "wsN": the warp-specialised kernel with an N-slot ring
             ws, ab = int(ab[2:]), "0"
+        if ab == "xcd":                              # 4th field "xcd": XCD-aware tile order of the stage kernel
+            ws, ab = -2, "0"
         cfgs.append((None if sh in ("auto", "") else sh, int(sp) or -1, int(pf) or -1, int(ab, 0), ws))
 else:
     cfgs = [(None, -1, -1, 0, -1)]
@@ -84,7 +86,7 @@ for c in calls:
     key = (c["n_out"], c["x"].F.shape[1], c["ref"].shape[1], K, c["stride"], c["residual"] is not None)
     classes.setdefault(key, c)
 print(f"{wl}: {len(calls)} convolutions, {len(classes)} classes; us per launch ({REPS} back to back)")
-hdr = ["rows", "Cin", "Cout", "K", "s", "res", "plan"] + [f"{a or 'auto'}:{b}:{c_}" + (f":{d:#x}" if d else "") + (f":ws{e}" if e >= 0 else "")
+hdr = ["rows", "Cin", "Cout", "K", "s", "res", "plan"] + [f"{a or 'auto'}:{b}:{c_}" + (f":{d:#x}" if d else "") + (f":ws{e}" if e >= 0 else (":xcd" if e == -2 else ""))
                                                          for a, b, c_, d, e in cfgs]
 print(" | ".join(hdr))
 tot = {i: 0.0 for i in range(len(cfgs))}
@@ -108,7 +110,7 @@ for key, c in sorted(classes.items(), key=lambda kv: -kv[0][0]):
             continue
         if Cout <= 32 and sh is not None:
             sh = None
-        S.conv_tuning(sh, sp, pf, ab, ws)
+        S.conv_tuning(sh, sp, pf, ab, max(ws, -1), 1 if ws == -2 else (0 if (sh, sp, pf, ab, ws) != (None, -1, -1, 0, -1) else -1))
         try:
             t, out = timed(c)
             err = 0.0 if ab else float((out - ref).abs().max() / (ref.abs().max() + 1e-30))
