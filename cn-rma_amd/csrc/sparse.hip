@@ -367,13 +367,18 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// Generative transpose: child z (offset bits x fastest) of parent i lands in row 8 * i + morton_child(z).  Parent-major rows
+// in Morton child order (x the most significant bit, as in the voxeliser's row order) keep every 64-row tile of the children
+// a compact 4x4x4-voxel block whenever the parents are compact: what the gather-once convolution needs.
+__device__ __forceinline__ int morton_child(int z) { return ((z & 1) << 2) | (z & 2) | ((z >> 2) & 1); }
+
 struct ConvArgs {
   const float* in; int Cin;
   const int32_t* nbr; int K;
   const float* weight; int Cout;
   const float* scale; const float* shift; const float* residual; int act;
   float* out; int64_t no_cap; const int32_t* no_dev;
-  int slices;        // > 1: generative transpose, slice z uses W[z] and writes rows z*n_live + i
+  int slices;        // > 1: generative transpose, slice z uses W[z] and writes row slices * i + morton_child(z)
   int splits;        // > 1: split over kernel offsets, raw partial sums go to slab[z]
   int k_per_split;
   float* slab;       // [splits][no_cap][Cout]
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   // ---- epilogue.  D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool partial = p.splits > 1;
   float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
-  const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+  const int child = p.slices > 1 ? morton_child(zs) : 0, row_step = p.slices > 1 ? p.slices : 1;   // see slice_out_row()
   const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
   const int act = partial ? 0 : p.act;
 #pragma unroll
@@ -620,7 +625,7 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
           for (int q = 0; q < 4; ++q) {
             const int64_t row = row0 + q + 8 * rg;
             const int64_t rc = row < n_live ? row : n_live - 1;        // clamped, branch-free
-            res[q] = p.residual[(out_base + rc) * Cout + colc];
+            res[q] = p.residual[(rc * row_step + child) * Cout + colc];
           }
         }
 #pragma unroll
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
           v = v + sh;
           if constexpr (HAS_RES) v = v + res[q];
           v = apply_act(v, act);
-          if (col_ok && row < n_live) dst[(out_base + row) * Cout + col] = v;
+          if (col_ok && row < n_live) dst[(row * row_step + child) * Cout + col] = v;
         }
       }
     }
@@ -1193,7 +1198,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   }
   const bool partial = p.splits > 1;
   float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
-  const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+  const int child = p.slices > 1 ? morton_child(zs) : 0, row_step = p.slices > 1 ? p.slices : 1;   // see slice_out_row()
   const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
   const int act = partial ? 0 : p.act;
   float mx = 0.0f;                                                     // largest |output| of this lane (f16x3 consumers)
@@ -1215,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
           for (int q = 0; q < 4; ++q) {
             const int64_t row = row0 + q + 8 * rg;
             const int64_t rc = row < n_live ? row : n_live - 1;        // clamped, branch-free
-            res[q] = p.residual[(out_base + rc) * Cout + colc];
+            res[q] = p.residual[(rc * row_step + child) * Cout + colc];
           }
         }
 #pragma unroll
@@ -1228,8 +1233,8 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
           if constexpr (HAS_RES) v = v + res[q];
           v = apply_act(v, act);
           if (col_ok && row < n_live) {
-            dst[(out_base + row) * Cout + col] = v;
-            if (!partial && p.out_split) store_split(p.out_split, out_base + row, Cout, col, v);
+            dst[(row * row_step + child) * Cout + col] = v;
+            if (!partial && p.out_split) store_split(p.out_split, row * row_step + child, Cout, col, v);
             mx = fmaxf(mx, fabsf(v));
           }
         }
@@ -1427,7 +1432,7 @@ void sparse_conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
 
   const bool partial = p.splits > 1;
   float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
-  const int64_t out_base = p.slices > 1 ? (int64_t)zs * n_live : 0;
+  const int child = p.slices > 1 ? morton_child(zs) : 0, row_step = p.slices > 1 ? p.slices : 1;   // see slice_out_row()
   const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
   const int act = partial ? 0 : p.act;
   float mx = 0.0f;
@@ -1449,7 +1454,7 @@ void sparse_conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
           for (int q = 0; q < 4; ++q) {
             const int64_t row = row0 + q + 8 * rg;
             const int64_t rc = row < n_live ? row : n_live - 1;
-            res[q] = p.residual[(out_base + rc) * Cout + colc];
+            res[q] = p.residual[(rc * row_step + child) * Cout + colc];
           }
         }
 #pragma unroll
@@ -1462,7 +1467,7 @@ void sparse_conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
           if constexpr (HAS_RES) v = v + res[q];
           v = apply_act(v, act);
           if (col_ok && row < n_live) {
-            dst[(out_base + row) * Cout + col] = v;
+            dst[(row * row_step + child) * Cout + col] = v;
             mx = fmaxf(mx, fabsf(v));
           }
         }
@@ -1774,21 +1779,33 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
 // ================================================================================================================
 constexpr int GO_BM = 64;            // output rows per tile
 constexpr int GO_UMAX = 320;         // union rows of one group held in LDS (+ 1 zero row): 2 planes x 64 B x 321 = 41 KB
-constexpr int GO_HASH = 1024;        // per-wave hash slots of the builder
+constexpr int GO_HASH = 2048;        // per-wave hash slots of the builder (>= 27 x 64 entries: a try never fills the set)
 constexpr int GO_HDR = 84;           // ints per tile: [0] groups, then per group {offset mask, first entry, entries}
 constexpr int GO_ROWS = 27 * GO_BM;  // worst case entries per tile (every (row, offset) distinct)
 constexpr int GO_BQ = 4;             // offsets whose weight fragments are in flight / in registers per wave
 
-// one wave per tile: groups of offsets + sorted union lists + local indices
+// one wave per tile: groups of offsets + sorted union lists + local indices.
+//   * the tile's 64 x 27 slice of the neighbour table is contiguous: 27 independent coalesced loads, then registers;
+//   * a group = a range of offsets whose distinct rows fit the LDS image.  A range is tried as a whole: every lane inserts its
+//     entries of the range into a per-wave LDS hash set, the set is compacted with ballots, and if it holds <= GO_UMAX rows
+//     the group is closed; otherwise the range is cut into ceil(1.15 * rows / GO_UMAX) parts that are tried in order
+//     (compact tiles close [0, 27) at the first attempt; a single offset always fits: <= 64 rows);
+//   * insertion without atomics and without a per-offset dependency chain: the set belongs to ONE wave, whose LDS
+//     instructions execute in order, so a round is "read the slot of every pending entry; write where it was empty (the
+//     last writer wins); read back": an entry is placed when the read-back shows its row, else it moves to the next slot.
+//     Entries with the same row share home slot and probe path and move in lockstep, so a row never lands twice;
+//   * closing a group: ranks by counting (each lane ranks its <= 5 entries against the list read 4 at a time: ascending
+//     row order -- neighbours of consecutive Morton rows are then mostly consecutive image rows and the indexed fragment
+//     reads of the convolution stay nearly conflict-free); the rank replaces the key in the set, and the local indices are
+//     read from the slots remembered at insertion.
+constexpr int GO_HASH_BITS = 11;
+static_assert(GO_HASH == 1 << GO_HASH_BITS, "hash size");
 __global__ __launch_bounds__(256) void tile_union_kernel(const int32_t* __restrict__ nbr, int64_t no_cap,
                                                          const int32_t* __restrict__ no_dev, int K,
                                                          int32_t* __restrict__ hdr, int32_t* __restrict__ rows,
-                                                         uint16_t* __restrict__ lidx) {
-  __shared__ int32_t hkey[4][GO_HASH];
-  __shared__ int16_t hval[4][GO_HASH];
-  __shared__ int32_t ulist[4][GO_UMAX];
-  __shared__ int16_t uslot[4][GO_UMAX];
-  __shared__ int32_t ucnt[4];
+                                                         uint16_t* __restrict__ lidx, int ablate) {
+  __shared__ int32_t hkey[4][GO_HASH + 1];                       // + 1: the slot the branch-free "no write" goes to
+  __shared__ __attribute__((aligned(16))) int32_t nloc[4][GO_BM * 27];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int64_t n_live = live_rows(no_cap, no_dev);
@@ -1796,77 +1813,144 @@ __global__ __launch_bounds__(256) void tile_union_kernel(const int32_t* __restri
   if (tile0 >= n_live) return;
   const int rows_here = (int)min((int64_t)GO_BM, n_live - tile0);
   int32_t* hk = hkey[wave];
-  int16_t* hv = hval[wave];
-  int32_t* ul = ulist[wave];
-  int16_t* us = uslot[wave];
+  int32_t* nl = nloc[wave];
+  uint16_t* stage = reinterpret_cast<uint16_t*>(nl);
   int32_t* th = hdr + tile * GO_HDR;
   int32_t* tr = rows + tile * GO_ROWS;
-  uint16_t* tl = lidx + tile * (GO_BM * 27);
-  const int32_t* nb = nbr + tile0 * K;
-  auto clear = [&]() {
-    for (int i = lane; i < GO_HASH; i += 64) { hk[i] = -1; hv[i] = -1; }
-    if (lane == 0) ucnt[wave] = 0;
+  // the tile's table slice [rows_here][27] is flat in memory: 27 coalesced loads, then through LDS so that lane r holds
+  // row r's 27 entries (stride 27 ints: conflict-free).  The buffer becomes the staging area of the local indices.
+  int32_t v[27];
+  {
+    const int32_t* nb = nbr + tile0 * 27;
+    const int total = rows_here * 27;
+    int32_t f[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) f[q] = q * 64 + lane < total ? nb[q * 64 + lane] : -1;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) nl[q * 64 + lane] = f[q];
     __builtin_amdgcn_wave_barrier();
-  };
-  auto find = [&](int32_t v) -> int {                       // slot of v (present)
-    unsigned s = (unsigned)v * 2654435761u >> 22;             // 10 bits
-    while (hk[s] != v) s = (s + 1) & (GO_HASH - 1);
-    return (int)s;
-  };
+#pragma unroll
+    for (int q = 0; q < 27; ++q) v[q] = nl[lane * 27 + q];
+    __builtin_amdgcn_wave_barrier();
+  }
+  int li[27];                                                          // local indices of the lane's row (GO_UMAX = none)
+#pragma unroll
+  for (int q = 0; q < 27; ++q) li[q] = GO_UMAX;
+  unsigned valid_k = 0;
+#pragma unroll
+  for (int q = 0; q < 27; ++q)
+    if (__ballot(v[q] >= 0) != 0ull) valid_k |= 1u << q;
+
   int n_groups = 0, u_begin = 0;
-  unsigned gmask = 0;
-  // close the current group: ranks in ascending row order (neighbours of consecutive Morton rows are then mostly
-  // consecutive image rows: the indexed fragment reads stay nearly conflict-free), rows, local indices, header
-  auto finalize = [&]() {
+  // the ranges still to do are consecutive: `cuts` has bit i set where a range ends after offset i
+  unsigned cuts = 1u << 26;
+  int lo = 0;
+  while (lo < 27) {
+    const int hi = __builtin_ctz(cuts >> lo) + lo + 1;
+    const unsigned rmask = ((hi >= 32 ? 0u : (1u << hi)) - 1u) & ~((1u << lo) - 1u) & valid_k;
+    if (rmask == 0u) { lo = hi; continue; }
+    for (int i = lane; i < GO_HASH; i += 64) hk[i] = -1;
     __builtin_amdgcn_wave_barrier();
-    const int un = ucnt[wave];
-    for (int i = lane; i < un; i += 64) {
-      const int32_t v = ul[i];
-      int rank = 0;
-      for (int j = 0; j < un; ++j) rank += ul[j] < v ? 1 : 0;
-      hv[us[i]] = (int16_t)rank;
-      tr[u_begin + rank] = v;
+    int sl[27];
+    unsigned pend = 0;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      sl[q] = (int)((unsigned)v[q] * 2654435761u >> (32 - GO_HASH_BITS));
+      pend |= (((rmask >> q) & 1u) & (v[q] >= 0 ? 1u : 0u)) << q;
+    }
+    if (ablate & 32) pend = 0;                                         // diagnostics (cnrma_debug_conv_tuning): phases off
+    const int max_rounds = hi - lo > GO_UMAX / GO_BM ? 8 : GO_HASH;    // <= GO_UMAX / 64 offsets always fit and always complete
+    int rounds = 0;
+    // branch-free rounds (the per-entry branches of a masked formulation cost more instructions than the work itself)
+    while (__ballot(pend != 0u) != 0ull && rounds < max_rounds) {
+      int32_t cur[27];
+#pragma unroll
+      for (int q = 0; q < 27; ++q) cur[q] = hk[sl[q]];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 27; ++q) hk[(((pend >> q) & 1u) != 0u && cur[q] == -1) ? sl[q] : GO_HASH] = v[q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 27; ++q) cur[q] = hk[sl[q]];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 27; ++q) {
+        const unsigned pq = (pend >> q) & 1u, ok = cur[q] == v[q] ? 1u : 0u;
+        pend &= ~((pq & ok) << q);
+        sl[q] = (pq & (ok ^ 1u)) ? ((sl[q] + 1) & (GO_HASH - 1)) : sl[q];
+      }
+      ++rounds;
+    }
+    const bool crowded = __ballot(pend != 0u) != 0ull;                 // long probe chains: far more than GO_UMAX rows
+    __builtin_amdgcn_wave_barrier();
+    // image row of a distinct input row = its order of first appearance over (offset, lane): the entry with the smallest
+    // q * 64 + lane among the holders of a slot owns it (an LDS minimum), owners are numbered with ballots
+    const unsigned act = crowded || (ablate & 64) ? 0u : rmask;
+    unsigned own = 0;
+    int cnt = 0;
+    int mypos[27];
+    {
+#pragma unroll
+      for (int q = 0; q < 27; ++q) {
+        const bool mine = ((act >> q) & 1u) != 0u && v[q] >= 0;
+        hk[mine ? sl[q] : GO_HASH] = 0x7fffffff;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 27; ++q) {
+        const bool mine = ((act >> q) & 1u) != 0u && v[q] >= 0;
+        atomicMin(&hk[mine ? sl[q] : GO_HASH], q * 64 + lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 27; ++q) {
+        const bool mine = ((act >> q) & 1u) != 0u && v[q] >= 0;
+        const bool owner = mine && hk[sl[q]] == q * 64 + lane;
+        const unsigned long long bal = __ballot(owner);
+        mypos[q] = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        own |= (owner ? 1u : 0u) << q;
+        cnt += __popcll(bal);
+      }
+    }
+    if (crowded || cnt > GO_UMAX) {
+      // cut the range; its first part runs next.  Up to 2 x GO_UMAX rows: two halves, each tried once more; beyond (a tile
+      // without locality): pieces of GO_UMAX / 64 offsets, which fit whatever their rows are -- a tile costs <= 9 attempts
+      const int len = hi - lo;
+      constexpr int SURE = GO_UMAX / GO_BM;
+      if (!crowded && cnt <= 2 * GO_UMAX - GO_UMAX / 4 && len > 2 * SURE) {
+        cuts |= 1u << (lo + len / 2 - 1);
+      } else {
+        for (int c = lo + SURE; c < hi; c += SURE) cuts |= 1u << (c - 1);
+      }
+      continue;
+    }
+    const int un = cnt;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      const bool owner = ((own >> q) & 1u) != 0u;
+      hk[owner ? sl[q] : GO_HASH] = mypos[q];                          // the set now maps slot -> image row
+      if (owner) tr[u_begin + mypos[q]] = v[q];
     }
     __builtin_amdgcn_wave_barrier();
-    for (int k = 0; k < K; ++k) {
-      if (!((gmask >> k) & 1u)) continue;
-      const int32_t v = lane < rows_here ? nb[lane * K + k] : -1;
-      tl[lane * 27 + k] = v >= 0 ? (uint16_t)hv[find(v)] : (uint16_t)GO_UMAX;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) {
+      const int r = hk[sl[q]];
+      li[q] = (((rmask >> q) & 1u) != 0u && v[q] >= 0) ? r : li[q];
     }
-    if (lane == 0) { th[1 + 3 * n_groups] = (int)gmask; th[2 + 3 * n_groups] = u_begin; th[3 + 3 * n_groups] = un; }
+    if (lane == 0) { th[1 + 3 * n_groups] = (int)rmask; th[2 + 3 * n_groups] = u_begin; th[3 + 3 * n_groups] = un; }
     u_begin += un;
     ++n_groups;
-    gmask = 0;
-  };
-  clear();
-  for (int k = 0; k < K; ++k) {
-    const int32_t v = lane < rows_here ? nb[lane * K + k] : -1;
-    const int nvalid = __popcll(__ballot(v >= 0));
-    if (nvalid == 0) { tl[lane * 27 + k] = (uint16_t)GO_UMAX; continue; }
-    if (ucnt[wave] + nvalid > GO_UMAX && gmask != 0u) { finalize(); clear(); }
-    // phase 1: claim slots (no waiting inside a wave: lanes that lose a race find the key in phase 3)
-    int slot = -1;
-    bool won = false;
-    if (v >= 0) {
-      unsigned s = (unsigned)v * 2654435761u >> 22;
-      while (true) {
-        const int32_t prev = atomicCAS(&hk[s], -1, v);
-        if (prev == -1) { won = true; break; }
-        if (prev == v) break;
-        s = (s + 1) & (GO_HASH - 1);
-      }
-      slot = (int)s;
-    }
+    lo = hi;
     __builtin_amdgcn_wave_barrier();
-    if (won) {                                              // phase 2: the winner numbers the new entry
-      const int idx = atomicAdd(&ucnt[wave], 1);
-      ul[idx] = v;
-      us[idx] = (int16_t)slot;
-    }
-    __builtin_amdgcn_wave_barrier();
-    gmask |= 1u << k;
   }
-  if (gmask != 0u) finalize();
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int q = 0; q < 27; ++q) stage[lane * 27 + q] = (uint16_t)li[q];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(lidx + tile * (GO_BM * 27));      // tile * 3456 bytes: 4-byte aligned
+  for (int i = lane; i < GO_BM * 27 / 2; i += 64) t32[i] = s32[i];
   if (lane == 0) th[0] = n_groups;
 }
 
@@ -2088,19 +2172,19 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
   }
 }
 
-// children coordinates of the generative transposed conv: out[k*n + i] = in[i] + off_k * half, k with x fastest
+// children coordinates of the generative transposed conv: child k (x fastest) of parent i is row 8 * i + morton_child(k)
 __global__ __launch_bounds__(256) void convtr_coords_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
                                                             const int32_t* __restrict__ n_dev, int half,
                                                             int32_t* __restrict__ out_coords) {
   const int64_t n = live_rows(n_cap, n_dev);
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * 8) return;
-  const int k = (int)(t / n);
-  const int64_t i = t - (int64_t)k * n;
+  const int m = (int)(t & 7);                  // Morton rank of the child: x is the most significant bit
+  const int64_t i = t >> 3;
   int4 c = reinterpret_cast<const int4*>(in_coords)[i];
-  c.y += (k & 1) * half;
-  c.z += ((k >> 1) & 1) * half;
-  c.w += ((k >> 2) & 1) * half;
+  c.y += ((m >> 2) & 1) * half;
+  c.z += ((m >> 1) & 1) * half;
+  c.w += (m & 1) * half;
   reinterpret_cast<int4*>(out_coords)[t] = c;
 }
 
@@ -3034,7 +3118,7 @@ extern "C" int cnrma_sparse_tile_union_build(const int32_t* nbr, int64_t no_cap,
   int32_t* rows = reinterpret_cast<int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
   uint16_t* lidx = reinterpret_cast<uint16_t*>(w);
   hipLaunchKernelGGL(tile_union_kernel, dim3((unsigned)ceil_div((int64_t)tiles, 4)), dim3(256), 0, as_stream(stream), nbr, no_cap,
-                     no_dev, K, hdr, rows, lidx);
+                     no_dev, K, hdr, rows, lidx, g_conv_tune.ablate);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

@@ -98,6 +98,8 @@ class CoordSet:
         self.device = coords.device
         self.n_batch = n_batch     # number of scenes in the tensor (the reference is structurally 1 per GPU)
         self.scene_major = n_batch <= 1   # rows of one scene contiguous and scenes in order (set by collate / strided)
+        self.compact = False      # consecutive rows are spatial neighbours (Morton runs): the voxeliser's sets and what is
+                                  # derived from them; selects the gather-once convolution
         self._counts = None
         self._counts_dev = None
         self._map = cmap
@@ -178,6 +180,7 @@ class CoordSet:
                      ptr(out), cap_k, ptr(n_out), ptr(ws), stream())
                 child = CoordSet(out, ns, m, self.n_batch, n=cap_k, n_dev=n_out)
                 child.scene_major = cs.scene_major
+                child.compact = cs.compact            # strided rows are written in the order of their keys
                 cs._children[ns] = child
                 cs, src_C, src_ndev, cap = child, child.C, n_out, cap_k
             return
@@ -199,6 +202,7 @@ class CoordSet:
                 m = None                      # a far over-sized table scatters the probes: rebuild compactly on first use
             child = CoordSet(out[:n], ns_k, m, self.n_batch)
             child.scene_major = cs.scene_major
+            child.compact = cs.compact
             cs._children[ns_k] = child
             cs = child
 
@@ -347,12 +351,16 @@ def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton", n_dev=No
         cap = plan.next_cap(coords.shape[0])
         out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, n_dev, cap)
         plan.watch(n_out, 1, cap)
-        return SparseTensor(out_f[:cap], CoordSet(out_c, 1, m, n=cap, n_dev=n_out)), src[:cap]
+        cs = CoordSet(out_c, 1, m, n=cap, n_dev=n_out)
+        cs.compact = row_order == "morton"
+        return SparseTensor(out_f[:cap], cs), src[:cap]
     out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, n_dev)
     n = _count(n_out, coords.shape[0])[0]
+    cs = CoordSet(out_c[:n], 1, m)
+    cs.compact = row_order == "morton"
     if _train(feats):                     # training: the surviving rows through torch indexing (keeps the graph)
-        return SparseTensor(feats.index_select(0, src[:n].long()), CoordSet(out_c[:n], 1, m)), src[:n]
-    return SparseTensor(out_f[:n], CoordSet(out_c[:n], 1, m)), src[:n]
+        return SparseTensor(feats.index_select(0, src[:n].long()), cs), src[:n]
+    return SparseTensor(out_f[:n], cs), src[:n]
 
 
 def sparse_collate(list_of_coords_feats, voxel_size):
@@ -371,6 +379,7 @@ def sparse_collate(list_of_coords_feats, voxel_size):
         F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
     cs = CoordSet(C, 1, None, len(parts))
     cs.scene_major = True
+    cs.compact = True
     cs._counts = counts
     return SparseTensor(F, cs)
 
@@ -411,6 +420,7 @@ def sparse_collate_static(list_of_coords_feats_ndev, voxel_size):
     total = incl[B - 1:].to(torch.int32).contiguous()
     cs = CoordSet(big_c.index_select(0, src), 1, None, B, n=cap_total, n_dev=total)
     cs.scene_major = True
+    cs.compact = True
     cs._counts_dev = (n.to(torch.int32).contiguous(), excl.to(torch.int32).contiguous())
     return SparseTensor(big_f.index_select(0, src), cs)
 
@@ -616,15 +626,23 @@ def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1):
     call("cnrma_debug_conv_tuning", arr, 6)
 
 
-GO_CONV = False      # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): built, parity-tested, measured
-                     # 1.0-1.2x per backbone layer but its tile-union builds (30-600 us per coordinate set) cost more than that:
-                     # S 184 vs 203 scenes/s -- off by default (DESIGN.md "Gather-once convolution")
+GO_CONV = "auto"     # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): "auto" = on coordinate sets
+                     # whose rows are compact (CoordSet.compact) with >= GO_MIN_ROWS rows; True / False force it (tests, A/B runs)
+GO_MIN_ROWS = 1024   # below: the stage kernel split over the 27 offsets fills the chip better (541-row level: 0.95x)
 PAIR_HDR_BYTES, PAIR_OVERFLOW_WORD = 512, 64 + 34      # csrc/sparse.hip: PAIR_HDR ints, hdr[64 + 34] = "an entry was dropped"
 PAIR_CONV = True     # pair-list kernel for stride-2 convolutions whose kernel map is nearly empty (the stem)
 # regrouping the table costs ~0.2 ms per 450 k output rows (count, plan, fill, reduce: MI355X); the tile kernel wastes
 # 27 x Cin / 32 stages per tile on empty offsets -- measured break-even between Cin = 32 (tile kernel 0.18 ms, pair list
 # 0.29 ms) and Cin = 256 (1.23 ms vs 0.45 ms)
 PAIR_CONV_MIN_CIN = 128
+
+
+def _gather_once(in_cs, out_cs):
+    """3x3x3 stride-1 convolution: the gather-once kernel where the rows are compact (a 64-row tile reads ~250 distinct
+    input rows instead of 64 x ~20) and there are enough of them to fill the chip; GO_CONV True / False force the choice"""
+    if GO_CONV == "auto":
+        return in_cs.compact and out_cs.n >= GO_MIN_ROWS
+    return bool(GO_CONV)
 
 
 def _nearly_empty_map(in_cs, out_cs):
@@ -686,7 +704,7 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
                     # silent: the word joins the plan's status -- copied out, the workspace is reused by the next layer)
                     P.current().watch(pw[:PAIR_HDR_BYTES].view(torch.int32)[PAIR_OVERFLOW_WORD:PAIR_OVERFLOW_WORD + 1].clone(), 0, 0)
                 return SparseTensor(out, out_cs, None, out_amax)
-            if GO_CONV and K == 27 and stride == 1 and Cout >= 64:
+            if K == 27 and stride == 1 and Cout >= 64 and _gather_once(in_cs, out_cs):
                 # gather-once kernel: a tile's distinct input rows staged once per channel slice, offsets run from LDS
                 go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < 65536 else 0
                 go_ws = _workspace(go_ws_bytes, x.device) if go_ws_bytes else None
@@ -813,20 +831,24 @@ def _act_torch(f, act):
 
 def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, precision=None):
     """MinkowskiGenerativeConvolutionTranspose(k=2, s=2): 8 children per parent at half the tensor stride;
-    out row k*N + i = in[i] @ W[k] (k decodes with x fastest)."""
+    out row 8*i + m = in[i] @ W[k]: parent-major, the children in Morton order (m = x<<2 | y<<1 | z for the child offset
+    bits; the weight slice k decodes with x fastest as in the reference's kernel offsets)."""
     _lib.require_gpu()
     if _train(x.F, weight):
         # training: 8 dense GEMMs (no neighbour structure: every parent has all 8 children) through torch / rocBLAS
         n, half = x.cs.n, x.cs.stride // 2
-        k = torch.arange(8, device=x.device)
-        off = torch.stack((torch.zeros_like(k), k & 1, (k >> 1) & 1, (k >> 2) & 1), dim=1).to(torch.int32) * half
-        out_c = (x.C.unsqueeze(0) + off.unsqueeze(1)).reshape(8 * n, 4).contiguous()
-        out_f = torch.einsum("nc,kcd->knd", x.F, weight.float()).reshape(8 * n, weight.shape[2]).float()   # fp32 storage under autocast too
+        m = torch.arange(8, device=x.device)
+        off = torch.stack((torch.zeros_like(m), (m >> 2) & 1, (m >> 1) & 1, m & 1), dim=1).to(torch.int32) * half
+        k_of_m = ((m >> 2) & 1) | (m & 2) | ((m & 1) << 2)
+        out_c = (x.C.unsqueeze(1) + off.unsqueeze(0)).reshape(8 * n, 4).contiguous()
+        out_f = torch.einsum("nc,kcd->nkd", x.F, weight.float()[k_of_m]).reshape(8 * n, weight.shape[2]).float()   # fp32 storage under autocast too
         if scale is not None:
             out_f = out_f * scale
         if shift is not None:
             out_f = out_f + shift
-        return SparseTensor(_act_torch(out_f, act), CoordSet(out_c, half, None, x.cs.n_batch))
+        cs = CoordSet(out_c, half, None, x.cs.n_batch)
+        cs.compact = x.cs.compact
+        return SparseTensor(_act_torch(out_f, act), cs)
     w = weight.contiguous().float()
     K, Cin, Cout = w.shape
     assert K == 8 and x.cs.stride % 2 == 0
@@ -855,9 +877,12 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
         else:
             call("cnrma_sparse_convtr_gen_f32", ptr(x.C), ptr(x.F.contiguous()), n, ptr(x.cs.n_dev), Cin, half, ptr(w), Cout,
                  ptr(scale), ptr(shift), ACT[act], ptr(out_c), ptr(out_f), stream())
-    # the kernels write child k of parent i at row k * n_live + i: the live rows stay contiguous, 8 per parent
+    # the kernels write child m of parent i at row 8 * i + m: the live rows stay contiguous, and 64 consecutive rows are the
+    # children of 8 consecutive parents (compact tiles for the gather-once convolution when the parents' rows are)
     nd = x.cs.n_dev * 8 if x.cs.n_dev is not None else None
-    return SparseTensor(out_f, CoordSet(out_c, half, None, x.cs.n_batch, n_dev=nd), out_split, out_amax)
+    cs = CoordSet(out_c, half, None, x.cs.n_batch, n_dev=nd)
+    cs.compact = x.cs.compact
+    return SparseTensor(out_f, cs, out_split, out_amax)
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -1012,6 +1037,11 @@ def union_add(a, b):
     assert a.cs.stride == b.cs.stride and a.F.shape[1] == b.F.shape[1]
     if a.cs is b.cs:
         return SparseTensor(a.F + b.F, a.cs)
+    if b.cs.n > a.cs.n:
+        # the result keeps the first operand's rows and appends the other's new ones: start from the larger set (in the neck
+        # the generated children, whole 8-blocks) so that the appended tail -- thin, without locality -- stays short.  The
+        # reference's row order is a hash map's; the sum is commutative, bit for bit.
+        a, b = b, a
     na, nb, C = a.cs.n, b.cs.n, a.F.shape[1]
     dev = a.device
     m = CoordMap(na + nb, dev)
@@ -1027,7 +1057,9 @@ def union_add(a, b):
          stream())
     if P.static():
         P.current().watch(n_out, 0, out_cap)
-        return SparseTensor(out_f[:out_cap], CoordSet(out_c, a.cs.stride, m, nbatch, n=out_cap, n_dev=n_out))
+        cs = CoordSet(out_c, a.cs.stride, m, nbatch, n=out_cap, n_dev=n_out)
+        cs.compact = a.cs.compact and b.cs.compact        # a's rows, then b's new ones: two compact runs
+        return SparseTensor(out_f[:out_cap], cs)
     if nbatch > 1:          # row count and rows per scene with ONE device->host read
         live = torch.arange(na + nb, device=dev) < n_out
         scene = out_c[:, 0]
@@ -1038,6 +1070,7 @@ def union_add(a, b):
         n, counts = _count(n_out, na + nb)[0], None
     cs = CoordSet(out_c[:n], a.cs.stride, m, nbatch)
     cs._counts = counts
+    cs.compact = a.cs.compact and b.cs.compact
     if _train(a.F, b.F):            # training: the kernel placed the rows (a's first, then b's new ones); sum through torch
         b_row = cs.neighbours(b.cs, 1, a.cs.stride, method="generic").view(-1).long()
         f = torch.zeros((n, C), dtype=torch.float32, device=dev)
@@ -1081,6 +1114,7 @@ def prune(x, keep_mask, n_keep=None, counts=None):
              stream())
     cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch, n_dev=nd)
     cs._counts = counts
+    cs.compact = x.cs.compact         # order preserved: a thinned-out compact set stays compact
     if _train(x.F):
         return SparseTensor(x.F.index_select(0, torch.nonzero(mask).view(-1)), cs)
     return SparseTensor(out_f, cs, None, x.amax)
