@@ -1987,10 +1987,15 @@ __global__ __launch_bounds__(256) void prep_weights_f16_frag_kernel(const float*
   }
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES>
+// KS = 2 (the 64-column tile): the four waves are 2 column halves x 2 OFFSET halves -- a wave owns all 64 rows x 32 columns for
+// every second offset of the group, so that a weight fragment is fetched by exactly one wave of the block and feeds two row
+// tiles (with 2 x 2 waves over rows x columns every fragment was fetched twice per block and fed one: the vector-memory
+// path, 64 B/clk/CU, carried 16 KB per 192 MFMA cycles); the two partial sums meet in LDS before the epilogue.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int KS = 1>
 __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-  static_assert(BM == GO_BM && WAVES_M * WAVES_N == 4, "tile shape");
+  static_assert(BM == GO_BM && WAVES_M * WAVES_N * KS == 4, "tile shape");
+  static_assert(KS == 1 || (KS == 2 && TM == 2 && TN == 1 && WAVES_M == 1), "offset halves: one wave = 64 rows x 32 columns");
   __shared__ __attribute__((aligned(16))) __bf16 Us[2][(GO_UMAX + 1) * LDK];      // fp16 bit patterns; row GO_UMAX = zeros
   __shared__ uint16_t Ls[GO_BM * 27];
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
@@ -2000,7 +2005,8 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
   const int Cin = p.Cin, Cout = p.Cout;
   const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid / WAVES_N, wc = wid % WAVES_N;
+  const int kg = wid / (WAVES_M * WAVES_N), w2 = wid % (WAVES_M * WAVES_N);
+  const int wr = w2 / WAVES_N, wc = w2 % WAVES_N;
   const float a_scale = f16_scale_for(read_amax(p.in_amax));
   const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
   const int32_t* th = g.hdr + tile * GO_HDR;
@@ -2065,19 +2071,31 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
     for (int grp = 0; grp < n_groups; ++grp) {
       const unsigned mask = (unsigned)th[1 + 3 * grp];
       const int ub = th[2 + 3 * grp], un = th[3 + 3 * grp];
+      unsigned mymask = mask;
+      if constexpr (KS == 2) {                               // every second offset of the group
+        mymask = 0;
+        unsigned m = mask;
+        int r = 0;
+        while (m) {
+          const unsigned low = m & (0u - m);
+          if ((r & 1) == kg) mymask |= low;
+          m ^= low;
+          ++r;
+        }
+      }
       // a ring of GO_BQ offsets' weights in flight (an L2 round trip under load is ~1400 cycles, one offset's MFMAs 192-384:
-      // with the single prefetched offset of the first build every offset waited for its weights -- noMFMA / noB ablations
-      // each removed a third of the kernel); the first ones fly while the union rows are staged
+      // with a single prefetched offset every offset waited for its weights); the first ones fly while the rows are staged
       u32x4_t bq[GO_BQ][TN][2][2];
       int kq[GO_BQ];
-      unsigned rest = mask;
+      unsigned rest = mymask;
 #pragma unroll
       for (int d = 0; d < GO_BQ; ++d) {
         kq[d] = -1;
         if (rest) { kq[d] = __ffs(rest) - 1; rest &= rest - 1u; load_b(bq[d], kq[d], slice); }
       }
-      __syncthreads();                                       // the previous group's fragment reads are done
-      // ---- the union rows of this group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight
+      __syncthreads();                                       // the previous stage's fragment reads are done
+      // ---- the union rows of this group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight (more in
+      // flight, or the row numbers of all batches up front, costs the third wave per SIMD: measured 20-35 % slower)
       const int tasks = un * 8;
       for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
         float4 v[4];
@@ -2122,6 +2140,29 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
     }
   }
 
+  if constexpr (KS == 2) {
+    // the two offset halves meet: each wave hands the row tile it does not finish to its partner through LDS (the images
+    // are dead) and finishes the other -- wave (kg, wc) writes rows 32 * kg .. + 31 of columns 32 * wc .. + 31
+    __syncthreads();
+    float* X = reinterpret_cast<float*>(&Us[0][0]);          // 4 x 4 KB of the 20-KB plane
+    float* mine = X + (wc * 2 + kg) * 1024, *theirs = X + (wc * 2 + (kg ^ 1)) * 1024;
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[1][0][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[0][0][i];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][0][i] += theirs[i * 64 + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[1][0][i] += theirs[i * 64 + lane];
+    }
+  }
+
   // ---- epilogue (as the stage kernel)
   const bool partial = p.splits > 1;
   float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
@@ -2137,6 +2178,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
     const float sh = use_shift ? p.shift[colc] : 0.0f;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
+      if (KS == 2 && a != kg) continue;
       const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
@@ -3186,8 +3228,11 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
     if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
     else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
   } else {
-    if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
-    else hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
+    if (g_conv_tune.pf == 3) {                             // A/B aid: the 2 x 2 waves-over-rows-x-columns form
+      if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
+      else hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
+    } else if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 2, 2, 1, true, 2>), grid, dim3(256), 0, st, p, g, wfrag);
+    else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 2, 2, 1, false, 2>), grid, dim3(256), 0, st, p, g, wfrag);
   }
   if (splits > 1) {
     int64_t rb = ceil_div(no_cap * Cout / 4 + 1, 256);

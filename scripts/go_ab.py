@@ -72,10 +72,12 @@ for c in calls:
     for mask_ in (1, 4, 5):
         S.conv_tuning(None, -1, -1, mask_)
         abl.append(timed(c)[0])
+    S.conv_tuning(pf=3)                      # Cout 64: the 2 x 2 waves-over-rows-x-columns form (every weight fragment fetched twice)
+    t_old = timed(c)[0]
     S.conv_tuning()
     tot[0] += t0
     tot[1] += t1
     print(f"rows={c['n_out']:7d} Cin={Cin:4d} Cout={Cout:4d} res={int(c['residual'] is not None)}  stage {t0:7.1f} us  gather-once {t1:7.1f} us "
-          f"({t0 / t1:.2f}x)  union build {e0.elapsed_time(e1) * 1e3:6.1f} us, groups/tile mean {float(groups.mean()):.2f} max {int(groups.max())}"
+          f"({t0 / t1:.2f}x; 2x2-wave form {t_old:7.1f})  union build {e0.elapsed_time(e1) * 1e3:6.1f} us, groups/tile mean {float(groups.mean()):.2f} max {int(groups.max())}"
           f"  rel.err {err:.1e}  ablate noMFMA/noB/neither {abl[0]:.0f}/{abl[1]:.0f}/{abl[2]:.0f}", flush=True)
 print(f"sum over the {wl} scene's 3x3x3 stride-1 convolutions: stage {tot[0]:.0f} us, gather-once {tot[1]:.0f} us")
