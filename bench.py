@@ -128,7 +128,7 @@ def build_model(C, device, n_classes=18, n_reg=6):
 # stream + the algorithmic work of every convolution (rows, kernel-map pairs)
 # ------------------------------------------------------------------------------------------------------------------
 CONV_CALLS = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_pairs_f16x3",
-              "cnrma_sparse_convtr_gen_f32",
+              "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_convtr_gen_f32",
               "cnrma_sparse_convtr_gen_bf16x6", "cnrma_sparse_convtr_gen_f16x3")
 
 
@@ -136,7 +136,8 @@ class KernelProfile:
     TIMED = ("cnrma_backproject_accum_f32", "cnrma_rma_neus_march_f32", "cnrma_rma_neus_emit_rows_f32",
              "cnrma_sparse_kernel_map_symmetric", "cnrma_sparse_kernel_map_strided", "cnrma_sparse_kernel_map",
              "cnrma_nchw_to_nhwc_f32", "cnrma_sparse_maxpool_f32", "cnrma_voxelize_f32", "cnrma_sample_mask",
-             "cnrma_sparse_stride_coords", "cnrma_sparse_union_add_f32", "cnrma_sparse_instnorm_f32") + CONV_CALLS
+             "cnrma_sparse_stride_coords", "cnrma_sparse_union_add_f32", "cnrma_sparse_instnorm_f32",
+             "cnrma_sparse_tile_union_build") + CONV_CALLS
 
     def __init__(self):
         self.records, self.layers = [], []

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(1024) void scan_tile_offsets(int32_t* __restrict__ 
 
 // phase C: rescan each tile with its offset.  MODE 0: out[i] = exclusive sum (and out[n] = total);
 // MODE 1 (mask -> index): out[i] = in[i] ? rank : -1, n_sel[0] = total.
-template <typename T, int MODE>
+// OWN_OFFSET (n_tiles <= SCAN_TILE, i.e. up to 4 M items): there is no phase B -- every block adds up the sums of the tiles
+// in front of it itself (<= 8 KB from L2), block 0 the grand total as well: two launches per scan instead of three.
+template <typename T, int MODE, bool OWN_OFFSET>
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const T* __restrict__ in, const int32_t* __restrict__ tile_off,
                                                          int32_t* __restrict__ out, int32_t* __restrict__ total_out,
                                                          int64_t n, int64_t n_tiles) {
@@ -64,16 +66,30 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const T* __restrict__ i
     v[j] = scan_load(in, base + j, n);
     s += v[j];
   }
+  int offset, grand = 0;
+  if constexpr (OWN_OFFSET) {
+    const int upto = blockIdx.x == 0 ? (int)n_tiles : (int)blockIdx.x;   // block 0 needs the total (its own offset is 0)
+    int part = 0;
+    for (int i = threadIdx.x; i < upto; i += SCAN_BLOCK) part += tile_off[i];
+    int sum;
+    block_excl_scan<SCAN_BLOCK>(part, smem, &sum);
+    __syncthreads();                                                  // smem is reused below
+    offset = blockIdx.x == 0 ? 0 : sum;
+    grand = sum;
+  } else {
+    offset = tile_off[blockIdx.x];
+    if (blockIdx.x == 0) grand = tile_off[n_tiles];
+  }
   int total;
-  int run = block_excl_scan<SCAN_BLOCK>(s, smem, &total) + tile_off[blockIdx.x];
+  int run = block_excl_scan<SCAN_BLOCK>(s, smem, &total) + offset;
 #pragma unroll
   for (int j = 0; j < SCAN_ITEMS; ++j) {
     if (base + j < n) out[base + j] = (MODE == 0) ? run : (v[j] ? run : -1);
     run += v[j];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (MODE == 0) out[n] = tile_off[n_tiles];
-    if (total_out) total_out[0] = tile_off[n_tiles];
+    if (MODE == 0) out[n] = grand;
+    if (total_out) total_out[0] = grand;
   }
 }
 
@@ -83,9 +99,14 @@ int run_scan(const T* in, int32_t* out, int32_t* total_out, int64_t n, void* wor
   int64_t n_tiles = ceil_div(n > 0 ? n : 1, SCAN_TILE);
   int32_t* tile = reinterpret_cast<int32_t*>(workspace);
   hipLaunchKernelGGL((scan_tile_sums<T>), dim3((unsigned)n_tiles), dim3(SCAN_BLOCK), 0, st, in, tile, n);
-  hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(1024), 0, st, tile, n_tiles);
-  hipLaunchKernelGGL((scan_apply<T, MODE>), dim3((unsigned)n_tiles), dim3(SCAN_BLOCK), 0, st, in, tile, out, total_out,
-                     n, n_tiles);
+  if (n_tiles <= SCAN_TILE) {
+    hipLaunchKernelGGL((scan_apply<T, MODE, true>), dim3((unsigned)n_tiles), dim3(SCAN_BLOCK), 0, st, in, tile, out, total_out,
+                       n, n_tiles);
+  } else {
+    hipLaunchKernelGGL(scan_tile_offsets, dim3(1), dim3(1024), 0, st, tile, n_tiles);
+    hipLaunchKernelGGL((scan_apply<T, MODE, false>), dim3((unsigned)n_tiles), dim3(SCAN_BLOCK), 0, st, in, tile, out, total_out,
+                       n, n_tiles);
+  }
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -201,7 +222,11 @@ struct SampleWs {          // sampler workspace (int32 words)
   int32_t hist2[3][2048];
   int32_t prefix2[3];
   int32_t need2[4];
+  int32_t list_count, pad2;     // top-k indices: the survivors, appended in arrival order ...
+  // ---- everything above is zeroed before a select; the list below is not (list_count bounds what is read)
+  uint64_t list[1024];          // ... as (selection key << 32 | row): ascending = descending score, ties by row
 };
+constexpr size_t SAMPLE_WS_ZEROED = offsetof(SampleWs, list);
 
 __device__ __forceinline__ int key_digit(uint32_t k, int pass) {
   return pass == 0 ? (int)(k >> 21) : (pass == 1 ? (int)((k >> 10) & 2047u) : (int)(k & 1023u));
@@ -331,15 +356,8 @@ __global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __r
     if (h[i]) atomicAdd(&ws->hist2[pass][i], h[i]);
 }
 
-__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
-                                                          const float* __restrict__ scores, uint32_t seed,
-                                                          const uint32_t* __restrict__ seed_dev,
-                                                          const SampleWs* __restrict__ ws, int n_keep,
-                                                          uint8_t* __restrict__ mask) {
-  seed = select_seed(seed, seed_dev);
-  const int64_t M = select_rows(m_dev, m_cap);
-  __shared__ int32_t tie_bound;     // rows with the threshold key are kept when their index <= tie_bound
-  __shared__ int rs[256 / 64 + 1 + 2];
+// index bound of the rows that carry the threshold key: kept when their index <= bound (block-uniform; all threads call)
+__device__ __forceinline__ int32_t select_tie_bound(const SampleWs* __restrict__ ws, int32_t* sh_bound, int* rs) {
   int32_t prefix2[3] = {0, 0, 0};
   if (ws->tie_count > 256) {         // exact: the need-th smallest tie index from the second-level histograms
     int need2 = ws->need[3];
@@ -362,9 +380,22 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
         bound = best;
       }
     }
-    tie_bound = bound;
+    *sh_bound = bound;
   }
   __syncthreads();
+  return *sh_bound;
+}
+
+__global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                          const float* __restrict__ scores, uint32_t seed,
+                                                          const uint32_t* __restrict__ seed_dev,
+                                                          const SampleWs* __restrict__ ws, int n_keep,
+                                                          uint8_t* __restrict__ mask) {
+  seed = select_seed(seed, seed_dev);
+  const int64_t M = select_rows(m_dev, m_cap);
+  __shared__ int32_t sh_bound;      // rows with the threshold key are kept when their index <= tie_bound
+  __shared__ int rs[256 / 64 + 1 + 2];
+  const int32_t tie_bound = select_tie_bound(ws, &sh_bound, rs);
   const bool all = M <= n_keep;
   const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
@@ -376,15 +407,57 @@ __global__ __launch_bounds__(256) void sample_mask_kernel(const int32_t* __restr
     mask[i] = 0;
 }
 
+// top-k INDICES: the kept rows go to a list instead of a mask ...
+__global__ __launch_bounds__(256) void sample_collect_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                             const float* __restrict__ scores, SampleWs* __restrict__ ws,
+                                                             int n_keep) {
+  const int64_t M = select_rows(m_dev, m_cap);
+  __shared__ int32_t sh_bound;
+  __shared__ int rs[256 / 64 + 1 + 2];
+  const int32_t tie_bound = select_tie_bound(ws, &sh_bound, rs);
+  const bool all = M <= n_keep;
+  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = select_key(scores, 0u, (uint32_t)i);
+    if (all || k < key || (k == key && (int32_t)i <= tie_bound)) {
+      const int slot = atomicAdd(&ws->list_count, 1);
+      if (slot < 1024) ws->list[slot] = ((uint64_t)k << 32) | (uint32_t)i;
+    }
+  }
+}
+
+// ... which one workgroup sorts (bitonic, 1024 packed keys in LDS): out[0..min(M, k)) = the rows in descending score order,
+// ties by smaller row -- torch.topk(scores, k)[1]; the slots behind them repeat row 0
+__global__ __launch_bounds__(1024) void topk_sort_kernel(const SampleWs* __restrict__ ws, int k, int64_t* __restrict__ out) {
+  __shared__ uint64_t a[1024];
+  const int t = threadIdx.x;
+  const int n = min(min(ws->list_count, k), 1024);
+  a[t] = t < n ? ws->list[t] : ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const int partner = t ^ stride;
+      if (partner > t) {
+        const bool up = (t & size) == 0;
+        const uint64_t x = a[t], y = a[partner];
+        if ((x > y) == up) { a[t] = y; a[partner] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < k) out[t] = t < n ? (int64_t)(uint32_t)a[t] : 0;
+}
+
 }  // namespace
 
 extern "C" size_t cnrma_sample_workspace_bytes(void) { return sizeof(SampleWs); }
 
+// mask != nullptr: keep-mask; else out_idx: the kept rows in selection order (n_keep <= 1024)
 static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, int n_keep, uint32_t seed,
-                      const uint32_t* seed_dev, uint8_t* mask, void* workspace, hipStream_t st) {
+                      const uint32_t* seed_dev, uint8_t* mask, void* workspace, hipStream_t st, int64_t* out_idx = nullptr) {
   if (m_cap <= 0 || n_keep <= 0 || m_cap >= ((int64_t)1 << 31)) return CNRMA_EINVAL;
   SampleWs* ws = reinterpret_cast<SampleWs*>(workspace);
-  hipError_t e = cnrma_fill_bytes(ws, 0, sizeof(SampleWs), st);
+  hipError_t e = cnrma_fill_bytes(ws, 0, SAMPLE_WS_ZEROED, st);
   if (e != hipSuccess) return -(int)e;
   int blocks = (int)(m_cap / 2048 + 1);
   if (blocks > 1024) blocks = 1024;
@@ -395,8 +468,13 @@ static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, 
   for (int pass = 0; pass < 3; ++pass)        // no-ops unless more than 256 rows carry the threshold key
     hipLaunchKernelGGL(sample_tie_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, pass,
                        ws);
-  hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, ws, n_keep,
-                     mask);
+  if (mask != nullptr) {
+    hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, ws, n_keep,
+                       mask);
+  } else {
+    hipLaunchKernelGGL(sample_collect_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, ws, n_keep);
+    hipLaunchKernelGGL(topk_sort_kernel, dim3(1), dim3(1024), 0, st, ws, n_keep, out_idx);
+  }
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -415,6 +493,14 @@ extern "C" int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, in
                                    void* workspace, void* stream) {
   if (scores == nullptr || n_dev == nullptr) return CNRMA_EINVAL;
   return run_select(n_dev, scores, n_cap, k, 0u, nullptr, mask, workspace, as_stream(stream));
+}
+
+// out_idx[0..k): the rows of the k largest scores in descending score order (ties by smaller row) -- torch.topk(scores,
+// k)[1] -- for k <= 1024; with fewer than k live rows the live rows come first and the remaining slots hold row 0
+extern "C" int cnrma_topk_indices_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, int64_t* out_idx,
+                                      void* workspace, void* stream) {
+  if (scores == nullptr || n_dev == nullptr || out_idx == nullptr || k > 1024) return CNRMA_EINVAL;
+  return run_select(n_dev, scores, n_cap, k, 0u, nullptr, nullptr, workspace, as_stream(stream), out_idx);
 }
 
 extern "C" size_t cnrma_scan_workspace_bytes(int64_t n) {

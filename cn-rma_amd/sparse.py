@@ -1174,18 +1174,24 @@ def topk_mask(scores, k, n_dev=None):
     n = scores.numel()
     mask = torch.empty(n, dtype=torch.uint8, device=scores.device)
     if n_dev is None:
-        key = (scores.device, n)
-        n_dev = _NDEV.get(key)
-        if n_dev is None:
-            if len(_NDEV) > 256:
-                _NDEV.clear()
-            n_dev = _NDEV[key] = torch.full((1,), n, dtype=torch.int32, device=scores.device)
+        n_dev = _n_word(scores.device, n)
     ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=scores.device)
     call("cnrma_topk_mask_f32", ptr(scores), ptr(n_dev), n, int(k), ptr(mask), ptr(ws), stream())
     return mask
 
 
 _NDEV = {}
+
+
+def _n_word(device, n):
+    """device word holding the constant n (cached)"""
+    key = (device, n)
+    w = _NDEV.get(key)
+    if w is None:
+        if len(_NDEV) > 256:
+            _NDEV.clear()
+        w = _NDEV[key] = torch.full((1,), n, dtype=torch.int32, device=device)
+    return w
 
 
 def topk_indices(scores, k, n_dev=None):
@@ -1195,6 +1201,13 @@ def topk_indices(scores, k, n_dev=None):
     With fewer than k live rows (n_dev) the live rows come first, in score order; the remaining slots repeat row 0."""
     scores = scores.contiguous().view(-1).float()
     n = scores.numel()
+    if 0 < k <= 1024 and n > 0:          # one select + one single-workgroup sort of the k survivors (2 + 8 launches, no torch ops)
+        _lib.require_gpu()
+        out = torch.empty(k, dtype=torch.int64, device=scores.device)
+        ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=scores.device)
+        call("cnrma_topk_indices_f32", ptr(scores), ptr(n_dev if n_dev is not None else _n_word(scores.device, n)), n, int(k),
+             ptr(out), ptr(ws), stream())
+        return out
     mask = topk_mask(scores, k, n_dev)
     sel = torch.empty(n, dtype=torch.int32, device=scores.device)
     n_sel = torch.empty(1, dtype=torch.int32, device=scores.device)

@@ -185,6 +185,11 @@ int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t 
  * workspace: cnrma_sample_workspace_bytes(). */
 int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, uint8_t* mask,
                         void* workspace, void* stream);
+/* torch.topk(scores, k)[1] for nms_pre (fcaf3d_head.py:252-256), k <= 1024: the same radix select, the kept rows collected
+ * in a list and sorted by one workgroup -- out_idx[0..min(n, k)) = rows in descending score order (ties -> smaller row),
+ * the slots behind them hold row 0.  workspace: cnrma_sample_workspace_bytes(). */
+int cnrma_topk_indices_f32(const float* scores, const int32_t* n_dev, int64_t n_cap, int k, int64_t* out_idx,
+                           void* workspace, void* stream);
 
 /* a6  depth variant   replaces ray_projection_depth()  ray_marching.py:809-956
  * Every ray emits exactly NUM = max(1, 2*select_grids) candidate slots; count[ray] = number of slots with

@@ -616,7 +616,8 @@ def test_f16x3_all_zero_and_empty_inputs(device):
     assert float((y.F - 0.5).abs().max()) == 0.0 and _amax(y) == 0.5
 
 
-@pytest.mark.parametrize("n,k,live", [(5000, 100, None), (300000, 1000, None), (2000, 500, 320), (64, 64, None)])
+@pytest.mark.parametrize("n,k,live", [(5000, 100, None), (300000, 1000, None), (2000, 500, 320), (64, 64, None),
+                                      (50000, 2000, None), (300000, 1024, None), (900, 1024, None)])
 def test_topk_indices_match_torch_topk(device, n, k, live):
     """decode's nms_pre cut: same rows, same order as torch.topk (ties -> smaller index); with fewer live rows than k the
     live rows come first in score order"""
@@ -631,6 +632,17 @@ def test_topk_indices_match_torch_topk(device, n, k, live):
     ref = torch.sort(s[:m], descending=True, stable=True)[1][:k]
     assert torch.equal(ids[:min(k, m)], ref[:min(k, m)])
     assert bool((ids[min(k, m):] == 0).all())
+
+
+def test_topk_indices_under_heavy_ties(device):
+    """thousands of equal scores across the k-th place: the fused select + sort keeps the smallest rows of the tie"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(5)
+    s = rng.rand(70000).astype(np.float32)
+    s[rng.permutation(70000)[:3000]] = 0.75
+    k = min(1000, int((s > 0.75).sum()) + 500)
+    ids = S.topk_indices(torch.from_numpy(s).to(device), k).cpu().numpy()
+    assert (ids == np.argsort(-s, kind="stable")[:k]).all()
 
 
 def test_topk_mask_is_exact_under_heavy_ties(device):
