@@ -1956,7 +1956,8 @@ __global__ __launch_bounds__(256) void tile_union_kernel(const int32_t* __restri
 
 struct GoArgs {
   const int32_t* hdr; const int32_t* rows; const uint16_t* lidx;
-  int slices_per_split;      // 32-channel slices per blockIdx.z (splits > 1: partial slabs, reduced by conv_reduce_kernel)
+  int slices_per_split;      // 32-channel slices per blockIdx.z (splits > 1: partial slabs, reduced by conv_reduce_kernel ...
+  unsigned* counters;        // ... or, when given, by the last block of each tile: one zeroed word per (row tile, column tile)
 };
 
 // W fp32 [K][Cin][Cout] -> fp16 fragment-order image [2 planes interleaved below][...]: element order
@@ -2163,11 +2164,74 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
     }
   }
 
-  // ---- epilogue (as the stage kernel)
-  const bool partial = p.splits > 1;
-  float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
-  const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
-  const int act = partial ? 0 : p.act;
+  // ---- epilogue (as the stage kernel).  Split over channel slices: every block leaves its partial tile in its slab; with a
+  // counter array (g.counters, zero between launches) the LAST block of a tile to arrive adds the slabs up in slab order --
+  // the sums conv_reduce_kernel forms, bit for bit -- and finishes the tile itself: no reduce launch behind the kernel.
+  // The partial tiles cross XCDs inside one kernel: they are written and read with device-scope accesses, and a release /
+  // acquire fence pair stands around the counter.
+  bool partial = p.splits > 1;
+  float oscale = out_scale;
+  if (partial) {
+    float* slab = p.slab + (int64_t)zs * p.no_cap * Cout;
+    const bool here = g.counters != nullptr;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if (KS == 2 && a != kg) continue;
+        const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
+          if (col < Cout && row < n_live) {
+            const float v = acc[a][b][i] * out_scale;
+            slab[row * Cout + col] = v;
+          }
+        }
+      }
+    }
+    if (!here) return;                                       // conv_reduce_kernel follows
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      unsigned* c = g.counters + (blockIdx.x * gridDim.y + blockIdx.y);
+      const unsigned old = atomicAdd(c, 1u);
+      s_last = old == (unsigned)p.splits - 1u;
+      if (s_last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int64_t slab_stride = p.no_cap * Cout;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if (KS == 2 && a != kg) continue;
+        const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
+          float sum = 0.0f;
+          if (col < Cout && row < n_live) {
+            const float* q = p.slab + row * Cout + col;
+            sum = __builtin_nontemporal_load(q);
+            for (int z = 1; z < p.splits; ++z) sum += __builtin_nontemporal_load(q + (int64_t)z * slab_stride);
+          }
+          acc[a][b][i] = sum;
+        }
+      }
+    }
+    partial = false;
+    oscale = 1.0f;
+  }
+  float* dst = p.out;
+  const bool use_scale = p.scale != nullptr, use_shift = p.shift != nullptr;
+  const int act = p.act;
+  const bool has_res_rt = !HAS_RES && p.residual != nullptr;  // a split launch is instantiated without the residual template
   float mx = 0.0f;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
@@ -2183,7 +2247,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         float res[4];
-        if constexpr (HAS_RES) {
+        if (HAS_RES || has_res_rt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int64_t row = row0 + q + 8 * rg;
@@ -2195,10 +2259,10 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
         for (int q = 0; q < 4; ++q) {
           const int64_t row = row0 + q + 8 * rg;
           float v = acc[a][b][rg * 4 + q];
-          v = v * out_scale;
+          v = v * oscale;
           v = v * sc;
           v = v + sh;
-          if constexpr (HAS_RES) v = v + res[q];
+          if (HAS_RES || has_res_rt) v = v + res[q];
           v = apply_act(v, act);
           if (col_ok && row < n_live) {
             dst[row * Cout + col] = v;
@@ -2208,7 +2272,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
       }
     }
   }
-  if (!partial && p.out_amax != nullptr) {
+  if (p.out_amax != nullptr) {
     __syncthreads();
     block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(&Us[0][0]));
   }
@@ -3188,7 +3252,8 @@ extern "C" int cnrma_sparse_conv_prepare_weights_f16_frag(const float* weight, i
 extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int Cin, const void* tile_union,
                                           const void* weight_frag, int Cout, const float* scale, const float* shift,
                                           const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
-                                          const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream) {
+                                          const int32_t* no_dev, void* workspace, size_t workspace_bytes,
+                                          void* tile_counters, void* stream) {
   if (in_feats == nullptr || in_amax == nullptr || tile_union == nullptr || weight_frag == nullptr || out_feats == nullptr ||
       Cin <= 0 || Cin % BK != 0 || Cout < 64 || no_cap <= 0)
     return CNRMA_EINVAL;
@@ -3222,6 +3287,7 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   g.slices_per_split = (int)ceil_div(ns, splits);
   splits = (int)ceil_div(ns, g.slices_per_split);
   p.splits = splits;
+  g.counters = splits > 1 ? reinterpret_cast<unsigned*>(tile_counters) : nullptr;
   const bool has_res = residual != nullptr && splits == 1;
   dim3 grid((unsigned)tiles, (unsigned)ceil_div(Cout, bn), (unsigned)splits);
   if (bn == 128) {
@@ -3234,7 +3300,7 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
     } else if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 2, 2, 1, true, 2>), grid, dim3(256), 0, st, p, g, wfrag);
     else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 2, 2, 1, false, 2>), grid, dim3(256), 0, st, p, g, wfrag);
   }
-  if (splits > 1) {
+  if (splits > 1 && g.counters == nullptr) {
     int64_t rb = ceil_div(no_cap * Cout / 4 + 1, 256);
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);

@@ -54,6 +54,7 @@ class Plan:
         self._reset()
         self._consts = []          # device constants of the static trace, created by the first (un-captured) static run
         self.workspaces = {}       # grow-only scratch buffers of the static trace (kept alive with the plan)
+        self._counters = {}        # zeroed arrival counters (see counters())
         self._kept = {}            # id -> tensor: buffers the captured launches read through raw pointers but that the
                                    # modules may drop at any time (prepared weight images, folded BatchNorm vectors, fused head
                                    # weights: all cached per module and invalidated on train() / load_state_dict()) -- a graph
@@ -154,6 +155,14 @@ class Plan:
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self.workspaces[device] = buf
+        return buf
+
+    def counters(self, device, words):
+        """zeroed 32-bit words for kernels that count arrivals and leave them zero again (one buffer per plan: the launches
+        of a scene are stream-ordered; scenes in flight have their own plans)"""
+        buf = self._counters.get(device)
+        if buf is None:
+            buf = self._counters[device] = torch.zeros(words, dtype=torch.int32, device=device)
         return buf
 
     def amax_slot(self, device, words):

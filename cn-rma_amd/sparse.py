@@ -452,6 +452,27 @@ def _workspace(nbytes, device):
     return buf
 
 
+_COUNTER_WORDS = 16384
+_COUNTERS = {}
+# split gather-once convolutions: the last block of a tile adds the partial slabs up itself instead of a reduce launch behind
+# the kernel.  Built and measured: 2.5-3.5x SLOWER (11 k rows x 128 -> 128: 48 -> 120-172 us; 2.4 k x 256 -> 256: 44 -> 140-174):
+# the partial tiles cross XCDs inside one kernel, and the device-scope release / acquire fences around the counter write back
+# and invalidate the XCD's L2 for every block.  Off; the reduce launch (9 us) stays.
+GO_INKERNEL_REDUCE = False
+
+
+def _tile_counters(device):
+    """zeroed arrival counters of the split gather-once convolutions (the last block of a tile reduces the slabs and resets
+    its word): per plan inside a static trace, per (device, stream) otherwise"""
+    if P.static():
+        return P.current().counters(device, _COUNTER_WORDS)
+    key = (device, stream())
+    buf = _COUNTERS.get(key)
+    if buf is None:
+        buf = _COUNTERS[key] = torch.zeros(_COUNTER_WORDS, dtype=torch.int32, device=device)
+    return buf
+
+
 # "f16x3":  22-bit operands on the fp16 matrix cores: a 2^s = h + m (two fp16 pieces, power-of-two scale from the tensor's
 #           magnitude), products hh + hm + mh in fp32 -- relative error <= 3 x 2^-22 per product, below the rounding noise
 #           of an fp32 accumulation of the same length; half the matrix work and 2/3 of the LDS traffic of "bf16x6";
@@ -628,6 +649,7 @@ def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1):
 
 GO_CONV = "auto"     # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): "auto" = on coordinate sets
                      # whose rows are compact (CoordSet.compact) with >= GO_MIN_ROWS rows; True / False force it (tests, A/B runs)
+GO_WS_ROWS = 65536   # below: a workspace for the split over channel slices is handed to the kernel (it decides)
 GO_MIN_ROWS = 1024   # below: the stage kernel split over the 27 offsets fills the chip better (541-row level: 0.95x)
 PAIR_HDR_BYTES, PAIR_OVERFLOW_WORD = 512, 64 + 34      # csrc/sparse.hip: PAIR_HDR ints, hdr[64 + 34] = "an entry was dropped"
 PAIR_CONV = True     # pair-list kernel for stride-2 convolutions whose kernel map is nearly empty (the stem)
@@ -706,12 +728,14 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
                 return SparseTensor(out, out_cs, None, out_amax)
             if K == 27 and stride == 1 and Cout >= 64 and _gather_once(in_cs, out_cs):
                 # gather-once kernel: a tile's distinct input rows staged once per channel slice, offsets run from LDS
-                go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < 65536 else 0
+                go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < GO_WS_ROWS else 0
                 go_ws = _workspace(go_ws_bytes, x.device) if go_ws_bytes else None
+                counters = _tile_counters(x.device) if GO_INKERNEL_REDUCE and go_ws_bytes and \
+                    -(-out_cs.n // 64) * -(-Cout // 64) <= _COUNTER_WORDS else None
                 call("cnrma_sparse_conv_go_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin,
                      ptr(tile_union(in_cs, out_cs, kernel_size, in_cs.stride)), ptr(split_weights_f16_frag(weight)), Cout,
                      ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax), out_cs.n, ptr(out_cs.n_dev),
-                     ptr(go_ws), go_ws_bytes, stream())
+                     ptr(go_ws), go_ws_bytes, ptr(counters), stream())
                 return SparseTensor(out, out_cs, None, out_amax)
             call("cnrma_sparse_conv_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin, ptr(nbr), K,
                  ptr(split_weights_f16(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax),

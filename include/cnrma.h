@@ -391,14 +391,18 @@ int cnrma_sparse_conv_f16x3(const float* in_feats, const float* in_amax, int Cin
  * convolution on that pair.  The convolution then stages a tile's union rows once per 32-channel slice and runs the
  * offsets from LDS without barriers; weights come in MFMA-fragment order (cnrma_sparse_conv_prepare_weights_f16_frag,
  * cnrma_sparse_conv_f16_weight_bytes bytes).  Cin % 32 == 0, Cout >= 64.  workspace: as cnrma_sparse_conv_f32 (slabs of the
- * split over channel slices that short layers use). */
+ * split over channel slices that short layers use).  tile_counters (may be NULL): ceil(no_cap / 64) * ceil(Cout / 64) zeroed
+ * 32-bit words owned by the caller's stream; with them the last block of a tile adds the slabs up itself (same order, same
+ * sums as the reduce launch it replaces) and leaves the words zero again.  Measured 2.5-3.5x slower than the reduce launch
+ * (device-scope fences per block: an L2 write-back / invalidate each); the plugin passes NULL. */
 size_t cnrma_sparse_tile_union_bytes(int64_t no_cap);
 int cnrma_sparse_tile_union_build(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K, void* tile_union, void* stream);
 int cnrma_sparse_conv_prepare_weights_f16_frag(const float* weight, int K, int Cin, int Cout, void* weight_frag, void* stream);
 int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int Cin, const void* tile_union,
                                const void* weight_frag, int Cout, const float* scale, const float* shift,
                                const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
-                               const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
+                               const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* tile_counters,
+                               void* stream);
 int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax, int64_t n_cap,
                                   const int32_t* n_dev, int Cin, int half_stride, const void* weight_split, int Cout,
                                   const float* scale, const float* shift, int act, int32_t* out_coords,
