@@ -36,6 +36,7 @@ SIGNATURES = {
     "cnrma_sample_mask": (c_int, [P, L, I, ctypes.c_uint32, P, P, P, P]),
     "cnrma_topk_mask_f32": (c_int, [P, P, L, I, P, P, P]),
     "cnrma_topk_indices_f32": (c_int, [P, P, L, I, P, P, P]),
+    "cnrma_rma_select_records": (c_int, [P, L, P, I, P, L, I, ctypes.c_uint32, P, P, P, P, P, L, P, P, P]),
     "cnrma_rma_depth_count_f32": (c_int, [P, P, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P]),
     "cnrma_rma_depth_emit_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, I, F, I, P, P, P, F, F, F,
                                          P, I, P, I, P, I, L, L, P]),

@@ -699,16 +699,18 @@ static int neus_emit_rows_any(const float* proj_inv, const float* feat_nhwc, con
                                             const float* w_div, float addx, float addy, float addz, float* out_xyz,
                                             int xyz_stride, float* out_w, int w_stride, float* out_feat,
                                             int feat_stride, int32_t* out_sample, void* stream) {
-  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || n_out <= 0 || kept == nullptr || cap <= 0 || records == nullptr ||
-      (feat_nhwc == nullptr && feat_ref == nullptr && out_feat != nullptr))
+  // kept == nullptr: the records are already there (cnrma_rma_select_records) -- only the row emission runs
+  if (V <= 0 || C <= 0 || H <= 0 || W <= 0 || n_out <= 0 || (kept != nullptr && cap <= 0) || records == nullptr ||
+      (kept == nullptr && row_offset != nullptr) || (feat_nhwc == nullptr && feat_ref == nullptr && out_feat != nullptr))
     return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, 1, 1, 1, 1.0f, 0.f, 0.f, 0.f, n_steps, t_one, 0.0f);
   EmitDst d{out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, out_sample, nullptr, w_div, addx, addy, addz};
   const int64_t R = (int64_t)V * H * W;
   hipStream_t st = as_stream(stream);
   int4* rec = reinterpret_cast<int4*>(records);
-  hipLaunchKernelGGL(neus_scatter_records_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, st, R, row_offset,
-                     reinterpret_cast<const int2*>(kept), cap, sel_index, sel_cap, n_out, rec);
+  if (kept != nullptr)
+    hipLaunchKernelGGL(neus_scatter_records_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, st, R, row_offset,
+                       reinterpret_cast<const int2*>(kept), cap, sel_index, sel_cap, n_out, rec);
   if (C % 256 == 0) {      // one wave copies a row's 1-KiB channel vector per instruction
     hipLaunchKernelGGL((neus_emit_rows_kernel<64>), dim3((unsigned)ceil_div(n_out * 64, 256)), dim3(256), 0, st, p, C,
                        proj_inv, feat_nhwc, feat_ref, n_out, n_out_dev, rec, d);

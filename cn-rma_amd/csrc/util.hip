@@ -448,6 +448,66 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const SampleWs* __restr
   if (t < k) out[t] = t < n ? (int64_t)(uint32_t)a[t] : 0;
 }
 
+// ---- the random subset straight from the per-ray sample records (no 72-M-row mask, no 72-M-row index) ----------------
+// Rows are the kept samples of the rays in ray order: ray r owns rows [off[r], off[r+1]).  The keep predicate of the select is
+// a pure function of the row number, so a ray counts its kept rows itself, a scan over the RAYS (12 M, not 72 M rows) places
+// them, and the records are written in the same order the mask + index pair produced.
+__global__ __launch_bounds__(256) void select_count_segments_kernel(int64_t R, const int32_t* __restrict__ off,
+                                                                    const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                                    uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                                    const SampleWs* __restrict__ ws, int n_keep,
+                                                                    int32_t* __restrict__ counts) {
+  seed = select_seed(seed, seed_dev);
+  const int64_t M = select_rows(m_dev, m_cap);
+  __shared__ int32_t sh_bound;
+  __shared__ int rs[256 / 64 + 1 + 2];
+  const int32_t tie_bound = select_tie_bound(ws, &sh_bound, rs);
+  const bool all = M <= n_keep;
+  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  int64_t m0 = off[r], m1 = off[r + 1];
+  if (m1 > M) m1 = M;
+  int c = 0;
+  for (int64_t i = m0; i < m1; ++i) {
+    const uint32_t k = row_hash(seed, (uint32_t)i);
+    c += (all || k < key || (k == key && (int32_t)i <= tie_bound)) ? 1 : 0;
+  }
+  counts[r] = c;
+}
+
+__global__ __launch_bounds__(256) void select_scatter_records_kernel(int64_t R, const int32_t* __restrict__ off,
+                                                                     const int32_t* __restrict__ sel_off,
+                                                                     const int2* __restrict__ kept, int cap,
+                                                                     const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                                     uint32_t seed, const uint32_t* __restrict__ seed_dev,
+                                                                     const SampleWs* __restrict__ ws, int n_keep,
+                                                                     int64_t rec_cap, int4* __restrict__ rec) {
+  seed = select_seed(seed, seed_dev);
+  const int64_t M = select_rows(m_dev, m_cap);
+  __shared__ int32_t sh_bound;
+  __shared__ int rs[256 / 64 + 1 + 2];
+  const int32_t tie_bound = select_tie_bound(ws, &sh_bound, rs);
+  const bool all = M <= n_keep;
+  const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int64_t m0 = off[r];
+  int64_t m1 = off[r + 1];
+  if (m1 > M) m1 = M;
+  int64_t j = sel_off[r];
+  for (int64_t i = m0; i < m1; ++i) {
+    const uint32_t k = row_hash(seed, (uint32_t)i);
+    if (all || k < key || (k == key && (int32_t)i <= tie_bound)) {
+      if (j < rec_cap && i - m0 < cap) {
+        const int2 kv = kept[r * cap + (i - m0)];
+        rec[j] = make_int4((int)r, kv.y, kv.x, 0);
+      }
+      ++j;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cnrma_sample_workspace_bytes(void) { return sizeof(SampleWs); }
@@ -471,6 +531,8 @@ static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, 
   if (mask != nullptr) {
     hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, ws, n_keep,
                        mask);
+  } else if (out_idx == nullptr) {
+    // threshold only: the caller evaluates the keep predicate itself (cnrma_rma_select_records)
   } else {
     hipLaunchKernelGGL(sample_collect_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, ws, n_keep);
     hipLaunchKernelGGL(topk_sort_kernel, dim3(1), dim3(1024), 0, st, ws, n_keep, out_idx);
@@ -493,6 +555,33 @@ extern "C" int cnrma_topk_mask_f32(const float* scores, const int32_t* n_dev, in
                                    void* workspace, void* stream) {
   if (scores == nullptr || n_dev == nullptr) return CNRMA_EINVAL;
   return run_select(n_dev, scores, n_cap, k, 0u, nullptr, mask, workspace, as_stream(stream));
+}
+
+// The random subset of cnrma_sample_mask applied to the march's per-ray sample records: records[j] = {ray, step, weight bits,
+// 0} of the j-th kept row in row order, n_sel[0] = their number (<= n_keep) -- what cnrma_sample_mask + cnrma_mask_to_index
+// + the record scatter of cnrma_rma_neus_emit_rows_f32 produce, without the m_cap-sized mask and index arrays.
+// ray_counts [R], ray_offsets [R + 1]: scratch; scan_ws: cnrma_scan_workspace_bytes(R); sample_ws: cnrma_sample_workspace_bytes().
+extern "C" int cnrma_rma_select_records(const int32_t* row_offset, int64_t R, const void* kept, int cap, const int32_t* m_dev,
+                                        int64_t m_cap, int n_keep, uint32_t seed, const uint32_t* seed_dev, void* sample_ws,
+                                        int32_t* ray_counts, int32_t* ray_offsets, void* scan_ws, int64_t rec_cap,
+                                        void* records, int32_t* n_sel, void* stream) {
+  if (row_offset == nullptr || kept == nullptr || m_dev == nullptr || R <= 0 || cap <= 0 || records == nullptr ||
+      ray_counts == nullptr || ray_offsets == nullptr || n_sel == nullptr)
+    return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int rc = run_select(m_dev, nullptr, m_cap, n_keep, seed, seed_dev, nullptr, sample_ws, st, nullptr);
+  if (rc != 0) return rc;
+  const SampleWs* ws = reinterpret_cast<const SampleWs*>(sample_ws);
+  const unsigned blocks = (unsigned)ceil_div(R, 256);
+  hipLaunchKernelGGL(select_count_segments_kernel, dim3(blocks), dim3(256), 0, st, R, row_offset, m_dev, m_cap, seed, seed_dev,
+                     ws, n_keep, ray_counts);
+  rc = run_scan<int32_t, 0>(ray_counts, ray_offsets, n_sel, R, scan_ws, st);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(select_scatter_records_kernel, dim3(blocks), dim3(256), 0, st, R, row_offset, ray_offsets,
+                     reinterpret_cast<const int2*>(kept), cap, m_dev, m_cap, seed, seed_dev, ws, n_keep, rec_cap,
+                     reinterpret_cast<int4*>(records));
+  CNRMA_LAUNCH_CHECK();
+  return 0;
 }
 
 // out_idx[0..k): the rows of the k largest scores in descending score order (ties by smaller row) -- torch.topk(scores,

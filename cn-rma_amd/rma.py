@@ -277,6 +277,16 @@ class _March:
              float(add[1]), float(add[2]), out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, ptr(out_sample),
              stream())
 
+    def emit_records(self, rec, n_out, n_out_dev, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride,
+                     out_sample=None):
+        """emit_rows for records that are already selected and placed (select_records)"""
+        by_ref = self.feat_ref is not None
+        call("cnrma_rma_neus_emit_rows_ref_f32" if by_ref else "cnrma_rma_neus_emit_rows_f32", ptr(self.pinv),
+             ptr(self.feat_ref) if by_ref else ptr(self.feat), self.V, self.C, self.H, self.W, self.N,
+             self.t_one, None, int(n_out), ptr(n_out_dev), None, 0, None, 0, ptr(rec), ptr(w_div), float(add[0]),
+             float(add[1]), float(add[2]), out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride, ptr(out_sample),
+             stream())
+
     def emit(self, row_offset, sel_index, w_div, add, out_xyz, xyz_stride, out_w, w_stride, out_feat, feat_stride,
              out_sample=None, sel_cap=0, out_cap=0):
         head = (ptr(self.pinv), ptr(self.tsdf), ptr(self.feat), self.V, self.C, self.H, self.W, self.X, self.Y, self.Z,
@@ -322,6 +332,26 @@ def sample_mask_device(m_dev, M, n_keep, seed=None, seed_dev=None):
     ws = torch.empty(_lib.load().cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=m_dev.device)
     call("cnrma_sample_mask", m_dev.data_ptr(), M, int(n_keep), int(seed), ptr(seed_dev), ptr(mask), ptr(ws), stream())
     return mask
+
+
+def select_records(row_offset, kept, m_dev, M, n_keep, rec_cap, seed=None, seed_dev=None):
+    """sample_mask_device + mask_to_index + the record scatter in one go, per ray (cnrma_rma_select_records): the same random
+    subset, records int32 [rec_cap, 4] = {ray, step, weight bits, 0} in row order and their number n_sel int32 [1]"""
+    if seed is None:
+        _SAMPLE_CALLS[0] += 1
+        seed = (0x9E3779B9 * _SAMPLE_CALLS[0] + int(torch.initial_seed())) & 0xFFFFFFFF
+    dev = m_dev.device
+    R = row_offset.numel() - 1
+    lib = _lib.load()
+    rec = torch.empty((int(rec_cap), 4), dtype=torch.int32, device=dev)
+    n_sel = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.cnrma_sample_workspace_bytes(), dtype=torch.uint8, device=dev)
+    cnt = torch.empty(R, dtype=torch.int32, device=dev)
+    off = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    sws = torch.empty(lib.cnrma_scan_workspace_bytes(R), dtype=torch.uint8, device=dev)
+    call("cnrma_rma_select_records", ptr(row_offset), R, ptr(kept), kept.shape[1], m_dev.data_ptr(), int(M), int(n_keep),
+         int(seed), ptr(seed_dev), ptr(ws), ptr(cnt), ptr(off), ptr(sws), int(rec_cap), ptr(rec), ptr(n_sel), stream())
+    return rec, n_sel
 
 
 def _drop_single_sample_views(cnt, wsum, V):
@@ -486,15 +516,18 @@ def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, ori
     if overflow is not None:
         plan.watch(overflow, 0, 0)
     n_keep = int(max_points) if max_points is not None else M_cap
-    mask = sample_mask_device(m_total, M_cap, n_keep, seed=seed, seed_dev=seed_dev)
-    sel, n_sel = mask_to_index(mask)
     cap = min(M_cap, n_keep)
     coords = torch.empty((cap, 3), dtype=torch.float32, device=m.dev)
     feats = torch.empty((cap, m.C), dtype=torch.float32, device=m.dev)
+    sel = None
     if depth:
+        mask = sample_mask_device(m_total, M_cap, n_keep, seed=seed, seed_dev=seed_dev)
+        sel, n_sel = mask_to_index(mask)
         m.emit(off, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C, sel_cap=M_cap, out_cap=cap)
     else:
-        m.emit_rows(off, cap, kept, sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C, n_out_dev=n_sel)
+        # the subset is drawn per ray from the sample records: no M-sized mask, no M-sized index (72 M rows at the north star)
+        rec, n_sel = select_records(off, kept, m_total, M_cap, n_keep, cap, seed=seed, seed_dev=seed_dev)
+        m.emit_records(rec, cap, n_sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
     info = dict(M=m_total, M_selected=n_sel, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m)
     return coords, feats, n_sel, info
 

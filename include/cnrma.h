@@ -155,7 +155,8 @@ int cnrma_rma_neus_rows_backward_f32(const float* grad_out_feat, int grad_stride
                                      const int32_t* row_offset, const void* kept, int cap, const int32_t* sel_index,
                                      const float* w_div, float* grad_feat_nhwc, void* stream);
 /* n_out = capacity of the output (rows of `records`, grid size); n_out_dev (may be NULL) = device word with the live number of
- * output rows (the n_sel of cnrma_mask_to_index); sel_cap = entries of sel_index (rows >= sel_cap are dropped). */
+ * output rows (the n_sel of cnrma_mask_to_index); sel_cap = entries of sel_index (rows >= sel_cap are dropped).
+ * kept == NULL and row_offset == NULL: `records` already holds the rows to emit (cnrma_rma_select_records). */
 int cnrma_rma_neus_emit_rows_f32(const float* proj_inv, const float* feat_nhwc, int V, int C, int H, int W,
                                  int n_steps, float t_one, const int32_t* row_offset, int64_t n_out,
                                  const int32_t* n_out_dev, const void* kept, int cap, const int32_t* sel_index,
@@ -179,6 +180,16 @@ int cnrma_rma_neus_emit_rows_ref_f32(const float* proj_inv, const float* const* 
 size_t cnrma_sample_workspace_bytes(void);
 int cnrma_sample_mask(const int32_t* m_dev, int64_t m_cap, int n_keep, uint32_t seed, const uint32_t* seed_dev,
                       uint8_t* mask, void* workspace, void* stream);
+/* sample_points (ray_marching.py:339-358) on the march's per-ray sample records, without the m_cap-sized mask and index:
+ * the same random subset as cnrma_sample_mask(m_dev, m_cap, n_keep, seed, seed_dev) -- the keep predicate is a function of
+ * the row number -- counted per ray, placed by a scan over the R rays, and written as records[j] = {ray, step, weight bits, 0}
+ * in row order (what cnrma_mask_to_index + the record scatter of cnrma_rma_neus_emit_rows_f32 produce); n_sel[0] = rows
+ * written (<= min(n_keep, rec_cap)).  row_offset [R + 1] = exclusive scan of the march's counts, kept / cap = its records.
+ * Scratch: ray_counts [R], ray_offsets [R + 1], scan_ws cnrma_scan_workspace_bytes(R), sample_ws cnrma_sample_workspace_bytes(). */
+int cnrma_rma_select_records(const int32_t* row_offset, int64_t R, const void* kept, int cap, const int32_t* m_dev,
+                             int64_t m_cap, int n_keep, uint32_t seed, const uint32_t* seed_dev, void* sample_ws,
+                             int32_t* ray_counts, int32_t* ray_offsets, void* scan_ws, int64_t rec_cap, void* records,
+                             int32_t* n_sel, void* stream);
 /* keep-mask of the k largest scores (ties -> smaller index): the row set of torch.topk(scores, k) as used by the
  * pts_threshold pruning (fcaf3d_head.py:131-137) and nms_pre (:252-256), by 3-pass radix select instead of a sort.
  * n = min(n_dev[0], n_cap) (device); mask has n_cap entries, those behind n are set to 0;

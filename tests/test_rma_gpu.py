@@ -372,3 +372,32 @@ def test_dense_traversal_orders_give_identical_volumes(device):
             assert torch.equal(vol, vol0) and torch.equal(cnt, cnt0), kw
     finally:
         rma.dense_tuning()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_select_records_equals_mask_index_scatter(device, name):
+    """the per-ray selection (no M-sized mask / index: cnrma_rma_select_records) emits exactly the rows of
+    sample_mask_device + mask_to_index + the record scatter -- same subset, same order, same values"""
+    from cnrma_amd import rma
+    g = load_golden(name)
+    feats, pinv, tsdf = _scene(g, device)
+    m = rma._March(feats, pinv, tsdf, g["dims"], g["voxel_size"], g["origin"], 300, g["thr"], "neus", 0)
+    cnt, wsum, kept, overflow = m.march()
+    off = rma.exclusive_scan(cnt)
+    M = int(off[-1])
+    m_dev = off[m.R:]
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    assert M > 40
+    for n_keep, cap_extra in ((M // 7, 100), (M + 5, 0), (1, 3), (M // 2, 0)):
+        M_cap = M + cap_extra
+        cap = min(M_cap, n_keep)
+        mask = rma.sample_mask_device(m_dev, M_cap, n_keep, seed=321)
+        sel, n_a = rma.mask_to_index(mask)
+        ca = torch.zeros((cap, 3), device=device); fa = torch.zeros((cap, m.C), device=device); wa = torch.zeros((cap, 1), device=device)
+        m.emit_rows(off, cap, kept, sel, one, (0.5, 0.25, 0.125), ca.data_ptr(), 3, wa.data_ptr(), 1, fa.data_ptr(), m.C, n_out_dev=n_a)
+        rec, n_b = rma.select_records(off, kept, m_dev, M_cap, n_keep, cap, seed=321)
+        cb = torch.zeros((cap, 3), device=device); fb = torch.zeros((cap, m.C), device=device); wb = torch.zeros((cap, 1), device=device)
+        m.emit_records(rec, cap, n_b, one, (0.5, 0.25, 0.125), cb.data_ptr(), 3, wb.data_ptr(), 1, fb.data_ptr(), m.C)
+        n = int(n_a)
+        assert n == int(n_b) == min(M, n_keep)
+        assert torch.equal(ca[:n], cb[:n]) and torch.equal(fa[:n], fb[:n]) and torch.equal(wa[:n], wb[:n])
