@@ -218,10 +218,9 @@ struct SampleWs {          // sampler workspace (int32 words)
   int32_t tie_count, pad;
   int32_t tie_idx[256];
   // more than 256 rows share the threshold key (e.g. thousands of exactly equal scores): a second select over the ROW
-  // INDEX of the tie rows finds the need[3]-th smallest one exactly (passes 3..5 reuse the find kernel)
-  int32_t hist2[3][2048];
+  // INDEX of the tie rows finds the need[3]-th smallest one exactly (sample_tie_select_kernel)
   int32_t prefix2[3];
-  int32_t need2[4];
+  int32_t pad3;
   int32_t list_count, pad2;     // top-k indices: the survivors, appended in arrival order ...
   // ---- everything above is zeroed before a select; the list below is not (list_count bounds what is read)
   uint64_t list[1024];          // ... as (selection key << 32 | row): ascending = descending score, ties by row
@@ -326,53 +325,56 @@ __global__ __launch_bounds__(256) void sample_ties_kernel(const int32_t* __restr
   }
 }
 
-// second-level select, only active when the tie list overflowed: digit histogram of the row index over the tie rows
-__global__ __launch_bounds__(256) void sample_tie_hist_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
-                                                              const float* __restrict__ scores, uint32_t seed,
-                                                              const uint32_t* __restrict__ seed_dev, int pass,
-                                                              SampleWs* __restrict__ ws) {
+// second-level select, only active when the tie list overflowed (more than 256 rows carry the threshold key: thousands of
+// exactly equal scores): the need[3]-th smallest ROW INDEX among the tie rows, by the same 3-digit radix select -- ONE
+// workgroup runs the three passes itself (it used to be three grid-wide launches that were no-ops in all but that case;
+// the case is cheap for score selects -- <= 0.5 M rows -- and does not occur for hashed keys)
+__global__ __launch_bounds__(1024) void sample_tie_select_kernel(const int32_t* __restrict__ m_dev, int64_t m_cap,
+                                                                const float* __restrict__ scores, uint32_t seed,
+                                                                const uint32_t* __restrict__ seed_dev,
+                                                                SampleWs* __restrict__ ws) {
   if (ws->tie_count <= 256) return;
   seed = select_seed(seed, seed_dev);
   __shared__ int h[2048];
-  __shared__ int rs[256 / 64 + 1 + 2];
-  int32_t prefix2[3] = {0, 0, 0};
-  int need = ws->need[3];
-  for (int q = 0; q < pass; ++q) {
-    int nn;
-    resolve_digit(ws->hist2[q], need, &prefix2[q], &nn, rs);
-    need = nn;
-  }
-  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
-  __syncthreads();
+  __shared__ int sh_digit, sh_need;
   const int64_t M = select_rows(m_dev, m_cap);
   const uint32_t key = ((uint32_t)ws->prefix[0] << 21) | ((uint32_t)ws->prefix[1] << 10) | (uint32_t)ws->prefix[2];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    if (select_key(scores, seed, (uint32_t)i) != key) continue;
-    const uint32_t k2 = (uint32_t)i;                         // smaller index = kept first
-    if (key_matches(k2, pass, prefix2)) atomicAdd(&h[key_digit(k2, pass)], 1);
+  int32_t prefix2[3] = {0, 0, 0};
+  int need = ws->need[3];
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = threadIdx.x; i < 2048; i += 1024) h[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < M; i += 1024) {
+      if (select_key(scores, seed, (uint32_t)i) != key) continue;
+      const uint32_t k2 = (uint32_t)i;                         // smaller index = kept first
+      if (key_matches(k2, pass, prefix2)) atomicAdd(&h[key_digit(k2, pass)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                    // first bin whose cumulative count reaches `need`
+      int cum = 0, d = 0, nn = 0;
+      for (int bin = 0; bin < 2048; ++bin) {
+        if (cum < need && cum + h[bin] >= need) { d = bin; nn = need - cum; break; }
+        cum += h[bin];
+      }
+      sh_digit = d; sh_need = nn;
+    }
+    __syncthreads();
+    prefix2[pass] = sh_digit;
+    need = sh_need;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2048; i += 256)
-    if (h[i]) atomicAdd(&ws->hist2[pass][i], h[i]);
+  if (threadIdx.x == 0) { ws->prefix2[0] = prefix2[0]; ws->prefix2[1] = prefix2[1]; ws->prefix2[2] = prefix2[2]; }
 }
 
 // index bound of the rows that carry the threshold key: kept when their index <= bound (block-uniform; all threads call)
 __device__ __forceinline__ int32_t select_tie_bound(const SampleWs* __restrict__ ws, int32_t* sh_bound, int* rs) {
-  int32_t prefix2[3] = {0, 0, 0};
-  if (ws->tie_count > 256) {         // exact: the need-th smallest tie index from the second-level histograms
-    int need2 = ws->need[3];
-    for (int q = 0; q < 3; ++q) {
-      int nn;
-      resolve_digit(ws->hist2[q], need2, &prefix2[q], &nn, rs);
-      need2 = nn;
-    }
-  }
+  (void)rs;
   if (threadIdx.x == 0) {
     // the need smallest indices among the (normally 1, at most 256) rows that carry the threshold key
     const int cnt = min(ws->tie_count, 256), need = ws->need[3];
     int32_t bound = -1;
-    if (ws->tie_count > 256) {
-      bound = (int32_t)(((uint32_t)prefix2[0] << 21) | ((uint32_t)prefix2[1] << 10) | (uint32_t)prefix2[2]);
+    if (ws->tie_count > 256) {         // exact: the need-th smallest tie index (sample_tie_select_kernel)
+      bound = (int32_t)(((uint32_t)ws->prefix2[0] << 21) | ((uint32_t)ws->prefix2[1] << 10) | (uint32_t)ws->prefix2[2]);
     } else {
       for (int r = 0; r < need; ++r) {
         int32_t best = 0x7FFFFFFF;
@@ -525,9 +527,8 @@ static int run_select(const int32_t* m_dev, const float* scores, int64_t m_cap, 
     hipLaunchKernelGGL(sample_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, pass,
                        n_keep, ws);
   hipLaunchKernelGGL(sample_ties_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, n_keep, ws);
-  for (int pass = 0; pass < 3; ++pass)        // no-ops unless more than 256 rows carry the threshold key
-    hipLaunchKernelGGL(sample_tie_hist_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, pass,
-                       ws);
+  hipLaunchKernelGGL(sample_tie_select_kernel, dim3(1), dim3(1024), 0, st, m_dev, m_cap, scores, seed, seed_dev, ws);   // a no-op
+                                                                     // unless more than 256 rows carry the threshold key
   if (mask != nullptr) {
     hipLaunchKernelGGL(sample_mask_kernel, dim3(blocks), dim3(256), 0, st, m_dev, m_cap, scores, seed, seed_dev, ws, n_keep,
                        mask);
