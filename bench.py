@@ -38,16 +38,17 @@ MFMA_F16_PEAK_TFLOPS = 2500.0
 # --pmc runs: FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM" -- + WRITE_SIZE)
 PMC_TRAFFIC = {
     # (workload, kernel) -> (bytes per launch, source): per-kernel sums of the passes / launches (profiles/README.md)
-    ("NS", "dense"): (58.8e9, "profiles/r04_ns_pmc_FETCH_SIZE.csv (x2) + r04_ns_pmc_WRITE_SIZE.csv: 25.79e6 KB x 2 + 7.26e6 KB per "
+    ("NS", "dense"): (58.9e9, "profiles/r04b_ns_pmc_FETCH_SIZE.csv (x2) + r04b_ns_pmc_WRITE_SIZE.csv: 25.83e6 KB x 2 + 7.26e6 KB per "
                               "launch of backproject_accum_pipe_kernel (the same kernel alone: r04_dense_alone_pmc_*.csv, 25.87e6 / "
                               "7.26e6 KB); L2<->fabric traffic, i.e. Infinity Cache + HBM (TCC: 350 M hits / 471 M misses incl. the "
                               "226 M 32-byte write pieces; read hit rate 30 %; the replay simulation scripts/dense_l2sim.cpp puts the "
                               "HBM share at ~19 GB of reads + 7.3 GB of writes)"),
-    ("NS", "conv"): (295.3e6, "profiles/r04_ns_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches "
-                              "(15.06 GB per scene)"),
-    ("S", "dense"): (1.04e9, "profiles/r04_s_pmc_FETCH_SIZE.csv (x2) + r04_s_pmc_WRITE_SIZE.csv"),
-    ("S", "conv"): (190.2e6, "profiles/r04_s_pmc_*: all sparse_conv_bf16x6_kernel instantiations, (2 x fetch + write) / 51 launches "
-                             "(9.70 GB per scene, L2<->fabric: the operands are Infinity-Cache resident)"),
+    ("NS", "conv"): (132.5e6, "profiles/r04b_ns_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
+                              "(2 x fetch + write) / 51 launches (6.76 GB per scene; 15.06 GB before the gather-once kernel)"),
+    ("S", "dense"): (1.04e9, "profiles/r04b_s_pmc_FETCH_SIZE.csv (x2) + r04b_s_pmc_WRITE_SIZE.csv"),
+    ("S", "conv"): (101.6e6, "profiles/r04b_s_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
+                             "(2 x fetch + write) / 51 launches (5.18 GB per scene, L2<->fabric: the operands are Infinity-Cache "
+                             "resident; 9.70 GB before the gather-once kernel)"),
 }
 
 
@@ -655,7 +656,8 @@ def profile_block(wl, block, name):
                          "stream (eager pass outside the timed region)")
     else:
         tr = PMC_TRAFFIC.get((name, "conv"))
-        roof = dict(kernel="sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_f16x3), all launches of one scene",
+        roof = dict(kernel="sparse_conv_go_kernel / sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_go_f16x3, "
+                           "cnrma_sparse_conv_f16x3), all launches of one scene",
                     bound="mfma", achieved=F_alg / 1e9 / conv_ms, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS, traffic=tr[0] if tr else None,
                     traffic_source=tr[1] if tr else None, launch_ms=conv_ms / max(1, len(layers)),

@@ -261,7 +261,8 @@ class SparseTensor:
         """upper bound of |F| as a device scalar: the producing kernel's running maximum, or one pass over F"""
         if self.amax is None:
             n, C = self.F.shape
-            out = torch.zeros(_AMAX_WORDS, dtype=torch.float32, device=self.F.device)
+            # the entry point zeroes the slots itself; an empty tensor's bound is 0
+            out = (torch.empty if n else torch.zeros)(_AMAX_WORDS, dtype=torch.float32, device=self.F.device)
             if n:
                 call("cnrma_absmax_f32", ptr(self.F.contiguous()), n, ptr(self.cs.n_dev), C, ptr(out), stream())
             self.amax = out
