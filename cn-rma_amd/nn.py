@@ -207,3 +207,38 @@ class BasicBlock(nn.Module):
         res = self.downsample(x) if self.downsample is not None else x
         s2, b2 = self.norm2.folded()
         return self.conv2(out, scale=s2, shift=b2, residual=res, act="relu")
+
+
+class Bottleneck(nn.Module):
+    """ME.modules.resnet_block.Bottleneck (MinkowskiEngine v0.5.4, third party, not under /root/reference; the reference
+    selects it for depth 50 / 101, fcaf3d_backbone.py:122-127): conv1(k1) - norm1 - ReLU - conv2(k3, stride) - norm2 - ReLU -
+    conv3(k1, planes -> 4 * planes) - norm3 - (+ shortcut) - ReLU; attribute names conv1..3, norm1..3, downsample.
+    Eval mode: the three BatchNorms fold into the convolution epilogues -- three launches (four with the shortcut branch)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=3):
+        super().__init__()
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=1, dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=stride, dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv3 = MinkowskiConvolution(planes, planes * self.expansion, kernel_size=1, dimension=dimension)
+        self.norm3 = MinkowskiBatchNorm(planes * self.expansion, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        if self.training:
+            out = self.relu(self.norm1(self.conv1(x)))
+            out = self.relu(self.norm2(self.conv2(out)))
+            out = self.norm3(self.conv3(out))
+            res = self.downsample(x) if self.downsample is not None else x
+            return self.relu(S.SparseTensor(out.F + res.F, out.cs))
+        s1, b1 = self.norm1.folded()
+        out = self.conv1(x, scale=s1, shift=b1, act="relu")
+        s2, b2 = self.norm2.folded()
+        out = self.conv2(out, scale=s2, shift=b2, act="relu")
+        res = self.downsample(x) if self.downsample is not None else x
+        s3, b3 = self.norm3.folded()
+        return self.conv3(out, scale=s3, shift=b3, residual=res, act="relu")
+

@@ -236,6 +236,25 @@ def _basic_block(c, f, ts, blk):
     return oc, relu(o + r), ots
 
 
+def _bottleneck(c, f, ts, blk):
+    """ME.modules.resnet_block.Bottleneck (MinkowskiEngine v0.5.4; selected by fcaf3d_backbone.py:122-127 for depth 50 / 101):
+    conv1 k1 - BN - ReLU - conv2 k3 (stride) - BN - ReLU - conv3 k1 (x4 channels) - BN - (+ shortcut) - ReLU"""
+    stride = blk.conv2.stride
+    _, o = conv(c, f, _np(blk.conv1.kernel), 1, 1, ts)
+    o = relu(batch_norm_eval(o, blk.norm1.bn))
+    oc, o = conv(c, o, _np(blk.conv2.kernel), 3, stride, ts)
+    ots = ts * stride
+    o = relu(batch_norm_eval(o, blk.norm2.bn))
+    _, o = conv(oc, o, _np(blk.conv3.kernel), 1, 1, ots)
+    o = batch_norm_eval(o, blk.norm3.bn)
+    if blk.downsample is not None:
+        _, r = conv(c, f, _np(blk.downsample[0].kernel), 1, stride, ts, out_coords=oc)
+        r = batch_norm_eval(r, blk.downsample[1].bn)
+    else:
+        r = np.asarray(f, dtype=np.float64)
+    return oc, relu(o + r), ots
+
+
 def backbone_forward(backbone, coords, feats):
     c, f, ts = np.asarray(coords, dtype=np.int64), np.asarray(feats, dtype=np.float64), 1
     stem = backbone.conv1
@@ -247,7 +266,7 @@ def backbone_forward(backbone, coords, feats):
     outs = []
     for i in range(backbone.n_outs):
         for blk in getattr(backbone, f"layer{i + 1}"):
-            c, f, ts = _basic_block(c, f, ts, blk)
+            c, f, ts = (_bottleneck if hasattr(blk, "conv3") else _basic_block)(c, f, ts, blk)
         outs.append((c, f, ts))
     return outs
 

@@ -10,7 +10,9 @@ from cnrma_amd import nn as snn
 
 from ..registry import BACKBONES
 
-_DEPTHS = {14: (1, 1, 1, 1), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+# depth -> (block, blocks per stage)   (reference :112-127; the Bottleneck depths widen the outputs to 256 / 512 / 1024 / 2048)
+_DEPTHS = {14: (snn.BasicBlock, (1, 1, 1, 1)), 18: (snn.BasicBlock, (2, 2, 2, 2)), 34: (snn.BasicBlock, (3, 4, 6, 3)),
+           50: (snn.Bottleneck, (4, 3, 6, 3)), 101: (snn.Bottleneck, (3, 4, 23, 3))}
 
 
 @BACKBONES.register_module()
@@ -21,8 +23,8 @@ class FCAF3DBackbone(nn.Module):
     def __init__(self, in_channels, depth, n_outs=4):
         super().__init__()
         if depth not in _DEPTHS:
-            # depth 50/101 use ME's Bottleneck block; no shipped config does (all six use depth=34)
             raise ValueError(f"invalid depth={depth}")
+        self.block, layers = _DEPTHS[depth]
         self.fp16_enabled = False
         self.n_outs = n_outs
         self.inplanes = self.INIT_DIM
@@ -33,18 +35,19 @@ class FCAF3DBackbone(nn.Module):
             snn.MinkowskiReLU(inplace=True),
             snn.MinkowskiMaxPooling(kernel_size=2, stride=2, dimension=3))
         for i in range(n_outs):
-            setattr(self, f"layer{i + 1}", self._make_layer(self.PLANES[i], _DEPTHS[depth][i], stride=2))
+            setattr(self, f"layer{i + 1}", self._make_layer(self.PLANES[i], layers[i], stride=2))
 
     def _make_layer(self, planes, blocks, stride):
         """first block strided with a 1x1 strided conv + BN shortcut, then `blocks-1` plain blocks (reference :59-87)"""
+        block, out_planes = self.block, planes * self.block.expansion
         downsample = None
-        if stride != 1 or self.inplanes != planes:
+        if stride != 1 or self.inplanes != out_planes:
             downsample = snn.FusedSequential(
-                snn.MinkowskiConvolution(self.inplanes, planes, kernel_size=1, stride=stride, dimension=3),
-                snn.MinkowskiBatchNorm(planes))
-        layers = [snn.BasicBlock(self.inplanes, planes, stride=stride, downsample=downsample)]
-        self.inplanes = planes
-        layers += [snn.BasicBlock(planes, planes) for _ in range(1, blocks)]
+                snn.MinkowskiConvolution(self.inplanes, out_planes, kernel_size=1, stride=stride, dimension=3),
+                snn.MinkowskiBatchNorm(out_planes))
+        layers = [block(self.inplanes, planes, stride=stride, downsample=downsample)]
+        self.inplanes = out_planes
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     def init_weights(self):

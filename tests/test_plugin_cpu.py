@@ -262,3 +262,25 @@ def test_integration_md_ctypes_stub_matches_the_abi():
         assert len(c.args) == len(_lib.SIGNATURES[c.func.attr][1]), c.func.attr
         seen.add(c.func.attr)
     assert {"cnrma_nchw_to_nhwc_f32", "cnrma_backproject_accum_f32", "cnrma_abi_version"} <= seen
+
+
+@pytest.mark.parametrize("depth,blocks,widths", [(50, (4, 3, 6, 3), (256, 512, 1024, 2048)), (101, (3, 4, 23, 3), (256, 512, 1024, 2048)),
+                                                 (34, (3, 4, 6, 3), (64, 128, 256, 512))])
+def test_backbone_depths_follow_the_reference_table(depth, blocks, widths):
+    """fcaf3d_backbone.py:112-127: BasicBlock for 14 / 18 / 34, ME's Bottleneck (expansion 4) for 50 / 101, ME's parameter names"""
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    bb = FCAF3DBackbone(32, depth)
+    keys = set(bb.state_dict())
+    for i, (n, w) in enumerate(zip(blocks, widths)):
+        layer = getattr(bb, f"layer{i + 1}")
+        assert len(layer) == n
+        last = layer[-1]
+        out = last.conv3.out_channels if depth >= 50 else last.conv2.out_channels
+        assert out == w
+        assert f"layer{i + 1}.0.downsample.0.kernel" in keys and f"layer{i + 1}.0.downsample.1.bn.running_var" in keys
+    if depth >= 50:
+        assert bb.layer1[0].conv1.kernel.shape == (64, 64) and bb.layer1[0].conv2.kernel.shape == (27, 64, 64)
+        assert bb.layer1[0].conv3.kernel.shape == (64, 256) and bb.layer1[1].conv1.kernel.shape == (256, 64)
+        assert {"layer1.0.conv3.kernel", "layer1.0.norm3.bn.weight", "layer3.5.norm2.bn.running_mean"} <= keys
+    with pytest.raises(ValueError):
+        FCAF3DBackbone(32, 20)

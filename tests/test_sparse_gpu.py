@@ -634,6 +634,35 @@ def test_topk_indices_match_torch_topk(device, n, k, live):
     assert bool((ids[min(k, m):] == 0).all())
 
 
+def test_bottleneck_backbone_vs_oracle(device):
+    """FCAF3DBackbone(depth=50): ME's Bottleneck blocks (1x1 - 3x3 strided - 1x1 x4, fcaf3d_backbone.py:122-124) against the fp64
+    oracle: coordinate sets bit-exact, every feature within 1e-5 of the level's largest (abs or rel; achieved 2e-6 -- 50
+    convolutions with random weights drive |f| to ~1e3, so the bound is taken on the features scaled to unit maximum)"""
+    from cnrma_amd import sparse as S
+    from projects.mvsdetection.models.fcaf3d_backbone import FCAF3DBackbone
+    rng = np.random.RandomState(12)
+    pts = rng.rand(6000, 3).astype(np.float32) * np.array([0.9, 0.7, 0.5], dtype=np.float32) - 0.1
+    pts[:2000, 2] = -0.1 + 0.01 * rng.rand(2000)
+    feats = rng.randn(6000, 16).astype(np.float32)
+    backbone = FCAF3DBackbone(16, 50)
+    _randomise(backbone, 3)
+    backbone.eval()
+    Cq, Fq, _ = RO.voxelize(torch.from_numpy(pts), torch.from_numpy(feats), 0.01)
+    levels = SO.backbone_forward(backbone, Cq.numpy(), Fq.numpy())
+    backbone.to(device)
+    with torch.no_grad():
+        x, _ = S.voxelize(torch.from_numpy(pts).to(device), torch.from_numpy(feats).to(device), 0.01)
+        outs = backbone(x)
+    assert [o.F.shape[1] for o in outs] == [256, 512, 1024, 2048]
+    for o, (c, f, ts) in zip(outs, levels):
+        check(o, c, f, tol=2e-4, same_order=False)
+        c1, f1 = sort_rows(o.C.cpu().numpy().astype(np.int64), o.F.cpu().numpy())
+        f2 = sort_rows(c, f)[1]
+        m = float(np.abs(f2).max())
+        assert elementwise_error(f1 / m, f2 / m) <= 1e-5
+        assert o.cs.stride == ts
+
+
 def test_topk_indices_under_heavy_ties(device):
     """thousands of equal scores across the k-th place: the fused select + sort keeps the smallest rows of the tie"""
     from cnrma_amd import sparse as S
