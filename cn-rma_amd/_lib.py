@@ -53,6 +53,7 @@ SIGNATURES = {
     "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, L, P, P, P]),
     "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
     "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, P]),
+    "cnrma_sparse_kernel_map_children": (c_int, [P, L, P, P, P]),
     "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, P]),
     "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
     "cnrma_sparse_conv_plan": (c_int, [L, I, I, I, I, I, c_size_t, P]),

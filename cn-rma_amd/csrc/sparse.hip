@@ -2891,6 +2891,36 @@ extern "C" int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t 
   return 0;
 }
 
+// 3x3x3 table of a GENERATED child set (conv_transpose_generative: all 8 children of every parent, child m of parent p at
+// row 8 p + m, m = x << 2 | y << 1 | z) from the parents' own 3x3x3 table: the neighbour of child d at offset o is child
+// (d + o) mod 2 of the parent at offset floor((d + o) / 2), per axis -- no hash table, no probes, one streaming pass
+__global__ __launch_bounds__(256) void kernel_map_children_kernel(const int32_t* __restrict__ parent_nbr, int64_t np_cap,
+                                                                  const int32_t* __restrict__ np_dev,
+                                                                  int32_t* __restrict__ nbr) {
+  const int64_t n = live_rows(np_cap, np_dev) * 8;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * 27) return;
+  const int64_t t = e / 27;
+  const int k = (int)(e - t * 27);
+  const int64_t p = t >> 3;
+  const int m = (int)(t & 7);
+  const int sx = ((m >> 2) & 1) + k % 3 - 1, sy = ((m >> 1) & 1) + (k / 3) % 3 - 1, sz = (m & 1) + k / 9 - 1;   // in {-1, 0, 1, 2}
+  const int px = (sx + 2) / 2 - 1, py = (sy + 2) / 2 - 1, pz = (sz + 2) / 2 - 1;                                  // floor(s / 2)
+  const int kp = (pz + 1) * 9 + (py + 1) * 3 + (px + 1);
+  const int mc = ((sx & 1) << 2) | ((sy & 1) << 1) | (sz & 1);
+  const int32_t j = parent_nbr[p * 27 + kp];
+  nbr[e] = j >= 0 ? 8 * j + mc : -1;
+}
+
+extern "C" int cnrma_sparse_kernel_map_children(const int32_t* parent_nbr, int64_t np_cap, const int32_t* np_dev, int32_t* nbr,
+                                                void* stream) {
+  if (parent_nbr == nullptr || nbr == nullptr || np_cap <= 0 || np_cap * 8 * 27 >= ((int64_t)1 << 40)) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(kernel_map_children_kernel, dim3((unsigned)ceil_div(np_cap * 8 * 27, 256)), dim3(256), 0, as_stream(stream),
+                     parent_nbr, np_cap, np_dev, nbr);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev,
                                                int in_stride, int kernel_size, const uint64_t* out_hash_keys,
                                                const int32_t* out_hash_vals, int64_t hash_cap, int32_t* nbr,

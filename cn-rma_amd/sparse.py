@@ -106,6 +106,7 @@ class CoordSet:
         self._nbr = {}        # (kernel_size, id(out CoordSet)) -> nbr table
         self._union = {}      # same key -> tile unions of that table (gather-once convolution)
         self._children = {}   # new_stride -> CoordSet
+        self._gen_parent = None   # set by conv_transpose_generative: the parent set whose 8 children per row these rows are
         self._offsets = {}
 
     def batch_counts(self):
@@ -216,8 +217,14 @@ class CoordSet:
             K = offs.shape[0]
             nbr = torch.empty((out_set.n, K), dtype=torch.int32, device=self.device)
             strided = out_set is not self and out_set.stride == 2 * self.stride and offset_stride == self.stride
+            par = self._gen_parent
             if out_set.n == 0 or self.n == 0:
                 nbr.fill_(-1)
+            elif method == "auto" and out_set is self and kernel_size == 3 and par is not None and \
+                    offset_stride == self.stride and self.n == 8 * par.n:
+                # a generated child set: its table follows from the parents' own 3x3x3 table (no hash map of this set at all)
+                call("cnrma_sparse_kernel_map_children", ptr(par.neighbours(par, 3, par.stride)), par.n, ptr(par.n_dev), ptr(nbr),
+                     stream())
             elif method == "auto" and out_set is self and kernel_size % 2 == 1 and kernel_size > 1:
                 m = self.cmap
                 call("cnrma_sparse_kernel_map_symmetric", ptr(self.C), self.n, ptr(self.n_dev), ptr(m.keys), ptr(m.vals), m.cap,
@@ -873,6 +880,7 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
             out_f = out_f + shift
         cs = CoordSet(out_c, half, None, x.cs.n_batch)
         cs.compact = x.cs.compact
+        cs._gen_parent = x.cs
         return SparseTensor(_act_torch(out_f, act), cs)
     w = weight.contiguous().float()
     K, Cin, Cout = w.shape
@@ -907,6 +915,7 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
     nd = x.cs.n_dev * 8 if x.cs.n_dev is not None else None
     cs = CoordSet(out_c, half, None, x.cs.n_batch, n_dev=nd)
     cs.compact = x.cs.compact
+    cs._gen_parent = x.cs
     return SparseTensor(out_f, cs, out_split, out_amax)
 
 

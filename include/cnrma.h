@@ -304,6 +304,12 @@ int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t n_cap, cons
 int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int in_stride,
                                     int kernel_size, const uint64_t* out_hash_keys, const int32_t* out_hash_vals,
                                     int64_t hash_cap, int32_t* nbr, int64_t no_cap, void* stream);
+/* _children: the 3x3x3 stride-1 table of the set cnrma_sparse_convtr_gen_* generates (fcaf3d_head.py:61-70 up blocks: all 8
+ *             children of every parent, child m of parent p at row 8 p + m) from the PARENTS' 3x3x3 table parent_nbr
+ *             [np_cap][27]: nbr[8 p + m][k] = 8 * parent_nbr[p][k'] + m' with (k', m') the parent offset / child rank of
+ *             child m displaced by offset k -- no hash table, no probes.  nbr [8 * np_cap][27]. */
+int cnrma_sparse_kernel_map_children(const int32_t* parent_nbr, int64_t np_cap, const int32_t* np_dev, int32_t* nbr,
+                                     void* stream);
 
 /* fused sparse convolution, output-stationary gather-GEMM on fp32 MFMA:
  *   out[o] = act( (sum_k in[nbr[o][k]] @ W[k]) * scale + shift + residual[o] )

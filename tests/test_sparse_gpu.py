@@ -799,3 +799,24 @@ def test_voxelize_reports_out_of_range_coordinates(device):
         p[17, 1] = bad
         with pytest.raises(_lib.CnrmaError):
             S.voxelize(p, f, 0.01)
+
+
+def test_generated_children_table_from_the_parents_table(device):
+    """the 3x3x3 table of a generated child set derived from the parents' table (cnrma_sparse_kernel_map_children) equals the
+    table the hash-map builder produces for the same rows, entry for entry"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(21)
+    c, f = rand_sparse(rng, n=3000, span=9, C=32, ts=4)
+    c[:, 1:] -= 16                                              # negative coordinates as well
+    W = torch.from_numpy((rng.randn(8, 32, 32) / 8).astype(np.float32)).to(device)
+    y = S.conv_transpose_generative(to_st(c, f, 4, device), W)
+    assert y.cs._gen_parent is not None and y.cs.stride == 2
+    got = y.cs.neighbours(y.cs, 3, 2)
+    plain = S.CoordSet(y.C.clone(), 2)
+    exp = plain.neighbours(plain, 3, 2)
+    assert torch.equal(got, exp)
+    # and a convolution over it matches the oracle
+    W3 = (rng.randn(27, 32, 64) / 30).astype(np.float32)
+    oc, of = SO.conv_transpose_generative(c, f, W.cpu().numpy(), 4)
+    _, o3 = SO.conv(oc, of, W3, 3, 1, 2)
+    check(S.conv(y, torch.from_numpy(W3).to(device), 3, 1), oc, o3, tol=2e-6, same_order=False)
