@@ -51,6 +51,7 @@ SIGNATURES = {
     "cnrma_voxelize_f32": (c_int, [P, P, L, P, I, F, I, I, P, P, L, P, P, P, L, P, P, P]),
     "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, P]),
     "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, L, P, P, P]),
+    "cnrma_sparse_stride_coords_sorted": (c_int, [P, L, P, I, P, L, P, P, P]),
     "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
     "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, P]),
     "cnrma_sparse_kernel_map_children": (c_int, [P, L, P, P, P]),

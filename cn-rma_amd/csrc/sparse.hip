@@ -2868,6 +2868,58 @@ extern "C" int cnrma_sparse_stride_coords(const int32_t* in_coords, int64_t n_ca
                        nullptr, n_out, workspace, as_stream(stream), false, out_cap);
 }
 
+// ---- strided coordinates of a set whose rows are SORTED by morton_key (the voxeliser's row order and everything strided from
+// it): the parents' keys are non-decreasing along the rows, so "first row of its parent" is an adjacent comparison -- no
+// hash table, no atomics (cnrma_sparse_stride_coords inserts every input row, ~6 per parent, with an atomic minimum each)
+__global__ __launch_bounds__(256) void stride_sorted_flag_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
+                                                                 const int32_t* __restrict__ n_dev, int new_stride,
+                                                                 uint8_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cap) return;
+  uint8_t f = 0;
+  if (i < live_rows(n_cap, n_dev)) {
+    int b, x, y, z;
+    quantise<1>(in_coords, i, 1.0f, new_stride, 0, &b, &x, &y, &z);
+    f = 1;
+    if (i > 0) {
+      int b0, x0, y0, z0;
+      quantise<1>(in_coords, i - 1, 1.0f, new_stride, 0, &b0, &x0, &y0, &z0);
+      f = (b != b0 || x != x0 || y != y0 || z != z0) ? 1 : 0;
+    }
+  }
+  flag[i] = f;
+}
+
+__global__ __launch_bounds__(256) void stride_sorted_write_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
+                                                                  const int32_t* __restrict__ n_dev, int new_stride,
+                                                                  const int32_t* __restrict__ idx,
+                                                                  int32_t* __restrict__ out_coords, int64_t out_cap) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= live_rows(n_cap, n_dev)) return;
+  const int32_t j = idx[i];
+  if (j < 0 || j >= out_cap) return;              // beyond the planned capacity: dropped (n_out says so)
+  int b, x, y, z;
+  quantise<1>(in_coords, i, 1.0f, new_stride, 0, &b, &x, &y, &z);
+  reinterpret_cast<int4*>(out_coords)[j] = make_int4(b, x, y, z);
+}
+
+extern "C" int cnrma_sparse_stride_coords_sorted(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int new_stride,
+                                                 int32_t* out_coords, int64_t out_cap, int32_t* n_out, void* workspace,
+                                                 void* stream) {
+  if (new_stride <= 0 || n_cap <= 0 || in_coords == nullptr || out_coords == nullptr || n_out == nullptr) return CNRMA_EINVAL;
+  if (out_cap <= 0 || out_cap > n_cap) out_cap = n_cap;
+  hipStream_t st = as_stream(stream);
+  UniqueWs w = carve_unique_ws(workspace, n_cap);
+  const unsigned nb = (unsigned)ceil_div(n_cap, 256);
+  hipLaunchKernelGGL(stride_sorted_flag_kernel, dim3(nb), dim3(256), 0, st, in_coords, n_cap, n_dev, new_stride, w.flag);
+  int rc = cnrma_mask_to_index(w.flag, w.idx, n_out, n_cap, w.scan, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(stride_sorted_write_kernel, dim3(nb), dim3(256), 0, st, in_coords, n_cap, n_dev, new_stride, w.idx,
+                     out_coords, out_cap);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int32_t* no_dev,
                                        const uint64_t* in_hash_keys, const int32_t* in_hash_vals, int64_t hash_cap,
                                        const int32_t* offsets, int K, int32_t* nbr, void* stream) {

@@ -100,6 +100,8 @@ class CoordSet:
         self.scene_major = n_batch <= 1   # rows of one scene contiguous and scenes in order (set by collate / strided)
         self.compact = False      # consecutive rows are spatial neighbours (Morton runs): the voxeliser's sets and what is
                                   # derived from them; selects the gather-once convolution
+        self.sorted = False       # the rows are ONE run in ascending Morton key (voxeliser, strided sets, generated children,
+                                  # pruned subsets): strided coordinates then need no hash table
         self._counts = None
         self._counts_dev = None
         self._map = cmap
@@ -176,22 +178,33 @@ class CoordSet:
                 out = torch.empty((cap, 4), dtype=torch.int32, device=self.device)
                 n_out = torch.empty(1, dtype=torch.int32, device=self.device)
                 cap_k = plan.next_cap(cap, n_out)
-                m = CoordMap(cap_k, self.device)
-                call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap,
-                     ptr(out), cap_k, ptr(n_out), ptr(ws), stream())
+                if cs.sorted:                         # adjacent comparison instead of a hash insert per input row
+                    m = None
+                    call("cnrma_sparse_stride_coords_sorted", ptr(src_C), cap, ptr(src_ndev), ns, ptr(out), cap_k, ptr(n_out),
+                         ptr(ws), stream())
+                else:
+                    m = CoordMap(cap_k, self.device)
+                    call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap,
+                         ptr(out), cap_k, ptr(n_out), ptr(ws), stream())
                 child = CoordSet(out, ns, m, self.n_batch, n=cap_k, n_dev=n_out)
                 child.scene_major = cs.scene_major
                 child.compact = cs.compact            # strided rows are written in the order of their keys
+                child.sorted = cs.sorted
                 cs._children[ns] = child
                 cs, src_C, src_ndev, cap = child, child.C, n_out, cap_k
             return
         for _ in range(levels):
             ns *= factor
-            m = CoordMap(cap, self.device)
             out = torch.empty((cap, 4), dtype=torch.int32, device=self.device)
             n_out = torch.empty(1, dtype=torch.int32, device=self.device)
-            call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
-                 0, ptr(n_out), ptr(ws), stream())
+            if cs.sorted:
+                m = None
+                call("cnrma_sparse_stride_coords_sorted", ptr(src_C), cap, ptr(src_ndev), ns, ptr(out), 0, ptr(n_out), ptr(ws),
+                     stream())
+            else:
+                m = CoordMap(cap, self.device)
+                call("cnrma_sparse_stride_coords", ptr(src_C), cap, ptr(src_ndev), ns, ptr(m.keys), ptr(m.vals), m.cap, ptr(out),
+                     0, ptr(n_out), ptr(ws), stream())
             todo.append((ns, out, n_out, m))
             src_C, src_ndev = out, n_out
         counts = _lib.read_ints(torch.cat([t[2] for t in todo]))
@@ -199,11 +212,12 @@ class CoordSet:
             for n in counts:
                 plan.record(n)
         for (ns_k, out, _, m), n in zip(todo, counts):
-            if m.cap > 8 * _next_pow2(max(2 * n, 16)):
+            if m is not None and m.cap > 8 * _next_pow2(max(2 * n, 16)):
                 m = None                      # a far over-sized table scatters the probes: rebuild compactly on first use
             child = CoordSet(out[:n], ns_k, m, self.n_batch)
             child.scene_major = cs.scene_major
             child.compact = cs.compact
+            child.sorted = cs.sorted
             cs._children[ns_k] = child
             cs = child
 
@@ -360,12 +374,12 @@ def voxelize(coords, feats, voxel_size, batch_id=0, row_order="morton", n_dev=No
         out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, n_dev, cap)
         plan.watch(n_out, 1, cap)
         cs = CoordSet(out_c, 1, m, n=cap, n_dev=n_out)
-        cs.compact = row_order == "morton"
+        cs.compact = cs.sorted = row_order == "morton"
         return SparseTensor(out_f[:cap], cs), src[:cap]
     out_c, out_f, src, n_out, m = _voxelize_enqueue(coords, feats, voxel_size, batch_id, row_order, n_dev)
     n = _count(n_out, coords.shape[0])[0]
     cs = CoordSet(out_c[:n], 1, m)
-    cs.compact = row_order == "morton"
+    cs.compact = cs.sorted = row_order == "morton"
     if _train(feats):                     # training: the surviving rows through torch indexing (keeps the graph)
         return SparseTensor(feats.index_select(0, src[:n].long()), cs), src[:n]
     return SparseTensor(out_f[:n], cs), src[:n]
@@ -387,7 +401,7 @@ def sparse_collate(list_of_coords_feats, voxel_size):
         F = torch.cat([p[1][:n] for p, n in zip(parts, counts)])
     cs = CoordSet(C, 1, None, len(parts))
     cs.scene_major = True
-    cs.compact = True
+    cs.compact = cs.sorted = True             # scene blocks in batch order, each in Morton order: the key carries the batch on top
     cs._counts = counts
     return SparseTensor(F, cs)
 
@@ -428,7 +442,7 @@ def sparse_collate_static(list_of_coords_feats_ndev, voxel_size):
     total = incl[B - 1:].to(torch.int32).contiguous()
     cs = CoordSet(big_c.index_select(0, src), 1, None, B, n=cap_total, n_dev=total)
     cs.scene_major = True
-    cs.compact = True
+    cs.compact = cs.sorted = True
     cs._counts_dev = (n.to(torch.int32).contiguous(), excl.to(torch.int32).contiguous())
     return SparseTensor(big_f.index_select(0, src), cs)
 
@@ -915,6 +929,7 @@ def conv_transpose_generative(x, weight, scale=None, shift=None, act=None, preci
     nd = x.cs.n_dev * 8 if x.cs.n_dev is not None else None
     cs = CoordSet(out_c, half, None, x.cs.n_batch, n_dev=nd)
     cs.compact = x.cs.compact
+    cs.sorted = x.cs.sorted           # child key = parent key with the child's rank in the three bits below it
     cs._gen_parent = x.cs
     return SparseTensor(out_f, cs, out_split, out_amax)
 
@@ -1149,6 +1164,7 @@ def prune(x, keep_mask, n_keep=None, counts=None):
     cs = CoordSet(out_c, x.cs.stride, None, x.cs.n_batch, n_dev=nd)
     cs._counts = counts
     cs.compact = x.cs.compact         # order preserved: a thinned-out compact set stays compact
+    cs.sorted = x.cs.sorted
     if _train(x.F):
         return SparseTensor(x.F.index_select(0, torch.nonzero(mask).view(-1)), cs)
     return SparseTensor(out_f, cs, None, x.amax)

@@ -286,6 +286,12 @@ int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, const int32_t* 
 int cnrma_sparse_stride_coords(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int new_stride,
                                uint64_t* hash_keys, int32_t* hash_vals, int64_t hash_cap, int32_t* out_coords,
                                int64_t out_cap, int32_t* n_out, void* workspace, void* stream);
+/* The same set, in the same order, for input rows SORTED by the voxeliser's Morton key (cnrma_voxelize_f32 row_order 1 and every
+ * set strided from such a set): the parents' keys are non-decreasing along the rows, so the first row of every parent is found
+ * by an adjacent comparison -- no hash table, no atomics.  The coordinate map of the result is not built (cnrma_sparse_build_map
+ * when a kernel map needs it).  workspace: cnrma_voxelize_workspace_bytes(n_cap). */
+int cnrma_sparse_stride_coords_sorted(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int new_stride,
+                                      int32_t* out_coords, int64_t out_cap, int32_t* n_out, void* workspace, void* stream);
 
 /* neighbour table ("kernel map", output-stationary): nbr[No][K] = input row at out_coord + offset[k], or -1.
  * offsets int32 [K][3] in coordinate units (already multiplied by the tensor stride), k with x fastest. */

@@ -820,3 +820,23 @@ def test_generated_children_table_from_the_parents_table(device):
     oc, of = SO.conv_transpose_generative(c, f, W.cpu().numpy(), 4)
     _, o3 = SO.conv(oc, of, W3, 3, 1, 2)
     check(S.conv(y, torch.from_numpy(W3).to(device), 3, 1), oc, o3, tol=2e-6, same_order=False)
+
+
+def test_strided_sets_of_sorted_rows_need_no_hash_table(device):
+    """strided coordinate sets of a Morton-sorted set by adjacent comparison (cnrma_sparse_stride_coords_sorted) == the hash
+    route, row for row, over a chain of levels; the kernel maps built on them (lazy coordinate map) match as well"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(31)
+    pts = (rng.rand(40000, 3).astype(np.float32) - 0.4) * np.array([3.0, 2.0, 1.0], dtype=np.float32)      # negative coordinates too
+    x, _ = S.voxelize(torch.from_numpy(pts).to(device), torch.zeros(40000, 4, device=device), 0.02)
+    assert x.cs.sorted and x.cs.compact
+    plain = S.CoordSet(x.C.clone(), 1)                                     # same rows, not flagged: the hash route
+    assert not plain.sorted
+    a, b = x.cs, plain
+    for level in range(4):
+        ca, cb = a.strided(2), b.strided(2)
+        assert ca.sorted and ca._map is None and ca.n == cb.n and torch.equal(ca.C, cb.C)
+        assert torch.equal(a.neighbours(ca, 3, a.stride), b.neighbours(cb, 3, b.stride))       # stride-2 map: probes ca's lazy map
+        assert torch.equal(ca.neighbours(ca, 3, ca.stride), cb.neighbours(cb, 3, cb.stride))
+        a, b = ca, cb
+    assert 0 < a.n < 2000
