@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
   const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
   const int32_t* th = g.hdr + tile * GO_HDR;
   const int32_t* tr = g.rows + tile * GO_ROWS;
-  for (int i = tid; i < GO_BM * 27; i += 256) Ls[i] = g.lidx[tile * (GO_BM * 27) + i];
+  for (int i = tid; i < GO_BM * 27; i += 256) Ls[i] = (p.ablate & 32) ? (uint16_t)(i & 127) : g.lidx[tile * (GO_BM * 27) + i];
   if (tid < 16) {                                            // the zero row of both planes (64 bytes each)
     reinterpret_cast<uint32_t*>(&Us[0][GO_UMAX * LDK])[tid] = 0u;
     reinterpret_cast<uint32_t*>(&Us[1][GO_UMAX * LDK])[tid] = 0u;
@@ -2105,7 +2105,8 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
           const int t = t0 + i * 256 + tid;
           const int u = t < tasks ? (t >> 3) : 0;
           const int32_t src = tr[ub + u];
-          v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src * Cin + cin0 + (t & 7) * 4);
+          if (!(p.ablate & 2)) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src * Cin + cin0 + (t & 7) * 4);
+          else v[i] = make_float4(0.f, 0.f, 0.f, (float)src);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -2115,8 +2116,10 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
             uint2 h, m;
             split2(v[i], a_scale, h, m);
             const int o = lds_slot(u, kc >> 1) + (kc & 1) * 4;
-            *reinterpret_cast<uint2*>(&Us[0][o]) = h;
-            *reinterpret_cast<uint2*>(&Us[1][o]) = m;
+            if (!(p.ablate & 8)) {
+              *reinterpret_cast<uint2*>(&Us[0][o]) = h;
+              *reinterpret_cast<uint2*>(&Us[1][o]) = m;
+            } else if (h.x == 0x12345678u) Us[0][0] = (__bf16)0.0f;
           }
         }
       }
@@ -2264,7 +2267,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoAr
           v = v + sh;
           if (HAS_RES || has_res_rt) v = v + res[q];
           v = apply_act(v, act);
-          if (col_ok && row < n_live) {
+          if (col_ok && row < n_live && !((p.ablate & 16) && v != 12345.678f)) {
             dst[row * Cout + col] = v;
             mx = fmaxf(mx, fabsf(v));
           }

@@ -339,7 +339,9 @@ int cnrma_sparse_conv_plan(int64_t no_cap, int Cin, int Cout, int K, int mode, i
 /* Debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): overrides {tile shape id, splits, load stages in flight,
  * ablation mask} of every later convolution launch (-1 = the launcher's choice; n = 0 restores the product configuration).
  * A non-zero ablation mask routes f16x3 launches to a DIAGNOSTIC kernel that leaves stage components out (timing
- * experiments: its results are meaningless).  Host-side global state; product code never calls it and nothing reads the
+ * experiments: its results are meaningless; stage kernel bits: 1 MFMAs, 2 A loads, 4 B loads, 8 LDS stores, 16 barriers;
+ * gather-once kernel: 1 MFMAs + fragment reads, 2 union-row loads, 4 weight loads, 8 LDS stores, 16 epilogue stores,
+ * 32 local-index load; tile-union builder: 32 / 64 insertion / numbering).  Host-side global state; product code never calls it and nothing reads the
  * environment. */
 int cnrma_debug_conv_tuning(const int* values, int n);
 
