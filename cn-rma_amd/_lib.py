@@ -67,6 +67,7 @@ SIGNATURES = {
     "cnrma_sparse_convtr_gen_bf16x6": (c_int, [P, P, P, L, P, I, I, P, I, P, P, I, P, P, P, P]),
     "cnrma_amax_bytes": (c_size_t, []),
     "cnrma_absmax_f32": (c_int, [P, L, P, I, P, P]),
+    "cnrma_rma_emit_features_f32": (c_int, [P, P, I, P, L, P, P, P, I, P, P]),
     "cnrma_sparse_conv_f16_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights_f16": (c_int, [P, I, I, I, P, P]),
     "cnrma_sparse_conv_f16x3": (c_int, [P, P, I, P, I, P, I, P, P, P, I, P, P, L, P, P, c_size_t, P]),

@@ -756,6 +756,50 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ i
   block_amax_publish(out, mx, sh4);
 }
 
+// feats[j][:] = feat[ray_j][:] * (w_j / w_div) for the point records {ray, step, weight bits, 0} (the feature half of
+// neus_emit_rows_kernel of rma.hip, same arithmetic), in whatever order the records are given -- the static trace hands them
+// over in VOXEL order (the voxeliser carried the 16-byte records through its representative selection and sort), so the
+// sparse tensor's feature rows are written once, in place, with their magnitude bound: no [M, C] intermediate, no row gather,
+// no absmax pass.  LPR lanes per row.
+template <int LPR>
+__global__ __launch_bounds__(256) void emit_features_kernel(const float* feat, const float* const* __restrict__ feat_ref, int C,
+                                                            const int4* __restrict__ rec, int64_t n_cap,
+                                                            const int32_t* __restrict__ n_dev, const float* __restrict__ w_div,
+                                                            float* __restrict__ out, int out_stride, float* __restrict__ out_amax) {
+  if (feat_ref != nullptr) feat = *feat_ref;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t j = t / LPR;
+  const int sub = (int)(t % LPR);
+  float mx = 0.0f;
+  if (j < live_rows(n_cap, n_dev)) {
+    const int4 rc = rec[j];
+    const float w = __int_as_float(rc.z);
+    const float* f = feat + (int64_t)rc.x * C;
+    float* q = out + j * out_stride;
+    const bool scaled = w_div != nullptr;
+    const float scale = scaled ? w / w_div[0] : 1.0f;
+    const bool vec = ((C | out_stride) & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)feat)) & 15) == 0;
+    if (vec) {
+      for (int c = 4 * sub; c < C; c += 4 * LPR) {
+        float4 x = *reinterpret_cast<const float4*>(f + c);
+        if (scaled) { x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale; }
+        *reinterpret_cast<float4*>(q + c) = x;
+        mx = fmaxf(fmaxf(mx, fabsf(x.x)), fmaxf(fmaxf(fabsf(x.y), fabsf(x.z)), fabsf(x.w)));
+      }
+    } else {
+      for (int c = sub; c < C; c += LPR) {
+        const float x = scaled ? f[c] * scale : f[c];
+        q[c] = x;
+        mx = fmaxf(mx, fabsf(x));
+      }
+    }
+  }
+  if (out_amax != nullptr) {
+    __shared__ float sh4[4];
+    block_amax_publish(out_amax, mx, sh4);
+  }
+}
+
 // prepared weight images pad Cout to a multiple of 128 with zero rows (the largest column tile): B-tile loads need no
 // bounds check and no select
 __host__ __device__ inline int conv_cout_padded(int Cout) { return (Cout + 127) & ~127; }
@@ -3049,6 +3093,27 @@ extern "C" int cnrma_sparse_conv_bf16x6(const float* in_feats, const void* in_sp
   return launch_conv(in_feats, Cin, nbr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1,
                      workspace, workspace_bytes, as_stream(stream), weight_split, in_split, in_zero_row, out_split,
                      no_cap);
+}
+
+extern "C" int cnrma_rma_emit_features_f32(const float* feat_nhwc, const float* const* feat_nhwc_ref, int C, const void* records,
+                                           int64_t n_cap, const int32_t* n_dev, const float* w_div, float* out_feat,
+                                           int feat_stride, float* out_amax, void* stream) {
+  if ((feat_nhwc == nullptr && feat_nhwc_ref == nullptr) || records == nullptr || out_feat == nullptr || C <= 0 || n_cap <= 0 ||
+      feat_stride < C)
+    return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int4* rec = reinterpret_cast<const int4*>(records);
+  if (C % 256 == 0)
+    hipLaunchKernelGGL((emit_features_kernel<64>), dim3((unsigned)ceil_div(n_cap * 64, 256)), dim3(256), 0, st, feat_nhwc,
+                       feat_nhwc_ref, C, rec, n_cap, n_dev, w_div, out_feat, feat_stride, out_amax);
+  else if (C % 32 == 0)
+    hipLaunchKernelGGL((emit_features_kernel<8>), dim3((unsigned)ceil_div(n_cap * 8, 256)), dim3(256), 0, st, feat_nhwc,
+                       feat_nhwc_ref, C, rec, n_cap, n_dev, w_div, out_feat, feat_stride, out_amax);
+  else
+    hipLaunchKernelGGL((emit_features_kernel<2>), dim3((unsigned)ceil_div(n_cap * 2, 256)), dim3(256), 0, st, feat_nhwc,
+                       feat_nhwc_ref, C, rec, n_cap, n_dev, w_div, out_feat, feat_stride, out_amax);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out_amax,

@@ -15,6 +15,7 @@ from . import plan as P
 from . import sparse as S
 
 
+DEFER_POINT_FEATURES = True     # static trace: point features are emitted once, in voxel order, into the sparse tensor (trace_net)
 DENSE_BRANCH = False     # StaticScene: the dense unprojection as a parallel branch of the scene graph (fork / join inside the
                          # capture).  Measured (bench.py --dense-branch 1): NS 40.8 vs 43.0 scenes/s, S 163 vs 202 -- a graph with a
                          # second stream in it replays slower than the linear chain, and the chip-filling kernel gains nothing
@@ -173,11 +174,22 @@ def forward_scene(cfg, backbone, head, features_nchw, projections, tsdf, offset=
     return out
 
 
-def trace_net(plan, backbone, head, coords, feats, n_dev, voxel_size, device, extra_counts=()):
+def trace_net(plan, backbone, head, coords, feats, n_dev, voxel_size, device, extra_counts=(), late=None):
     """the sparse half inside a static trace (plan.static): voxelise -> MinkResNet34 -> neck / head -> decode of the point
     rows [0, n_dev) of the capacity-sized (coords, feats).  Returns the padded detections, the per-level head outputs and
-    one small tensor of live counts -- no device->host read."""
-    x, _ = S.voxelize(coords, feats, voxel_size, n_dev=n_dev)
+    one small tensor of live counts -- no device->host read.
+    late (feats is None): the aggregation's info with the point RECORDS instead of features -- the voxeliser carries the
+    16-byte records (as 4-float rows) through its representative selection and sort, and the features of the surviving rows
+    are emitted straight into the sparse tensor, with their magnitude bound: no [M, C] intermediate, no row gather, no
+    absmax pass (0.27 ms per scene at the north-star shape)."""
+    if feats is None:
+        rec_f = late["rec"].view(torch.float32)                        # bit patterns travel through float4 copies untouched
+        xr, _ = S.voxelize(coords, rec_f, voxel_size, n_dev=n_dev)
+        amax = S._amax_slot(device)
+        F = rma.emit_point_features(late, xr.F.view(torch.int32), xr.cs.n, xr.cs.n_dev, amax=amax)
+        x = S.SparseTensor(F, xr.cs, None, amax)
+    else:
+        x, _ = S.voxelize(coords, feats, voxel_size, n_dev=n_dev)
     levels = backbone(x)
     cen, box, cls, pts, css = map(list, head(levels, fused=True))
     bboxes, scores, valid, sizes = head.get_bboxes_static(cen, box, cls, pts, css)
@@ -419,17 +431,31 @@ class StaticScene:
                 max_points=cfg.max_points, seed=cfg.sample_seed if fixed else 0x5EED,
                 seed_dev=None if fixed else self.seed_dev,
                 marched=(self.march, self.march_out) if self.march is not None else None,
-                mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0, feat_ref=self.feat_ref, shape=self.shape_nhwc)
+                mode=cfg.ray_marching_type, select_grids=cfg.depth_points or 0, feat_ref=self.feat_ref, shape=self.shape_nhwc,
+                defer_feats=DEFER_POINT_FEATURES)
             moved = coords + self.offset_dev     # ray_marching.py:364 (one fp32 add per coordinate, as the reference)
             out.update(trace_net(plan, self.backbone, self.head, moved, feats, n_sel, cfg.voxel_size_fcaf3d, self.device,
-                                 extra_counts=[info["M"], n_sel]))
+                                 extra_counts=[info["M"], n_sel], late=info))
             if not fixed:
                 self.seed_dev.add_(1)            # the next replay draws a fresh point subset
             if side is not None:
                 torch.cuda.current_stream(self.device).wait_stream(side)          # join
         plan.end_static()
-        out.update(points=(coords, feats, n_sel))
+        # the aggregated points: places and row count are static outputs; with deferred features the [cap, C] rows are
+        # produced on demand from the slot's records (point_features(): one launch outside the graph, on the caller's stream)
+        out.update(points=(coords, feats, n_sel), points_info=info if feats is None else None)
         return out
+
+    @staticmethod
+    def point_features(out):
+        """features [cap, C] of the aggregated points of a static output (rows >= out["points"][2] undefined): the stored rows,
+        or -- deferred emission -- emitted now from the slot's records (valid until the slot's next run)"""
+        coords, feats, n_sel = out["points"]
+        if feats is None:
+            if out.get("done") is not None:
+                torch.cuda.current_stream(coords.device).wait_event(out["done"])
+            feats = rma.point_features(out["points_info"])
+        return feats
 
     def calibrate(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
         """one eager forward under a recording plan; several calls (several scenes of the configuration) are merged:

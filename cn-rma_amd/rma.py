@@ -482,11 +482,13 @@ def aggregate_finish(st, readback, offset=(0.0, 0.0, 0.0), max_points=None, samp
 
 def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, origin, n_steps=300, thr=0.05,
                             offset=(0.0, 0.0, 0.0), max_points=None, seed=0, seed_dev=None, reference_quirks=True,
-                            marched=None, mode="neus", select_grids=0, feat_ref=None, shape=None):
+                            marched=None, mode="neus", select_grids=0, feat_ref=None, shape=None, defer_feats=False):
     """aggregate_points() without a device->host read (the static trace of plan.Plan; NeuS single-march only): the row
     count M stays on the device, the selection always goes through the device sampler (it keeps every row when
     M <= max_points) and the outputs are capacity-sized.  Returns (coords [cap,3], feats [cap,C], n_dev int32 [1], info);
-    rows >= n_dev[0] are undefined."""
+    rows >= n_dev[0] are undefined.  defer_feats (NeuS): only the places are emitted, feats is None and info["rec"] holds the
+    point records -- the caller carries them through the voxeliser and emits the features of the surviving rows in place
+    (emit_point_features), or all of them on demand (point_features)."""
     plan = P.current()
     assert plan is not None and plan.static
     depth = mode == "depth"
@@ -517,9 +519,10 @@ def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, ori
         plan.watch(overflow, 0, 0)
     n_keep = int(max_points) if max_points is not None else M_cap
     cap = min(M_cap, n_keep)
+    defer_feats = bool(defer_feats) and not depth
     coords = torch.empty((cap, 3), dtype=torch.float32, device=m.dev)
-    feats = torch.empty((cap, m.C), dtype=torch.float32, device=m.dev)
-    sel = None
+    feats = None if defer_feats else torch.empty((cap, m.C), dtype=torch.float32, device=m.dev)
+    sel = rec = None
     if depth:
         mask = sample_mask_device(m_total, M_cap, n_keep, seed=seed, seed_dev=seed_dev)
         sel, n_sel = mask_to_index(mask)
@@ -527,9 +530,28 @@ def aggregate_points_static(features_nhwc, proj_inv, tsdf, dims, voxel_size, ori
     else:
         # the subset is drawn per ray from the sample records: no M-sized mask, no M-sized index (72 M rows at the north star)
         rec, n_sel = select_records(off, kept, m_total, M_cap, n_keep, cap, seed=seed, seed_dev=seed_dev)
-        m.emit_records(rec, cap, n_sel, mean_w, offset, coords.data_ptr(), 3, None, 0, feats.data_ptr(), m.C)
-    info = dict(M=m_total, M_selected=n_sel, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m)
+        m.emit_records(rec, cap, n_sel, mean_w, offset, coords.data_ptr(), 3, None, 0,
+                       feats.data_ptr() if feats is not None else None, m.C)
+    info = dict(M=m_total, M_selected=n_sel, mean_w=mean_w, row_offset=off, count=cnt, kept=kept, sel=sel, march=m, rec=rec)
     return coords, feats, n_sel, info
+
+
+def emit_point_features(info, rec, n_rows, n_dev, out=None, amax=None):
+    """feats [n_rows, C] of the point records `rec` (int32 [n_rows, 4], any order): feat[ray] * w / mean(w), the arithmetic of
+    the row emission; amax: zeroed magnitude-bound slots that receive max|feats| (cnrma_rma_emit_features_f32)"""
+    m = info["march"]
+    if out is None:
+        out = torch.empty((int(n_rows), m.C), dtype=torch.float32, device=m.dev)
+    by_ref = m.feat_ref is not None
+    call("cnrma_rma_emit_features_f32", None if by_ref else ptr(m.feat), ptr(m.feat_ref) if by_ref else None, m.C, ptr(rec),
+         int(n_rows), ptr(n_dev), ptr(info["mean_w"]), ptr(out), out.shape[1], ptr(amax), stream())
+    return out
+
+
+def point_features(info):
+    """the [cap, C] feature rows of a deferred aggregation, in point order (what feats would have been)"""
+    rec = info["rec"]
+    return emit_point_features(info, rec, rec.shape[0], info["M_selected"])
 
 
 def aggregate_points_backward(info, grad_feats):

@@ -401,6 +401,15 @@ int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float* in_amax, i
  * holding max|weight| (cnrma_sparse_conv_f16_weight_bytes bytes in all), done once per layer. */
 size_t cnrma_amax_bytes(void);
 int cnrma_absmax_f32(const float* in, int64_t n_cap, const int32_t* n_dev, int C, float* out_amax, void* stream);
+/* The feature half of cnrma_rma_neus_emit_rows_f32 (ray_marching.py:298-307: point_features * weights / mean(weights)) for point
+ * records {ray, step, weight bits, 0} in ANY order: out_feat[j][:] = feat[ray_j][:] * (w_j / w_div[0]), same arithmetic.  The
+ * static trace carries the 16-byte records of cnrma_rma_select_records through the voxeliser (as 4-float rows) and emits the
+ * features of the surviving representatives straight into the sparse tensor's rows, with their magnitude bound (out_amax:
+ * cnrma_amax_bytes() ZEROED bytes, or NULL): no [M, C] intermediate, no row gather, no absmax pass.  Exactly one of feat_nhwc /
+ * feat_nhwc_ref (see cnrma_backproject_accum_ref_f32) is given. */
+int cnrma_rma_emit_features_f32(const float* feat_nhwc, const float* const* feat_nhwc_ref, int C, const void* records,
+                                int64_t n_cap, const int32_t* n_dev, const float* w_div, float* out_feat, int feat_stride,
+                                float* out_amax, void* stream);
 size_t cnrma_sparse_conv_f16_weight_bytes(int K, int Cin, int Cout);
 int cnrma_sparse_conv_prepare_weights_f16(const float* weight, int K, int Cin, int Cout, void* weight_split,
                                           void* stream);

@@ -144,8 +144,11 @@ class RayMarching(MultiViewBase):
         device->host read) and is valid until that slot takes its next scene."""
         lazy = self.__dict__.get("_lazy_points")
         if lazy is not None:
-            coords, feats, n_dev, done = lazy
-            torch.cuda.current_stream(coords.device).wait_event(done)
+            from cnrma_amd import pipeline
+            out = lazy
+            coords, _, n_dev = out["points"]
+            torch.cuda.current_stream(coords.device).wait_event(out["done"])
+            feats = pipeline.StaticScene.point_features(out)       # stored rows, or emitted now from the slot's point records
             n = int(n_dev.item())
             self.__dict__["_points"] = [torch.cat((coords[:n], feats[:n]), dim=1)]
             self.__dict__["_lazy_points"] = None
@@ -406,7 +409,7 @@ class RayMarching(MultiViewBase):
             # one elementwise kernel on the slot's stream when somebody reads it)
             self.volume = out["volume"].unsqueeze(0)
             self.__dict__["_lazy_valid"] = (out["count"], out["done"])
-        self.__dict__["_lazy_points"] = out["points"] + (out["done"],)
+        self.__dict__["_lazy_points"] = out
         item = dict(st=st, out=out, scene=scene, inputs=(feats, proj, tsdf, offset), finished=threading.Event(), status=None,
                     result=None)
         ctx["pending"][i] = item

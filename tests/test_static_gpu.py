@@ -274,7 +274,8 @@ def test_static_depth_mode_vs_reference_golden(device, k):
     n = exp.shape[0]
     assert info["M"] == eager["M"] == n > 0 and info["M_unique"] == eager["M_unique"]
     assert info["level_rows"] == eager["level_rows"] and info["head_rows"] == eager["head_rows"]
-    coords, pf, n_sel = out["points"]
+    coords, _, n_sel = out["points"]
+    pf = pipeline.StaticScene.point_features(out)
     assert int(n_sel) == n
     assert (coords[:n].cpu().numpy().view(np.uint32) == exp[:, :3].astype(np.float32).view(np.uint32)).all()
     w = exp[:, 3].astype(np.float64)
@@ -307,7 +308,9 @@ def test_channels_last_maps_are_read_in_place_with_identical_results(device, sha
     def run(f, p, t):
         out = st.run(f, p, t)
         b, s, info = pipeline.StaticScene.detections(out)
-        return out["volume"].clone(), out["count"].clone(), out["points"][0].clone(), out["points"][1].clone(), b.clone(), s.clone(), info
+        n = int(out["points"][2])                                         # rows behind the live count are undefined
+        return (out["volume"].clone(), out["count"].clone(), out["points"][0][:n].clone(),
+                pipeline.StaticScene.point_features(out)[:n].clone(), b.clone(), s.clone(), info)
     a = run(cl, proj, tsdf)
     assert st.nhwc is None
     other = run(cl2, proj2, tsdf2)                                        # another producer tensor: only the reference changes

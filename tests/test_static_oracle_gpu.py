@@ -50,7 +50,8 @@ def test_graph_replay_vs_reference_golden(device, name):
         b, s, info = pipeline.StaticScene.detections(out)
         assert (out["count"].cpu().numpy() == g["dense_count"]).all()
         assert count_mismatch(out["volume"], g["dense_volume"]) == 0
-        coords, pf, n_sel = out["points"]
+        coords, _, n_sel = out["points"]
+        pf = pipeline.StaticScene.point_features(out)                  # deferred emission: produced from the slot's records
         assert info["M"] == exp.shape[0] == int(n_sel) == info["M_selected"]
         n = exp.shape[0]
         assert count_mismatch(coords[:n], exp[:, :3]) == 0
