@@ -1822,11 +1822,13 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
 // result differs from the stage kernel's in fp32 rounding order only.
 // ================================================================================================================
 constexpr int GO_BM = 64;            // output rows per tile
-constexpr int GO_UMAX = 320;         // union rows of one group held in LDS (+ 1 zero row): 2 planes x 64 B x 321 = 41 KB
+constexpr int GO_UMAX = 280;         // union rows of one group held in LDS (+ 1 zero row): 2 planes x 64 B x 281 = 36 KB; with the
+                                     // local indices 39.4 KB per block: FOUR blocks per CU (320 rows: 43.5 KB, three)
 constexpr int GO_HASH = 2048;        // per-wave hash slots of the builder (>= 27 x 64 entries: a try never fills the set)
 constexpr int GO_HDR = 84;           // ints per tile: [0] groups, then per group {offset mask, first entry, entries}
 constexpr int GO_ROWS = 27 * GO_BM;  // worst case entries per tile (every (row, offset) distinct)
-constexpr int GO_BQ = 4;             // offsets whose weight fragments are in flight / in registers per wave
+constexpr int GO_BQ = 2;             // offsets whose weight fragments are in flight / in registers per wave (4: 158-166 registers,
+                                     // three waves per SIMD; 2: 125, four -- measured S 247 -> 256-258, NS 58.4 -> 59.0 scenes/s)
 
 // one wave per tile: groups of offsets + sorted union lists + local indices.
 //   * the tile's 64 x 27 slice of the neighbour table is contiguous: 27 independent coalesced loads, then registers;
@@ -2037,7 +2039,7 @@ __global__ __launch_bounds__(256) void prep_weights_f16_frag_kernel(const float*
 // tiles (with 2 x 2 waves over rows x columns every fragment was fetched twice per block and fed one: the vector-memory
 // path, 64 B/clk/CU, carried 16 KB per 192 MFMA cycles); the two partial sums meet in LDS before the epilogue.
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int KS = 1>
-__global__ __launch_bounds__(256, 2) void sparse_conv_go_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag) {
+__global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   static_assert(BM == GO_BM && WAVES_M * WAVES_N * KS == 4, "tile shape");
   static_assert(KS == 1 || (KS == 2 && TM == 2 && TN == 1 && WAVES_M == 1), "offset halves: one wave = 64 rows x 32 columns");

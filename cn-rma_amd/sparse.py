@@ -671,6 +671,7 @@ def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1):
 
 GO_CONV = "auto"     # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): "auto" = on coordinate sets
                      # whose rows are compact (CoordSet.compact) with >= GO_MIN_ROWS rows; True / False force it (tests, A/B runs)
+GO_UMAX = 280        # csrc/sparse.hip GO_UMAX: rows of a tile's union image in LDS (the local index of "no neighbour")
 GO_WS_ROWS = 65536   # below: a workspace for the split over channel slices is handed to the kernel (it decides)
 GO_MIN_ROWS = 1024   # below: the stage kernel split over the 27 offsets fills the chip better (541-row level: 0.95x)
 PAIR_HDR_BYTES, PAIR_OVERFLOW_WORD = 512, 64 + 34      # csrc/sparse.hip: PAIR_HDR ints, hdr[64 + 34] = "an entry was dropped"

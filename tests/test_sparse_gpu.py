@@ -208,7 +208,7 @@ def test_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n
         seen = 0
         for g in range(hdr[t, 0]):
             mask, ub, un = int(hdr[t, 1 + 3 * g]) & 0xFFFFFFFF, hdr[t, 2 + 3 * g], hdr[t, 3 + 3 * g]
-            assert 0 < un <= 320 and (mask & seen) == 0
+            assert 0 < un <= S.GO_UMAX and (mask & seen) == 0
             seen |= mask
             u = rows[t, ub:ub + un]
             first = []                                                          # distinct, in the order of first appearance
@@ -220,7 +220,7 @@ def test_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n
                 if (mask >> k) & 1:
                     for r in range(min(64, len(c) - 64 * t)):
                         want = nbr[64 * t + r, k]
-                        assert (lidx[t, r, k] == 320) if want < 0 else (u[lidx[t, r, k]] == want)
+                        assert (lidx[t, r, k] == S.GO_UMAX) if want < 0 else (u[lidx[t, r, k]] == want)
         live = nbr[64 * t:64 * t + 64]
         assert all(((seen >> k) & 1) == int((live[:, k] >= 0).any()) for k in range(27))
     if n >= 20000:
