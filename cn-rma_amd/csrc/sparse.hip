@@ -2459,6 +2459,59 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   }
 }
 
+// InstanceNorm (+ ReLU) applied on the fly to the candidates of a max pooling (the stem: conv - InstanceNorm - ReLU - MaxPool,
+// fcaf3d_backbone.py:25-32): the normalised tensor is never written or re-read, the pooled rows come with their magnitude
+// bound.  The same operations in the same order as instnorm_apply_kernel followed by maxpool_kernel: bit-identical.
+__global__ __launch_bounds__(256) void instnorm_maxpool_kernel(const float* __restrict__ in, int C,
+                                                               const double* __restrict__ stats,
+                                                               const float* __restrict__ weight,
+                                                               const float* __restrict__ bias, float eps, int relu,
+                                                               const int32_t* __restrict__ nbr, int K, float* __restrict__ out,
+                                                               int64_t no_cap, const int32_t* __restrict__ no_dev,
+                                                               float* __restrict__ out_amax) {
+  const int64_t n = live_rows(no_cap, no_dev);
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;                                  // C % 4 == 0 (checked by the entry point)
+  float mx = 0.0f;
+  if (t < n * c4) {
+    const int64_t o = t / c4;
+    const int c = (int)(t - o * c4) * 4;
+    float mean[4], inv[4], w[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mean[j] = (float)stats[c + j];
+      inv[j] = 1.0f / sqrtf((float)stats[C + c + j] + eps);
+      w[j] = weight ? weight[c + j] : 1.0f;
+      b[j] = bias ? bias[c + j] : 0.0f;
+    }
+    float m[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+      const int32_t s_ = nbr[o * K + k];
+      if (s_ >= 0) {
+        const float4 q = *reinterpret_cast<const float4*>(in + (int64_t)s_ * C + c);
+        const float x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = (x[j] - mean[j]) * inv[j];
+          if (weight) v = v * w[j];
+          if (bias) v = v + b[j];
+          if (relu) v = fmaxf(v, 0.0f);
+          m[j] = fmaxf(m[j], v);
+        }
+        any = true;
+      }
+    }
+    float4 r = any ? make_float4(m[0], m[1], m[2], m[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(out + o * C + c) = r;
+    mx = fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w)));
+  }
+  if (out_amax != nullptr) {
+    __shared__ float sh4[4];
+    block_amax_publish(out_amax, mx, sh4);
+  }
+}
+
 // ---- BatchNorm (training) backward over the rows of a [n][C] matrix -----------------------------------------------------
 // s1[c] = sum_r dy[r][c], s2[c] = sum_r dy[r][c] * x[r][c] in fp64, deterministic two-stage like colstats; then
 // dgamma = (s2 - mean * s1) / sigma, dbeta = s1, dx = gamma / sigma * (dy - s1 / n - xhat * dgamma / n)
@@ -3565,8 +3618,22 @@ extern "C" int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, c
   double* part = stats_ws + 2 * C;
   hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, in_feats, n_cap, n_dev, row0_dev, C, part);
   hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n_cap, n_dev, stats_ws);
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, st, in_feats, n_cap,
-                     n_dev, row0_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
+  if (out_feats != nullptr)            // NULL: statistics only (cnrma_sparse_instnorm_maxpool_f32 applies them)
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(n_cap * C, 256, 4096)), dim3(256), 0, st, in_feats, n_cap,
+                       n_dev, row0_dev, C, stats_ws, weight, bias, eps, relu, out_feats);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_instnorm_maxpool_f32(const float* in_feats, int C, const double* stats, const float* weight,
+                                                 const float* bias, float eps, int relu, const int32_t* nbr, int K,
+                                                 float* out_feats, int64_t no_cap, const int32_t* no_dev, float* out_amax,
+                                                 void* stream) {
+  if (no_cap <= 0 || C <= 0 || (C & 3) != 0 || K <= 0 || in_feats == nullptr || stats == nullptr || nbr == nullptr ||
+      out_feats == nullptr)
+    return CNRMA_EINVAL;
+  hipLaunchKernelGGL(instnorm_maxpool_kernel, dim3((unsigned)ceil_div(no_cap * (C / 4), 256)), dim3(256), 0, as_stream(stream),
+                     in_feats, C, stats, weight, bias, eps, relu, nbr, K, out_feats, no_cap, no_dev, out_amax);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

@@ -173,6 +173,12 @@ class FusedSequential(nn.Sequential):
                 act = _act_name(nxt2)
                 x = m(x, scale=scale, shift=shift, act=act)
                 i += 3 if act else 2
+            elif (not self.training) and isinstance(m, MinkowskiInstanceNorm) and isinstance(nxt, MinkowskiReLU) and \
+                    isinstance(nxt2, MinkowskiMaxPooling) and x.cs.n_batch <= 1 and x.F.shape[1] % 4 == 0 and \
+                    not (torch.is_grad_enabled() and x.F.requires_grad):
+                # the stem: the normalised tensor is never written -- the pooling normalises its candidates on the fly
+                x = S.instance_norm_max_pool(x, m.weight, m.bias, m.eps, relu=True, kernel_size=nxt2.kernel_size, stride=nxt2.stride)
+                i += 3
             elif isinstance(m, MinkowskiInstanceNorm) and isinstance(nxt, MinkowskiReLU):
                 x = m(x, relu=True)
                 i += 2

@@ -978,6 +978,31 @@ def max_pool(x, kernel_size=2, stride=2):
     return SparseTensor(out, out_cs, None, x.amax)       # a maximum over a subset: the input's bound still holds
 
 
+def instance_norm_max_pool(x, weight=None, bias=None, eps=1e-8, relu=True, kernel_size=2, stride=2):
+    """max_pool(instance_norm(x, relu=relu)) of a single-scene tensor without the normalised intermediate (the stem of the
+    backbone): one statistics pass + one pooling pass that normalises its candidates on the fly; bit-identical to the two
+    separate operators, and the pooled tensor carries its magnitude bound."""
+    _lib.require_gpu()
+    n, C = x.F.shape
+    assert x.cs.n_batch <= 1 and C % 4 == 0 and not _train(x.F, weight, bias)
+    ws = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=x.device)
+    w = weight.contiguous().view(-1).float() if weight is not None else None
+    b = bias.contiguous().view(-1).float() if bias is not None else None
+    src = x.F.contiguous()
+    if P.static():
+        P.current().keep(w, b)
+    out_cs = x.cs.strided(stride)
+    nbr = x.cs.neighbours(out_cs, kernel_size, x.cs.stride)
+    out = torch.empty((out_cs.n, C), dtype=torch.float32, device=x.device)
+    amax = _amax_slot(x.device)
+    if n and out_cs.n:
+        call("cnrma_sparse_instnorm_f32", ptr(src), n, ptr(x.cs.n_dev), None, C, ptr(w), ptr(b), float(eps), int(relu), None,
+             ptr(ws), stream())
+        call("cnrma_sparse_instnorm_maxpool_f32", ptr(src), C, ptr(ws), ptr(w), ptr(b), float(eps), int(relu), ptr(nbr),
+             nbr.shape[1], ptr(out), out_cs.n, ptr(out_cs.n_dev), ptr(amax), stream())
+    return SparseTensor(out, out_cs, None, amax)
+
+
 def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
     """MinkowskiInstanceNorm for a single scene (+ optional fused ReLU)."""
     _lib.require_gpu()

@@ -487,6 +487,13 @@ size_t cnrma_instnorm_workspace_bytes(int C);
 int cnrma_sparse_instnorm_f32(const float* in_feats, int64_t n_cap, const int32_t* n_dev, const int32_t* row0_dev, int C,
                               const float* weight, const float* bias, float eps, int relu, float* out_feats,
                               double* stats_ws, void* stream);
+/* The stem's InstanceNorm - ReLU - MaxPool (fcaf3d_backbone.py:29-31) without the normalised intermediate: out_feats == NULL in
+ * cnrma_sparse_instnorm_f32 leaves only the statistics in stats_ws; this entry normalises the candidates of every pooling
+ * window on the fly (same operations, same order: bit-identical to the two launches) and publishes max|out| (out_amax:
+ * cnrma_amax_bytes() zeroed bytes, or NULL).  C % 4 == 0; nbr [no_cap][K] = the pooling table. */
+int cnrma_sparse_instnorm_maxpool_f32(const float* in_feats, int C, const double* stats, const float* weight,
+                                      const float* bias, float eps, int relu, const int32_t* nbr, int K, float* out_feats,
+                                      int64_t no_cap, const int32_t* no_dev, float* out_amax, void* stream);
 
 /* MinkowskiBatchNorm in training (nn.BatchNorm1d over the rows, fcaf3d_backbone.py / fcaf3d_head.py blocks): the forward is
  * cnrma_sparse_instnorm_f32 with the layer's eps (it leaves {mean, biased variance} in stats_ws); this is the backward:

@@ -840,3 +840,20 @@ def test_strided_sets_of_sorted_rows_need_no_hash_table(device):
         assert torch.equal(ca.neighbours(ca, 3, ca.stride), cb.neighbours(cb, 3, cb.stride))
         a, b = ca, cb
     assert 0 < a.n < 2000
+
+
+def test_instance_norm_relu_max_pool_fused_is_bit_identical(device):
+    """the stem's InstanceNorm - ReLU - MaxPool as statistics pass + one pooling pass that normalises its candidates on the fly
+    (cnrma_sparse_instnorm_maxpool_f32) == the two operators one after the other, bit for bit; the magnitude bound is exact"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(41)
+    c, f = rand_sparse(rng, n=20000, span=20, C=64, ts=2)
+    w = torch.from_numpy((rng.rand(1, 64) + 0.5).astype(np.float32)).to(device)
+    b = torch.from_numpy((rng.randn(1, 64) * 0.3).astype(np.float32)).to(device)
+    x = to_st(c, f * 3.0 + 0.7, 2, device)
+    ref = S.max_pool(S.instance_norm(x, w, b, 1e-8, relu=True), 2, 2)
+    got = S.instance_norm_max_pool(x, w, b, 1e-8, relu=True, kernel_size=2, stride=2)
+    assert got.cs.stride == 4 and torch.equal(got.C, ref.C) and torch.equal(got.F, ref.F)
+    assert float(got.amax.max()) == float(got.F.abs().max())
+    oc, of = SO.max_pool(c, SO.relu(SO.instance_norm(f * 3.0 + 0.7, w.cpu().numpy(), b.cpu().numpy())), 2)
+    check(got, oc, of, tol=1e-5)
