@@ -2034,16 +2034,36 @@ __global__ __launch_bounds__(256) void prep_weights_f16_frag_kernel(const float*
   }
 }
 
+// Weight fragments of the gather-once kernel are fetched with explicit instructions and explicit waits: hipcc's own
+// s_waitcnt placement put vmcnt(0) in front of every offset's MFMAs (it cannot count loads issued around a loop back-edge), so
+// every offset waited for the fragment fetched one step before it -- an L2 round trip per step.  The asm loads are invisible
+// to that pass; go_wait4() names the registers it releases, which keeps their uses behind it.  Older outstanding loads never
+// invalidate a compiler-placed vmcnt(n) (returns are in order), and inside the offset loop there are no other vector loads.
+template <int OFF>
+__device__ __forceinline__ void go_load16(u32x4_t& d, const uint16_t* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF));       // no "memory": see above
+}
+__device__ __forceinline__ void go_wait0(u32x4_t (&a)[1][2][2], u32x4_t (&b)[1][2][2]) {      // every load has landed
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0][0]), "+v"(a[0][0][1]), "+v"(a[0][1][0]), "+v"(a[0][1][1]),
+               "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]));
+}
+__device__ __forceinline__ void go_wait4(u32x4_t (&b)[1][2][2]) {          // everything but the 4 newest loads has landed
+  asm volatile("s_waitcnt vmcnt(4)" : "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]));
+}
+
 // KS = 2 (the 64-column tile): the four waves are 2 column halves x 2 OFFSET halves -- a wave owns all 64 rows x 32 columns for
 // every second offset of the group, so that a weight fragment is fetched by exactly one wave of the block and feeds two row
 // tiles (with 2 x 2 waves over rows x columns every fragment was fetched twice per block and fed one: the vector-memory
 // path, 64 B/clk/CU, carried 16 KB per 192 MFMA cycles); the two partial sums meet in LDS before the epilogue.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int KS = 1>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int KS = 1, bool ABL = false>
 __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag) {
+  // ABL: the diagnostic instantiation (cnrma_debug_conv_tuning ablation mask != 0); the product kernel has none of its branches
+  // (a branch around a load makes hipcc wait for every load on its own)
+  const int abl = ABL ? p.ablate : 0;
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   static_assert(BM == GO_BM && WAVES_M * WAVES_N * KS == 4, "tile shape");
   static_assert(KS == 1 || (KS == 2 && TM == 2 && TN == 1 && WAVES_M == 1), "offset halves: one wave = 64 rows x 32 columns");
-  __shared__ __attribute__((aligned(16))) __bf16 Us[2][(GO_UMAX + 1) * LDK];      // fp16 bit patterns; row GO_UMAX = zeros
+  __shared__ __attribute__((aligned(16))) __bf16 Us[2][(GO_UMAX + 2) * LDK];      // fp16 bit patterns; row GO_UMAX = zeros, GO_UMAX + 1 = dump
   __shared__ uint16_t Ls[GO_BM * 27];
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
   const int64_t tile = blockIdx.x, tile0 = tile * BM;
@@ -2058,7 +2078,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
   const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
   const int32_t* th = g.hdr + tile * GO_HDR;
   const int32_t* tr = g.rows + tile * GO_ROWS;
-  for (int i = tid; i < GO_BM * 27; i += 256) Ls[i] = (p.ablate & 32) ? (uint16_t)(i & 127) : g.lidx[tile * (GO_BM * 27) + i];
+  for (int i = tid; i < GO_BM * 27; i += 256) Ls[i] = (abl & 32) ? (uint16_t)(i & 127) : g.lidx[tile * (GO_BM * 27) + i];
   if (tid < 16) {                                            // the zero row of both planes (64 bytes each)
     reinterpret_cast<uint32_t*>(&Us[0][GO_UMAX * LDK])[tid] = 0u;
     reinterpret_cast<uint32_t*>(&Us[1][GO_UMAX * LDK])[tid] = 0u;
@@ -2077,15 +2097,13 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
 
   const int a_row0 = wr * (32 * TM) + (lane & 31), fhalf = lane >> 5;
   // B fragments of one (offset, slice): [TN][plane][k-step] x 16 bytes per lane, straight from the fragment-order image
+  static_assert(TN == 1, "one 32-column fragment set per wave");
   auto load_b = [&](u32x4_t (&bf)[TN][2][2], int k, int slice) {
     const uint16_t* base = wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc * TN) * 2048 + lane * 8;
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-          bf[b][pl][ks] = *reinterpret_cast<const u32x4_t*>(base + b * 2048 + pl * 1024 + ks * 512);
+    go_load16<0>(bf[0][0][0], base);                           // [plane][k-step]: 1024 bytes apart
+    go_load16<1024>(bf[0][0][1], base);
+    go_load16<2048>(bf[0][1][0], base);
+    go_load16<3072>(bf[0][1][1], base);
   };
   auto mfma_k = [&](const u32x4_t (&bf)[TN][2][2], int k) {
     int li[TM];
@@ -2130,16 +2148,18 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
           ++r;
         }
       }
-      // a ring of GO_BQ offsets' weights in flight (an L2 round trip under load is ~1400 cycles, one offset's MFMAs 192-384:
-      // with a single prefetched offset every offset waited for its weights); the first ones fly while the rows are staged
-      u32x4_t bq[GO_BQ][TN][2][2];
-      int kq[GO_BQ];
+      // two offsets' weights in flight, in a pattern the compiler can count: EVERY step issues exactly one offset's four loads,
+      // unconditionally (behind the last offset the last one again), so the wait in front of an offset's MFMAs is "all but
+      // the four newest loads" -- with conditional prefetches hipcc emitted s_waitcnt vmcnt(0) there and every offset waited
+      // for the weights fetched one step before it (an L2 round trip per step: 0.75 us for 0.18 us of MFMAs)
+      u32x4_t b0[TN][2][2], b1[TN][2][2];
       unsigned rest = mymask;
-#pragma unroll
-      for (int d = 0; d < GO_BQ; ++d) {
-        kq[d] = -1;
-        if (rest) { kq[d] = __ffs(rest) - 1; rest &= rest - 1u; load_b(bq[d], kq[d], slice); }
-      }
+      const int n_off = __popc(mymask);
+      int k_last = 0;
+      auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
+      int k0 = pop(), k1 = pop();
+      load_b(b0, k0, slice);
+      load_b(b1, k1, slice);
       __syncthreads();                                       // the previous stage's fragment reads are done
       // ---- the union rows of this group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight (more in
       // flight, or the row numbers of all batches up front, costs the third wave per SIMD: measured 20-35 % slower)
@@ -2151,42 +2171,43 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
           const int t = t0 + i * 256 + tid;
           const int u = t < tasks ? (t >> 3) : 0;
           const int32_t src = tr[ub + u];
-          if (!(p.ablate & 2)) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src * Cin + cin0 + (t & 7) * 4);
+          if (!(abl & 2)) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src * Cin + cin0 + (t & 7) * 4);
           else v[i] = make_float4(0.f, 0.f, 0.f, (float)src);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          // EVERY loaded value is consumed here, on every path (tasks behind the union go to a dump row): a load whose use
+          // sits behind a branch stays "pending" for hipcc's wait placement, and the wait for it lands in the header of the
+          // offset loop below -- where it would drain the weight prefetches on every iteration
           const int t = t0 + i * 256 + tid;
-          if (t < tasks) {
-            const int u = t >> 3, kc = t & 7;
-            uint2 h, m;
-            split2(v[i], a_scale, h, m);
-            const int o = lds_slot(u, kc >> 1) + (kc & 1) * 4;
-            if (!(p.ablate & 8)) {
-              *reinterpret_cast<uint2*>(&Us[0][o]) = h;
-              *reinterpret_cast<uint2*>(&Us[1][o]) = m;
-            } else if (h.x == 0x12345678u) Us[0][0] = (__bf16)0.0f;
-          }
+          const int u = t < tasks ? (t >> 3) : GO_UMAX + 1, kc = t & 7;
+          uint2 h, m;
+          split2(v[i], a_scale, h, m);
+          const int o = lds_slot(u, kc >> 1) + (kc & 1) * 4;
+          if (!(abl & 8)) {
+            *reinterpret_cast<uint2*>(&Us[0][o]) = h;
+            *reinterpret_cast<uint2*>(&Us[1][o]) = m;
+          } else if (h.x == 0x12345678u) Us[0][0] = (__bf16)0.0f;
         }
       }
       __syncthreads();
       // ---- the group's offsets back to back: no barrier, no LDS store, no index load from memory
-      const int ab = p.ablate;                               // diagnostic switches (0 in product launches): 1 no MFMAs, 4 no B loads
-      bool more = true;
-      while (more) {
-#pragma unroll
-        for (int d = 0; d < GO_BQ; ++d) {
-          const int k = kq[d];
-          if (k < 0) { more = false; break; }
-          if (!(ab & 1)) mfma_k(bq[d], k);
-          kq[d] = -1;
-          if (rest) {
-            kq[d] = __ffs(rest) - 1;
-            rest &= rest - 1u;
-            if (!(ab & 4)) load_b(bq[d], kq[d], slice);
-          }
-        }
+      int i = 0;
+      for (; i + 2 < n_off; i += 2) {                          // steady state: two offsets per turn, their successors prefetched
+        go_wait4(b0);                                          // b0 has landed; b1's four loads may still fly
+        if (!(abl & 1)) mfma_k(b0, k0);
+        k0 = pop();
+        load_b(b0, k0, slice);
+        go_wait4(b1);                                          // b1 has landed; the four just issued may fly
+        if (!(abl & 1)) mfma_k(b1, k1);
+        k1 = pop();                                            // behind the last offset: the last one again (never used)
+        load_b(b1, k1, slice);
       }
+      // the last one or two offsets: nothing more to prefetch, and NO load may be left in flight -- the asm loads are invisible
+      // to the compiler, which is free to reuse their destination registers from here on
+      go_wait0(b0, b1);
+      if (i < n_off && !(abl & 1)) mfma_k(b0, k0);
+      if (i + 1 < n_off && !(abl & 1)) mfma_k(b1, k1);
     }
   }
 
@@ -2313,7 +2334,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
           v = v + sh;
           if (HAS_RES || has_res_rt) v = v + res[q];
           v = apply_act(v, act);
-          if (col_ok && row < n_live && !((p.ablate & 16) && v != 12345.678f)) {
+          if (col_ok && row < n_live && !((abl & 16) && v != 12345.678f)) {
             dst[row * Cout + col] = v;
             mx = fmaxf(mx, fabsf(v));
           }
@@ -3495,7 +3516,10 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   g.counters = splits > 1 ? reinterpret_cast<unsigned*>(tile_counters) : nullptr;
   const bool has_res = residual != nullptr && splits == 1;
   dim3 grid((unsigned)tiles, (unsigned)ceil_div(Cout, bn), (unsigned)splits);
-  if (bn == 128) {
+  if (p.ablate != 0 && !has_res) {                         // diagnostic instantiations (timing experiments only)
+    if (bn == 128) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, false, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
+    else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 2, 2, 1, false, 2, true>), grid, dim3(256), 0, st, p, g, wfrag);
+  } else if (bn == 128) {
     if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
     else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
   } else {
