@@ -2166,13 +2166,17 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
       const int tasks = un * 8;
       for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
         float4 v[4];
+        int32_t src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // the four row numbers first, then the four rows: two round trips
+          const int t = t0 + i * 256 + tid;                    // per batch instead of up to eight
+          src[i] = tr[ub + (t < tasks ? (t >> 3) : 0)];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int t = t0 + i * 256 + tid;
-          const int u = t < tasks ? (t >> 3) : 0;
-          const int32_t src = tr[ub + u];
-          if (!(abl & 2)) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src * Cin + cin0 + (t & 7) * 4);
-          else v[i] = make_float4(0.f, 0.f, 0.f, (float)src);
+          if (!(abl & 2)) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (t & 7) * 4);
+          else v[i] = make_float4(0.f, 0.f, 0.f, (float)src[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
