@@ -2105,29 +2105,32 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
     go_load16<2048>(bf[0][1][0], base);
     go_load16<3072>(bf[0][1][1], base);
   };
+  // A fragments come from LDS one at a time, each read issued BEFORE the MFMAs of the fragment in front of it (two 16-byte
+  // registers in rotation): the register budget of four waves per SIMD leaves no room for a k-step's four fragments at once,
+  // and with a single register hipcc had every MFMA group wait for its own LDS round trip (8 per offset: ~1000 cycles for 384
+  // cycles of MFMAs).  Order per k-step and row tile: the low plane (one product), then the high plane (two products).
   auto mfma_k = [&](const u32x4_t (&bf)[TN][2][2], int k) {
     int li[TM];
 #pragma unroll
     for (int a = 0; a < TM; ++a) li[a] = Ls[(a_row0 + a * 32) * 27 + k];
+    auto rd = [&](int a, int pl, int ks) -> f16x8_t {
+      return *reinterpret_cast<const f16x8_t*>(&Us[pl][lds_slot(li[a], ks * 2 + fhalf)]);
+    };
+    f16x8_t cur = rd(0, 1, 0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f16x8_t af[TM][2];
+      const f16x8_t bh = __builtin_bit_cast(f16x8_t, bf[0][0][ks]), bm = __builtin_bit_cast(f16x8_t, bf[0][1][ks]);
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          af[a][pl] = *reinterpret_cast<const f16x8_t*>(&Us[pl][lds_slot(li[a], ks * 2 + fhalf)]);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x16 c = acc[a][b];
-          const f16x8_t bh = __builtin_bit_cast(f16x8_t, bf[b][0][ks]), bm = __builtin_bit_cast(f16x8_t, bf[b][1][ks]);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][1], bh, c, 0, 0, 0);    // m*h
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bm, c, 0, 0, 0);    // h*m
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bh, c, 0, 0, 0);    // h*h
-          acc[a][b] = c;
-        }
+      for (int a = 0; a < TM; ++a) {
+        f16x8_t nxt = rd(a, 0, ks);                                              // this row tile's high plane
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh, acc[a][0], 0, 0, 0);       // m*h
+        cur = nxt;
+        const bool last = ks == 1 && a == TM - 1;
+        if (!last) nxt = a + 1 < TM ? rd(a + 1, 1, ks) : rd(0, 1, ks + 1);       // the next low plane
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bm, acc[a][0], 0, 0, 0);       // h*m
+        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh, acc[a][0], 0, 0, 0);       // h*h
+        cur = nxt;
+      }
     }
   };
 
