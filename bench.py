@@ -43,11 +43,11 @@ PMC_TRAFFIC = {
                               "7.26e6 KB); L2<->fabric traffic, i.e. Infinity Cache + HBM (TCC: 350 M hits / 471 M misses incl. the "
                               "226 M 32-byte write pieces; read hit rate 30 %; the replay simulation scripts/dense_l2sim.cpp puts the "
                               "HBM share at ~19 GB of reads + 7.3 GB of writes)"),
-    ("NS", "conv"): (133.2e6, "profiles/r04b_ns_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
-                              "(2 x fetch + write) / 51 launches (6.79 GB per scene; 15.06 GB before the gather-once kernel)"),
+    ("NS", "conv"): (139.8e6, "profiles/r04b_ns_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
+                              "(2 x fetch + write) / 51 launches (7.13 GB per scene; 15.06 GB before the gather-once kernel)"),
     ("S", "dense"): (1.04e9, "profiles/r04b_s_pmc_FETCH_SIZE.csv (x2) + r04b_s_pmc_WRITE_SIZE.csv"),
-    ("S", "conv"): (101.6e6, "profiles/r04b_s_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
-                             "(2 x fetch + write) / 51 launches (5.18 GB per scene, L2<->fabric: the operands are Infinity-Cache "
+    ("S", "conv"): (101.7e6, "profiles/r04b_s_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
+                             "(2 x fetch + write) / 51 launches (5.19 GB per scene, L2<->fabric: the operands are Infinity-Cache "
                              "resident; 9.70 GB before the gather-once kernel)"),
 }
 
