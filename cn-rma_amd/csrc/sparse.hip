@@ -1827,8 +1827,8 @@ constexpr int GO_UMAX = 280;         // union rows of one group held in LDS (+ 1
 constexpr int GO_HASH = 2048;        // per-wave hash slots of the builder (>= 27 x 64 entries: a try never fills the set)
 constexpr int GO_HDR = 84;           // ints per tile: [0] groups, then per group {offset mask, first entry, entries}
 constexpr int GO_ROWS = 27 * GO_BM;  // worst case entries per tile (every (row, offset) distinct)
-constexpr int GO_BQ = 2;             // offsets whose weight fragments are in flight / in registers per wave (4: 158-166 registers,
-                                     // three waves per SIMD; 2: 125, four -- measured S 247 -> 256-258, NS 58.4 -> 59.0 scenes/s)
+// two offsets of weights are in flight per wave (registers b0 / b1 of the kernel: 123-128 registers, four waves per SIMD; with four
+// in flight 158-166 and three -- measured S 247 -> 256-258, NS 58.4 -> 59.0 scenes/s for the smaller footprint)
 
 // one wave per tile: groups of offsets + sorted union lists + local indices.
 //   * the tile's 64 x 27 slice of the neighbour table is contiguous: 27 independent coalesced loads, then registers;
