@@ -1547,19 +1547,43 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
   float mx = 0.0f;
   for (int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; t < total; t += (int64_t)gridDim.x * blockDim.x * 4) {
     if ((p.Cout & 3) == 0) {
+      // every load of this element group is issued before the first is used, none sits behind a branch (a load behind a
+      // branch or in a loop of unknown length gets its own s_waitcnt vmcnt(0): the slabs were read one round trip at a time
+      // and the epilogue operands one scalar at a time -- ~19 dependent round trips, the 9 us this launch took whatever
+      // its size); the slabs are still added in slab order
+      const int col = (int)(t % p.Cout);
+      const float* dummy = p.slab + t;                                        // a valid 16-byte aligned address
+      const float4 sc4 = *reinterpret_cast<const float4*>(p.scale ? p.scale + col : dummy);
+      const float4 sh4 = *reinterpret_cast<const float4*>(p.shift ? p.shift + col : dummy);
+      const float4 rs4 = *reinterpret_cast<const float4*>(p.residual ? p.residual + t : dummy);
       float4 s = *reinterpret_cast<const float4*>(p.slab + t);
-      for (int z = 1; z < p.splits; ++z) {
-        const float4 q = *reinterpret_cast<const float4*>(p.slab + (int64_t)z * slab_stride + t);
-        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+      int z = 1;
+      for (; z + 3 < p.splits; z += 4) {
+        const float* b = p.slab + (int64_t)z * slab_stride + t;
+        const float4 q0 = *reinterpret_cast<const float4*>(b), q1 = *reinterpret_cast<const float4*>(b + slab_stride),
+                     q2 = *reinterpret_cast<const float4*>(b + 2 * slab_stride), q3 = *reinterpret_cast<const float4*>(b + 3 * slab_stride);
+        s.x += q0.x; s.y += q0.y; s.z += q0.z; s.w += q0.w;
+        s.x += q1.x; s.y += q1.y; s.z += q1.z; s.w += q1.w;
+        s.x += q2.x; s.y += q2.y; s.z += q2.z; s.w += q2.w;
+        s.x += q3.x; s.y += q3.y; s.z += q3.z; s.w += q3.w;
+      }
+      {                                                                      // the last <= 3 slabs: clamped (re-read), added under a uniform test
+        const int z1 = min(z + 1, p.splits - 1), z2 = min(z + 2, p.splits - 1);
+        const float4 q0 = *reinterpret_cast<const float4*>(p.slab + (int64_t)min(z, p.splits - 1) * slab_stride + t),
+                     q1 = *reinterpret_cast<const float4*>(p.slab + (int64_t)z1 * slab_stride + t),
+                     q2 = *reinterpret_cast<const float4*>(p.slab + (int64_t)z2 * slab_stride + t);
+        if (z < p.splits) { s.x += q0.x; s.y += q0.y; s.z += q0.z; s.w += q0.w; }
+        if (z + 1 < p.splits) { s.x += q1.x; s.y += q1.y; s.z += q1.z; s.w += q1.w; }
+        if (z + 2 < p.splits) { s.x += q2.x; s.y += q2.y; s.z += q2.z; s.w += q2.w; }
       }
       float v[4] = {s.x, s.y, s.z, s.w};
-      const int col = (int)(t % p.Cout);
+      const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, rsv[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = v[j];
-        if (p.scale) x = x * p.scale[col + j];
-        if (p.shift) x = x + p.shift[col + j];
-        if (p.residual) x = x + p.residual[t + j];
+        if (p.scale) x = x * scv[j];
+        if (p.shift) x = x + shv[j];
+        if (p.residual) x = x + rsv[j];
         v[j] = apply_act(x, p.act);
         mx = fmaxf(mx, fabsf(v[j]));
         if (p.out_split) store_split(p.out_split, t / p.Cout, p.Cout, col + j, v[j]);
