@@ -34,22 +34,37 @@ HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0   # measured float4 copy (same guide)
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_F16_PEAK_TFLOPS = 2500.0
-# HBM-side traffic of the dominant kernel per launch from the PMC passes committed under profiles/ (separate rocprofv3
-# --pmc runs: FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM" -- + WRITE_SIZE)
-PMC_TRAFFIC = {
-    # (workload, kernel) -> (bytes per launch, source): per-kernel sums of the passes / launches (profiles/README.md)
-    ("NS", "dense"): (58.9e9, "profiles/r04b_ns_pmc_FETCH_SIZE.csv (x2) + r04b_ns_pmc_WRITE_SIZE.csv: 25.83e6 KB x 2 + 7.26e6 KB per "
-                              "launch of backproject_accum_pipe_kernel (the same kernel alone: r04_dense_alone_pmc_*.csv, 25.87e6 / "
-                              "7.26e6 KB); L2<->fabric traffic, i.e. Infinity Cache + HBM (TCC: 350 M hits / 471 M misses incl. the "
-                              "226 M 32-byte write pieces; read hit rate 30 %; the replay simulation scripts/dense_l2sim.cpp puts the "
-                              "HBM share at ~19 GB of reads + 7.3 GB of writes)"),
-    ("NS", "conv"): (139.8e6, "profiles/r04b_ns_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
-                              "(2 x fetch + write) / 51 launches (7.13 GB per scene; 15.06 GB before the gather-once kernel)"),
-    ("S", "dense"): (1.04e9, "profiles/r04b_s_pmc_FETCH_SIZE.csv (x2) + r04b_s_pmc_WRITE_SIZE.csv"),
-    ("S", "conv"): (101.7e6, "profiles/r04b_s_pmc_*: all sparse_conv_go_kernel / sparse_conv_bf16x6_kernel instantiations, "
-                             "(2 x fetch + write) / 51 launches (5.19 GB per scene, L2<->fabric: the operands are Infinity-Cache "
-                             "resident; 9.70 GB before the gather-once kernel)"),
-}
+# HBM-side traffic of the dominant kernel per launch: READ from the per-kernel sums of the PMC passes committed under
+# profiles/ (scripts/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs folded by scripts/pmc_sum.py;
+# counter unit KB; FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM")
+PMC_TAG = "r04b"
+PMC_KERNELS = {"dense": ("backproject_accum",), "conv": ("sparse_conv_",)}
+
+
+def pmc_traffic(workload, family, tag=None, profiles=None):
+    """(bytes per launch, source) of a kernel family from profiles/<tag>_<workload>_pmc_{FETCH_SIZE,WRITE_SIZE}.csv:
+    (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the family's instantiations / their dispatches.  None when the
+    passes are not there (roofline.traffic is then null, never a stale constant)."""
+    import csv
+    tag = tag or PMC_TAG
+    profiles = profiles or os.path.join(ROOT, "profiles")
+    total, launches, files = 0.0, None, []
+    for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(profiles, f"{tag}_{workload.lower()}_pmc_{counter}.csv")
+        if not os.path.exists(path):
+            return None
+        kb, n = 0.0, 0
+        with open(path, newline="") as f:
+            for r in csv.DictReader(f):
+                if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in PMC_KERNELS[family]):
+                    kb += float(r["Sum"])
+                    n += int(r["Dispatches"])
+        if n == 0:
+            return None
+        total += mult * kb * 1024.0 / n
+        launches = n
+        files.append(os.path.relpath(path, ROOT))
+    return total, f"{files[0]} (x2) + {files[1]}: per-kernel sums over {launches} dispatches of {'/'.join(PMC_KERNELS[family])}*"
 
 
 PASS_DEFAULT = {}             # workload -> scenes per sparse-network pass (measured: see DESIGN.md "Scenes per pass")
@@ -296,6 +311,8 @@ def cpu_baseline(shape_name, Ms_full, C):
     fx_dense, fx_rma = V_full / n_views * (C_full / C_s), V_full / n_views * (H / rows)
     return dict(value=1.0 / est, unit="scenes/s", cores=cores, kind="port",
                 stage_s=dict(dense=dense_scene, rma=rma_scene, sparse=t_sparse),
+                sample_short=f"oracle/ on {cores} threads: dense {n_views}/{V_full} views x {C_s}/{C_full} ch (x{fx_dense:g}), RMA {n_views}/"
+                             f"{V_full} views x {rows}/{H} rows (x{fx_rma:g}), sparse net full {Ms_full}-point set (x1)",
                 extrapolated=dict(dense=f"x{fx_dense:g} ({n_views} of {V_full} views x {C_s} of {C_full} channels, linear)",
                                   rma=f"x{fx_rma:g} ({n_views} of {V_full} views x {rows} of {H} image rows, linear)",
                                   sparse="x1 (full point set)"),
@@ -647,7 +664,7 @@ def profile_block(wl, block, name):
     if dominant in ("dense", "nhwc", "march"):
         # the march is cache-resident VALU work and the layout pass is not algorithmic traffic: the HBM-bound kernel the
         # metric is about is the dense unprojection; report it (and say which kernel is actually the longest)
-        tr = PMC_TRAFFIC.get((name, "dense"))
+        tr = pmc_traffic(name, "dense")
         roof = dict(kernel="backproject_accum kernel (cnrma_backproject_accum_f32)", bound="hbm", achieved=B["dense"] / 1e6 / dense_ms,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=B["dense"] / 1e6 / dense_ms / HBM_PEAK_GBS,
                     traffic=tr[0] if tr else None, traffic_source=tr[1] if tr else None, launch_ms=dense_ms,
@@ -655,7 +672,7 @@ def profile_block(wl, block, name):
                     note="algorithmic bytes = 4*V*C*H*W + 4*C*G + 4*G + 48*V (SURVEY 8d) / HIP-event launch time on the launch "
                          "stream (eager pass outside the timed region)")
     else:
-        tr = PMC_TRAFFIC.get((name, "conv"))
+        tr = pmc_traffic(name, "conv")
         roof = dict(kernel="sparse_conv_go_kernel / sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_go_f16x3, "
                            "cnrma_sparse_conv_f16x3), all launches of one scene",
                     bound="mfma", achieved=F_alg / 1e9 / conv_ms, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
@@ -666,6 +683,102 @@ def profile_block(wl, block, name):
                          "against the dense fp16 MFMA peak; the f16x3 arithmetic issues 3 fp16 products per fp32 product, "
                          "so the MFMA pipe itself runs at 3x this fraction")
     return roof
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# output: ONE stdout line of <= 4 KB (what the driver parses) + everything else in bench_detail.json beside bench.py
+# ------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms")
+DETAIL_NAME = "bench_detail.json"
+
+
+def _r(x, nd=4):
+    """floats to `nd` significant digits (the line is for reading and parsing, the detail file keeps full precision)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    return x
+
+
+def _roof(r):
+    if not r:
+        return None
+    out = {k: r.get(k) for k in ROOF_KEYS}
+    out["kernel"] = str(out["kernel"])[:96]
+    return out
+
+
+def _cpu(c, sample=True):
+    if not c:
+        return None
+    out = dict(value=c["value"], unit=c["unit"], cores=c["cores"], kind=c["kind"], stage_s=c.get("stage_s"))
+    if sample:
+        out["sample"] = str(c.get("sample_short") or c.get("sample", ""))[:200]
+    return out
+
+
+def compact_line(result):
+    """The driver-facing line: the contract's keys + `roofline` + `cpu_baseline` (+ the S block and the three labelled
+    variants as numbers only).  Kernel tables, per-layer convolution tables, stage times, notes and the long `sample` /
+    `traffic_source` strings live in bench_detail.json.  Pure function of `result` (tests/test_bench_line_cpu.py)."""
+    cfg = result.get("config", {})
+    line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                        "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "scenes_per_step", "M_rows", "M_selected", "M_unique", "level_rows", "head_rows")
+                      if k in cfg}
+    for k in ("ms_per_scene", "plan_violations", "value_f32_conv", "feature_layout", "graph_nodes_per_scene"):
+        if k in result:
+            line[k] = result[k]
+    if result.get("conv"):
+        line["conv_ms_per_scene"] = result["conv"].get("ms_per_scene")
+    if result.get("whole_path_hbm"):
+        line["whole_path_hbm_frac"] = result["whole_path_hbm"].get("frac_of_8TBps")
+    line["roofline"] = _roof(result.get("roofline"))
+    line["cpu_baseline"] = _cpu(result.get("cpu_baseline"))
+    if result.get("S"):
+        s = result["S"]
+        line["S"] = dict(value=s["value"], ms_per_step=s["ms_per_step"], ms_per_scene=s.get("ms_per_scene"),
+                         graph_nodes_per_scene=s.get("graph_nodes_per_scene"),
+                         conv_ms_per_scene=(s.get("conv") or {}).get("ms_per_scene"),
+                         roofline=_roof(s.get("roofline")), cpu_baseline=_cpu(s.get("cpu_baseline"), sample=False))
+    for k in ("through_plugin", "nchw_input", "f32_conv", "train_S"):
+        if result.get(k):
+            line[k] = {kk: result[k][kk] for kk in ("value", "ms_per_step") if kk in result[k]}
+    if result.get("dist"):
+        d = result["dist"]
+        line["dist"] = dict(world_size=d.get("world_size"), backend=d.get("backend"))
+    line["detail"] = DETAIL_NAME
+    line = _r(line)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:                                          # never print a line the driver cannot parse
+        for k in ("train_S", "f32_conv", "nchw_input", "through_plugin", "dist"):
+            line.pop(k, None)
+        line["config"] = {k: v for k, v in line["config"].items() if k in ("workload", "scenes_per_step")}
+        line["config"]["workload"] = line["config"].get("workload", "")[:200]
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit(result):
+    """detail file + stderr first, then the ONE stdout line, last thing this process prints"""
+    text = compact_line(result)
+    detail = json.dumps(result, indent=1, default=str)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                    f.write(detail)
+        except OSError as e:                                             # a read-only tree must not cost the line
+            log(f"could not write {d}/{DETAIL_NAME}: {e}")
+    log(f"detail: {DETAIL_NAME} ({len(detail)} bytes); line: {len(text)} bytes")
+    sys.stderr.flush()
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -708,8 +821,11 @@ def main():
         "metric": "scenes/sec fwd (40-view->192^3 voxel): dense unprojection + RMA + voxelise + FCAF3D + decode",
         "value": main_block["value"], "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": main_block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (sparse convolutions f16x3: 22-bit operands, fp32 accumulate; block f32_conv = exact fp32)", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}, fp32 [V,C,H,W], " +
+        "dtype": "f32 (sparse conv f16x3: 22-bit operands, fp32 accumulate; value_f32_conv = exact fp32)", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {V} views x {C} ch x {H}x{W} fp32 maps ({wl.layout}) -> grid {dims[0]}x{dims[1]}x{dims[2]}, "
+                               f"N=300, max_points=500000, FCAF3D MinkResNet34 + head, 1 HIP graph per scene, {len(wl.slots) or 1} in flight",
+                   "scenes_per_step": main_block["scenes_per_step"],
+                   "description": f"{args.workload}: V={V} views, C={C}, feature maps {H}x{W} (stride {stride}, fp32 [V,C,H,W], " +
                                ("channels-last in memory -- what the plugin's 2D stack, run in torch.channels_last, hands over "
                                 "(MultiViewBase.channels_last_2d) --, read in place by reference; block `nchw_input` = the same maps "
                                 "handed over NCHW, layout pass inside the timed path" if wl.layout == "channels_last" else
@@ -803,7 +919,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(name, Ms_full, C)
         log("done")
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
         dist.destroy_process_group()
 
