@@ -106,7 +106,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class CnrmaError(RuntimeError):

@@ -296,10 +296,13 @@ class StaticScene:
     buffers, valid until the next run() of this object; `status` (device int32) counts violated capacity / branch
     assumptions -- non-zero means the scene outgrew the plan and must be re-run eagerly (forward_scene)."""
 
-    def __init__(self, cfg, backbone, head, device, margin=1.2, dense=True, stream=None):
+    def __init__(self, cfg, backbone, head, device, margin=1.2, dense=True, stream=None, by_reference=True):
         self.cfg, self.backbone, self.head = cfg, backbone, head
         self.device = torch.device(device)
         self.margin, self.dense = margin, dense
+        # feature hand-off of channels-last maps (run()'s `by_reference` overrides it per scene): True = the trace reads the
+        # caller's tensor in place for the WHOLE replay; False = copied into the slot's own buffer first
+        self.by_reference = bool(by_reference)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
         self.graph = None
         self.plan = None
@@ -351,8 +354,9 @@ class StaticScene:
                 self.march.feat = self.nhwc
         return self.nhwc
 
-    def _load(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
-        """stage one scene's inputs into the static buffers (on self.stream, which must be current).  proj_inv: the
+    def _load(self, features_nchw, projections, tsdf, proj_inv=None, offset=None, by_reference=None):
+        """stage one scene's inputs into the static buffers (on self.stream, which must be current).  by_reference: see
+        run().  proj_inv: the
         [V,4,4] inverse of [P/stride; 0 0 0 1] when the caller pins it (parity tests: LAPACK's inverse is not bit-stable
         across host CPUs); computed here on the host like ray_marching.py:96-102 otherwise."""
         if self._copied is not None:
@@ -373,9 +377,11 @@ class StaticScene:
         # are channels-last in memory are read in place (NeuS mode); everything else goes through the layout pass (NCHW ->
         # the slot's buffer, in ONE launch with the march)
         layout_from = None
+        by_reference = self.by_reference if by_reference is None else bool(by_reference)
+        self._held = None
         if features_nchw is None:
             addr = self._nhwc_buffer().data_ptr()
-        elif rma.is_channels_last(features_nchw) and self.march is not None:
+        elif rma.is_channels_last(features_nchw) and self.march is not None and by_reference:
             assert tuple(features_nchw.shape) == (self.shape_nhwc[0], self.shape_nhwc[3], self.shape_nhwc[1], self.shape_nhwc[2])
             addr = features_nchw.data_ptr()
             self._held = features_nchw           # alive until this slot takes its next scene
@@ -393,6 +399,8 @@ class StaticScene:
             self.march.march(layout_from=layout_from, into=self.march_out)
         elif layout_from is not None:            # depth mode: the layout pass alone (its two small kernels run inside the trace)
             rma.to_nhwc(layout_from, out=self.nhwc)
+        self._consumed = torch.cuda.Event()      # copies and the layout pass are behind this point: unless the maps are read
+        self._consumed.record()                  # by reference (self._held), the caller's feature tensor is free again
 
     def _enter(self, *inputs):
         """order self.stream behind the caller's stream (the 2D backbone / Atlas head that produced the inputs ran
@@ -488,25 +496,41 @@ class StaticScene:
             self.out = self._trace()                         # plain static run: creates the trace's constants
             self.stream.synchronize()
             if capture:
-                self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+                try:                                             # keep_graph only serves the node count, a diagnostic
+                    self.graph, kept = torch.cuda.CUDAGraph(keep_graph=True), True
+                except TypeError:                                # a torch build without it: capture instantiates by itself
+                    self.graph, kept = torch.cuda.CUDAGraph(), False
                 with torch.cuda.graph(self.graph, stream=self.stream):
                     self.out = self._trace()
-                self.n_nodes = graph_node_count(self.graph)      # launches per scene inside the graph (bench: graph_nodes_per_scene)
-                self.graph.instantiate()
+                self.n_nodes = graph_node_count(self.graph) if kept else None   # launches per scene (bench: graph_nodes_per_scene)
+                if kept:
+                    self.graph.instantiate()
                 self.stream.synchronize()
         self._tag = weights_tag(self._weights)
         return eager
 
-    def run(self, features_nchw, projections, tsdf, proj_inv=None, offset=None):
+    def run(self, features_nchw, projections, tsdf, proj_inv=None, offset=None, by_reference=None):
         """enqueue one scene on self.stream (ordered behind the caller's current stream, which produced the inputs);
         returns the static output dict (device tensors, valid until the next run; consumers on another stream wait on
-        `self.done` first -- detections() does)."""
+        `self.done` first -- detections() does).
+
+        Feature hand-off (`by_reference`, None = the slot's default set at construction, True unless told otherwise):
+        * maps that are channels-last in memory and by_reference=True: the captured graph reads the CALLER'S tensor in
+          place during the whole replay (~16 ms at the north-star shape, with up to `slots` scenes in flight).  CONTRACT: the
+          caller must not write that memory -- no in-place op, no reuse of a preallocated / double-buffered / graph-static
+          output buffer of the 2D network -- until `out["done"]` has completed.  The slot only keeps the memory from being
+          freed or recycled (it holds the tensor and record_stream()s it); an in-place overwrite corrupts the dense volume
+          and the point features silently (the plan status stays 0).
+        * by_reference=False (or NCHW maps, always): the maps are copied / converted into the slot's own buffer (12.6 GB
+          at the north-star shape, allocated on first use) before the trace starts; the caller may overwrite them as soon
+          as `out["inputs_consumed"]` (an event on the slot's stream) has completed."""
         if self.graph is not None and self.check_weights and weights_tag(self._weights) != self._tag:
             raise _lib.CnrmaError("the model's weights changed since this scene graph was captured (optimiser step, "
                                   "load_state_dict, .to()): the graph replays prepared weight images -- rebuild() it")
         self._enter(features_nchw, tsdf)
         with torch.cuda.stream(self.stream):
-            self._load(features_nchw, projections, tsdf, proj_inv, offset)
+            self._load(features_nchw, projections, tsdf, proj_inv, offset, by_reference)
+            consumed = self._consumed
             if self.graph is not None:
                 self.graph.replay()
             else:
@@ -514,6 +538,8 @@ class StaticScene:
             self.done = torch.cuda.Event()
             self.done.record()
         self.out["done"] = self.done
+        # when the caller may write the feature maps again: by reference -> only after the whole scene
+        self.out["inputs_consumed"] = self.done if self._held is not None else consumed
         return self.out
 
     def rebuild(self, features_nchw, projections, tsdf):
@@ -550,13 +576,13 @@ class StaticScene:
             info.update(M=counts[0], M_selected=counts[1])
         return out["bboxes"].index_select(0, rows), out["scores"].index_select(0, rows), info
 
-    def detect(self, features_nchw, projections, tsdf, rebuild_after=4, offset=None):
+    def detect(self, features_nchw, projections, tsdf, rebuild_after=4, offset=None, by_reference=None):
         """run() + detections() with the fallback a server wants: a scene that outgrows the size plan (status != 0) is
         re-run through the eager path (sizes read back from the device) and its sizes are kept; after `rebuild_after`
         such scenes the plan is enlarged and the graph captured again (rebuild()), so a deployment whose scenes grew
         stops paying a replay plus an eager pass per scene.  Returns (bboxes, scores, info); info["static"] tells which
         path produced them."""
-        out = self.run(features_nchw, projections, tsdf, offset=offset)
+        out = self.run(features_nchw, projections, tsdf, offset=offset, by_reference=by_reference)
         try:
             with torch.cuda.stream(self.stream):          # the read-back waits on the stream the graph runs on
                 b, s, info = self.detections(out)

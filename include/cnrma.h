@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 3
+#define CNRMA_ABI_VERSION 4   /* 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
 
 int cnrma_abi_version(void);
 

@@ -59,7 +59,8 @@ class RayMarching(MultiViewBase):
                  voxel_size_fcaf3d=0.01, use_batchnorm_train=True, use_batchnorm_test=True, max_points=None,
                  train_cfg=None, test_cfg=None, pretrained=None, use_feature_transform=True,
                  ray_marching_type="neus", depth_points=None, neus_threshold=None, middle_save_path=None,
-                 middle_visualize_path=None, point_sampler="device", static_test=True, static_slots=3, static_calibration=2):
+                 middle_visualize_path=None, point_sampler="device", static_test=True, static_slots=3, static_calibration=2,
+                 static_feature_handoff="reference"):
         super().__init__(pixel_mean, pixel_std, voxel_size, n_scales, voxel_dim_train, voxel_dim_test, origin, backbone2d_stride,
                          backbone2d, feature_2d, backbone_3d, tsdf_head, save_path)
         self.detection_backbone = build_backbone(detection_backbone)
@@ -93,6 +94,14 @@ class RayMarching(MultiViewBase):
         # flight, the first `static_calibration` scenes eagerly (they size the graphs); see _forward_test_static
         self.static_test, self.static_slots, self.static_calibration = static_test, int(static_slots), int(static_calibration)
         self.static_margin = 1.2          # capacity = recorded size x margin (+ slack) of the graphs' size plan
+        # how the fast path takes channels-last feature maps (pipeline.StaticScene.run): "reference" = the scene graph reads
+        # the tensor the 2D stack (or the caller, for precomputed `features`) handed over, in place, until the scene has
+        # left the GPU -- the producer must hand over a tensor it does not write again (a fresh allocation per scene, what
+        # torch modules do; NOT a preallocated / double-buffered / graph-static output buffer); "copy" = copied into the
+        # slot's own buffer first (+12.6 GB per slot and ~3.5 ms per scene at the north-star shape), nothing is assumed
+        if static_feature_handoff not in ("reference", "copy"):
+            raise ValueError(f"static_feature_handoff must be 'reference' or 'copy', got {static_feature_handoff!r}")
+        self.static_feature_handoff = static_feature_handoff
         self._static = {}
         self._writer = None
         import atexit
@@ -299,6 +308,9 @@ class RayMarching(MultiViewBase):
         return self._run(inputs, test=False)
 
     def forward_test(self, inputs):
+        """reference :456-521.  On the graph path (see _forward_test_static) precomputed `features` that are channels-last in
+        memory are read IN PLACE by the scene's graph until the scene has left the GPU (flush() / the scene's result file):
+        do not overwrite that tensor before then, or construct the detector with static_feature_handoff="copy"."""
         if self._static_eligible(inputs):
             with torch.no_grad():
                 self._forward_test_static(inputs)
@@ -366,7 +378,7 @@ class RayMarching(MultiViewBase):
                                        self.neus_threshold if self.ray_marching_type == "neus" else 0.05,
                                        self.max_points, self.voxel_size_fcaf3d, self.ray_marching_type, self.depth_points, "device")
             first = pipeline.StaticScene(cfg, self.detection_backbone, self.detection_head, feats.device, margin=self.static_margin,
-                                         dense=dense_in_graph)
+                                         dense=dense_in_graph, by_reference=self.static_feature_handoff == "reference")
             ctx = dict(cfg=cfg, slots=[first], pending=[None] * max(1, self.static_slots), seen=0, k=0, built=False,
                        weights=pipeline.weight_tensors(self.detection_backbone, self.detection_head), tag=None, grown=0)
             self._static[key] = ctx
@@ -426,7 +438,7 @@ class RayMarching(MultiViewBase):
         ctx["slots"] = [first]
         for _ in range(1, max(1, self.static_slots)):
             st = pipeline.StaticScene(ctx["cfg"], self.detection_backbone, self.detection_head, feats.device, margin=first.margin,
-                                      dense=dense_in_graph)
+                                      dense=dense_in_graph, by_reference=first.by_reference)
             st.build(feats, proj, tsdf, plan=first.plan)
             ctx["slots"].append(st)
         ctx["built"], ctx["grown"] = True, 0

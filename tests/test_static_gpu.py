@@ -323,3 +323,34 @@ def test_channels_last_maps_are_read_in_place_with_identical_results(device, sha
     assert not torch.equal(a[0], other[0])
     eager = pipeline.forward_scene(cfg, backbone, head, cl, proj, tsdf)
     assert torch.equal(eager["volume"], a[0]) and torch.equal(eager["count"], a[1])
+
+
+def test_copy_hand_off_lets_the_producer_overwrite_its_buffer(device):
+    """reading channels-last maps in place is a contract (nobody writes them until out["done"]); a producer
+    that reuses its output buffer asks for by_reference=False: the maps are copied into the slot's buffer, the caller may
+    overwrite its tensor once out["inputs_consumed"] has completed, and the results are those of the reference hand-off."""
+    from cnrma_amd import pipeline
+    sc, feat, proj, tsdf = _scene("tiny", 3, device, boxes=2)
+    backbone, head = _model(feat.shape[1], device)
+    cfg = pipeline.SceneConfig(sc["dims"], stride=sc["stride"], max_points=20000, sample_seed=77)
+    cl = feat.contiguous(memory_format=torch.channels_last)
+    st = pipeline.StaticScene(cfg, backbone, head, device)
+    st.build(cl, proj, tsdf)
+    out = st.run(cl, proj, tsdf)
+    assert st._held is cl and out["inputs_consumed"] is out["done"]      # by reference: free again only after the scene
+    b0, s0, _ = pipeline.StaticScene.detections(out)
+    vol0, b0, s0 = out["volume"].clone(), b0.clone(), s0.clone()
+    buf = cl.clone(memory_format=torch.channels_last)                    # a producer-owned, reused output buffer
+    out = st.run(buf, proj, tsdf, by_reference=False)
+    assert st._held is None and st.nhwc is not None and out["inputs_consumed"] is not out["done"]
+    out["inputs_consumed"].synchronize()
+    buf.zero_()                                                          # the producer's next output lands in the same memory
+    b1, s1, _ = pipeline.StaticScene.detections(out)
+    assert torch.equal(out["volume"], vol0) and torch.equal(b1, b0) and torch.equal(s1, s0)
+    # slot-level default
+    st2 = pipeline.StaticScene(cfg, backbone, head, device, by_reference=False)
+    st2.build(cl, proj, tsdf, plan=st.plan)
+    out2 = st2.run(cl, proj, tsdf)
+    assert st2._held is None
+    b2, s2, _ = pipeline.StaticScene.detections(out2)
+    assert torch.equal(out2["volume"], vol0) and torch.equal(b2, b0) and torch.equal(s2, s0)
