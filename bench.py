@@ -108,6 +108,8 @@ def parse():
                     help="memory layout of the resident feature maps [V,C,H,W]: channels_last (default) = what the plugin's 2D stack "
                          "hands over (MultiViewBase.channels_last_2d: the 2D network runs in torch.channels_last), read in place; "
                          "nchw = the reference's layout, converted by the layout pass inside the timed path")
+    ap.add_argument("--detail", default="", help="where the full result (kernel tables, per-layer convolution table, stage times, notes) "
+                    "goes; default: bench_detail.json beside bench.py (and a copy under gpurun_out/ when that directory exists)")
     ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
                     "'variant=0' = the round-2 kernel (cnrma_debug_dense_tuning; never set by the driver)")
     return ap.parse_args()
@@ -764,17 +766,18 @@ def compact_line(result):
     return text
 
 
-def emit(result):
+def emit(result, detail_path=""):
     """detail file + stderr first, then the ONE stdout line, last thing this process prints"""
     text = compact_line(result)
     detail = json.dumps(result, indent=1, default=str)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    targets = [detail_path] if detail_path else [os.path.join(ROOT, DETAIL_NAME), os.path.join(ROOT, "gpurun_out", DETAIL_NAME)]
+    for path in targets:
         try:
-            if os.path.isdir(d):
-                with open(os.path.join(d, DETAIL_NAME), "w") as f:
+            if os.path.isdir(os.path.dirname(os.path.abspath(path))):
+                with open(path, "w") as f:
                     f.write(detail)
         except OSError as e:                                             # a read-only tree must not cost the line
-            log(f"could not write {d}/{DETAIL_NAME}: {e}")
+            log(f"could not write {path}: {e}")
     log(f"detail: {DETAIL_NAME} ({len(detail)} bytes); line: {len(text)} bytes")
     sys.stderr.flush()
     sys.stdout.write(text + "\n")
@@ -919,7 +922,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(name, Ms_full, C)
         log("done")
     if rank == 0:
-        emit(result)
+        emit(result, args.detail)
     if world > 1:
         dist.destroy_process_group()
 

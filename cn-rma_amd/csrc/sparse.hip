@@ -1667,7 +1667,7 @@ constexpr int CONV_WS_SLOTS = 0;       // product default of the warp-specialise
 
 // Debug / A-B switches of the convolution launcher (cnrma_debug_conv_tuning: scripts/conv_sweep.py and the tests that force a
 // variant).  Product code never changes them; -1 = the launcher's own choice.
-struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; int ws = -1; int xcd = -1; };   // ws: LDS ring slots of the warp-specialised kernel (0 = stage kernel)
+struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; int ws = -1; int xcd = -1; int go = -1; int nb = -1; };   // ws: LDS ring slots of the warp-specialised kernel (0 = stage kernel)
 static ConvTune g_conv_tune;
 
 enum ConvShape { T128x128, T128x64, T64x64, T128x32, T64x128, T256x128, T256x64, N_CONV_SHAPES };   // the last two: warp-specialised kernel only
@@ -2376,6 +2376,343 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoAr
   if (p.out_amax != nullptr) {
     __syncthreads();
     block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(&Us[0][0]));
+  }
+}
+
+// ================================================================================================================
+// Gather-once convolution, second form (round 5).  The first form's blocks were timed phase by phase with s_memtime stamps
+// (scripts/go_stamps.py, profiles/r05_go_stamps_*.log; 277 k rows, 64 -> 64, 77.8 k cycles per block at four blocks per CU):
+// header / local indices / first barrier 15 %, the two union gathers 11 % each, the two offset phases 24 + 20 %, the barrier
+// between them 7 %, merge + epilogue 12 % -- the matrix pipe sees a block for 44 % of its life (SQ_VALU_MFMA_BUSY 0.52 with four
+// blocks per CU), the rest is chains of dependent loads.  Two tiles per block (half the weight bytes per MFMA, two blocks per
+// CU) and four weight offsets in flight were built and measured 10-40 % / 0-5 % SLOWER (profiles/r05_go_forms_S.log): the
+// weight stream is not the bound, the chains are.  This form keeps the tile, the image and the summation order (bit-identical
+// results: the test) and shortens the chains:
+//   * everything a block needs first is requested before anything is waited for: the tile header as ONE 16-byte scalar load,
+//     the local indices, the first 128 row numbers of group 0 (speculatively: group 0 starts at entry 0 of the tile's list),
+//     the magnitude bounds and the epilogue's scale / shift;
+//   * the row numbers of group 0 stay in LDS for the later channel slices: their gathers are one round trip, not two;
+//   * the offset loop is scalar: the wave index is made uniform (readfirstlane), so the offset masks, the pop of the next offset
+//     and the weight addresses live in SGPRs (hipcc had kept them in VGPRs -- a divergent loop with 64-bit vector multiplies per
+//     step); weight fragments are loaded with an SGPR base + lane offset;
+//   * the local indices of the next offset are read one step ahead of its MFMAs;
+//   * the grid is one-dimensional and decoded so that the blocks sharing operands run on ONE XCD (workgroups are dealt round-
+//     robin over the 8 XCDs, each with a private 4-MB L2): layers split over many (column tile, channel slice) groups -- the
+//     small levels, whose weight tensors are 7-28 MB -- keep every group on one XCD, so a group's weights are pulled from the
+//     fabric once instead of once per XCD (541 rows x 512 -> 512: 56.7 -> 38 us); layers with few groups give each XCD one
+//     contiguous eighth of the row tiles (neighbouring tiles share most of their union rows).
+// ================================================================================================================
+struct Go2Map { int tiles, ncol, ng, mode, per; };   // mode 0: block L = tile L / ng, group L % ng; 1: groups -> XCDs; 2: tiles -> XCDs
+// diagnostic build only (STAMP instantiation, conv_tuning(ablate=64)): phase boundaries of every block as s_memtime stamps of its first wave, 16 words
+// per block in the buffer handed over as tile_counters (cdna_hip_programming.md "In-kernel stamps"); read the shares, not the time
+__device__ __forceinline__ void go_stamp(unsigned long long* dbg, int slot) {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0 && slot < 16) dbg[(size_t)blockIdx.x * 16 + slot] = t;
+}
+
+template <int N>
+__device__ __forceinline__ void go_waitn(u32x4_t (&b)[2][2]) {              // everything but the N newest loads has landed
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N));
+}
+__device__ __forceinline__ void go_drain(u32x4_t (&b)[2][2]) {              // every load has landed (names what it releases)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]));
+}
+// one offset's four fragment loads (planes x k-steps, 1024 bytes apart) from an SGPR base + lane offset, as ONE statement.  The
+// s_nop covers the "VALU writes an SGPR, vector memory reads it" hazard (5 wait states): hipcc's hazard recogniser does not look
+// inside inline asm, and when it forms the base with v_readfirstlane right in front of the statement -- seen in the diagnostic
+// instantiation -- the load went out with a stale half of the address (memory fault).  Early-clobber outputs: a landed fragment
+// must not overwrite the lane offset the later loads of the statement still read.
+__device__ __forceinline__ void go_load_frag(u32x4_t (&b)[2][2], const uint16_t* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\t"
+               "global_load_dwordx4 %0, %4, %5 offset:0\n\t"
+               "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+               "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+               "global_load_dwordx4 %3, %4, %5 offset:3072"
+               : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[1][0]), "=&v"(b[1][1]) : "v"(voff), "s"(sbase));
+}
+
+constexpr int GO2_US = (GO_UMAX + 2) * LDK;              // 16-bit elements of one plane of the image
+constexpr int GO2_LDS = 2 * GO2_US * 2 + GO_BM * 27 * 2 + GO_UMAX * 4;     // bytes: two planes, local indices, row numbers
+
+template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false>
+__global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_go2_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag,
+                                                                             Go2Map mp) {
+  static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
+  constexpr int TM = 2, BN = 32 * WAVES_N;
+  extern __shared__ __attribute__((aligned(16))) unsigned char go2_smem[];
+  __bf16* const Us = reinterpret_cast<__bf16*>(go2_smem);                                // [2 planes][(GO_UMAX + 2) * LDK]
+  uint16_t* const Ls = reinterpret_cast<uint16_t*>(go2_smem + 2 * GO2_US * 2);            // [GO_BM * 27]
+  int32_t* const Rs = reinterpret_cast<int32_t*>(go2_smem + 2 * GO2_US * 2 + GO_BM * 27 * 2);   // [GO_UMAX] row numbers of group 0
+  // STAMP: the diagnostic instantiation (conv_tuning(ablate=64)): the product code + s_memtime stamps at its phase boundaries
+  unsigned long long* const dbg = STAMP ? reinterpret_cast<unsigned long long*>(g.counters) : nullptr;
+  int n_stamp = 0;
+  if (STAMP && dbg) go_stamp(dbg, n_stamp++);                  // 0: block start
+  if (STAMP && dbg && threadIdx.x == 0)                        // 14: where the block ran -- XCC_ID (hwreg 20) | HW_ID (hwreg 4) << 32
+    dbg[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) |
+                                        ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
+  const int L = blockIdx.x;
+  int tile_i, grp;
+  if (mp.mode == 1) { grp = (L & 7) + 8 * ((L >> 3) / mp.tiles); tile_i = (L >> 3) % mp.tiles; }
+  else if (mp.mode == 2) { tile_i = (L & 7) * mp.per + (L >> 3) / mp.ng; grp = (L >> 3) % mp.ng; if ((L >> 3) / mp.ng >= mp.per) return; }
+  else { tile_i = L / mp.ng; grp = L % mp.ng; }
+  if (tile_i >= mp.tiles || grp >= mp.ng) return;
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int64_t tile = tile_i, tile0 = tile * GO_BM;
+  if (tile0 >= n_live) return;
+  const int cout0 = (grp % mp.ncol) * BN, zs = grp / mp.ncol;
+  const int Cin = p.Cin, Cout = p.Cout;
+  const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);                  // uniform: everything derived from it stays scalar
+  const int kg = wid / WAVES_N, wc = wid % WAVES_N;
+  const int32_t* th = g.hdr + tile * GO_HDR;
+  const int32_t* tr = g.rows + tile * GO_ROWS;
+  // ---- requests first, waits later: header (one scalar 16-byte load: groups, then group 0's {mask, first entry, entries}),
+  // local indices, the row numbers of the first gather batch (group 0 starts at entry 0; entries behind the union are read
+  // but never used as addresses), bounds, epilogue operands
+  const int4 h0 = *reinterpret_cast<const int4*>(th);
+  uint4 lv = make_uint4(0x00010000u, 0x00030002u, 0x00050004u, 0x00070006u);
+  if (tid < GO_BM * 27 / 8) lv = reinterpret_cast<const uint4*>(g.lidx + tile * (GO_BM * 27))[tid];
+  int32_t pre[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pre[i] = tr[(tid >> 3) + 32 * i];
+  const int col = cout0 + wc * 32 + (lane & 31);
+  const bool col_ok = col < Cout;
+  const int colc = col_ok ? col : 0;
+  const bool use_scale = p.scale != nullptr && p.splits == 1, use_shift = p.shift != nullptr && p.splits == 1;
+  const float sc = use_scale ? p.scale[colc] : 1.0f;
+  const float sh = use_shift ? p.shift[colc] : 0.0f;
+  const float a_scale = f16_scale_for(read_amax(p.in_amax));
+  const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
+  if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls)[tid] = lv;
+  if (tid < 16) {                                            // the zero row of both planes (64 bytes each)
+    reinterpret_cast<uint32_t*>(Us + GO_UMAX * LDK)[tid] = 0u;
+    reinterpret_cast<uint32_t*>(Us + GO2_US + GO_UMAX * LDK)[tid] = 0u;
+  }
+  const int n_groups = __builtin_amdgcn_readfirstlane(h0.x);
+  int s_lo = 0, s_hi = ns;
+  if (p.splits > 1) { s_lo = zs * g.slices_per_split; s_hi = min(ns, s_lo + g.slices_per_split); }
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+
+  const int fhalf = lane >> 5;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const uint16_t* ls0 = Ls + (lane & 31) * 27;               // this lane's rows of the local indices: row, row + 32
+  auto load_b = [&](u32x4_t (&bf)[2][2], int k, int slice) {
+    const uint64_t ba = reinterpret_cast<uint64_t>(wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc) * 2048);
+    const uint16_t* base = reinterpret_cast<const uint16_t*>(                          // uniform by construction: say so
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ba));
+    go_load_frag(bf, base, lane16);                            // [plane][k-step]: 1024 bytes apart
+  };
+  auto load_li = [&](int (&li)[TM], int k) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) li[a] = ls0[a * (32 * 27) + k];
+  };
+  // one offset: A fragments one ahead of their MFMAs (two registers in rotation), as in the first form
+  auto mfma_k = [&](const u32x4_t (&bf)[2][2], const int (&li)[TM]) {
+    auto rd = [&](int a, int pl, int ks) -> f16x8_t {
+      return *reinterpret_cast<const f16x8_t*>(Us + pl * GO2_US + lds_slot(li[a], ks * 2 + fhalf));
+    };
+    f16x8_t cur = rd(0, 1, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f16x8_t bh = __builtin_bit_cast(f16x8_t, bf[0][ks]), bm = __builtin_bit_cast(f16x8_t, bf[1][ks]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        f16x8_t nxt = rd(a, 0, ks);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh, acc[a], 0, 0, 0);       // m*h
+        cur = nxt;
+        const bool last = ks == 1 && a == TM - 1;
+        if (!last) nxt = a + 1 < TM ? rd(a + 1, 1, ks) : rd(0, 1, ks + 1);
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bm, acc[a], 0, 0, 0);       // h*m
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh, acc[a], 0, 0, 0);       // h*h
+        cur = nxt;
+      }
+    }
+  };
+
+  for (int slice = s_lo; slice < s_hi; ++slice) {
+    const int cin0 = slice * BK;
+    for (int grpi = 0; grpi < n_groups; ++grpi) {
+      // (readfirstlane: the header is the same for every lane, but a load hipcc cannot prove unclobbered is a vector load)
+      const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(grpi == 0 ? h0.y : th[1 + 3 * grpi]);
+      const int ub = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.z : th[2 + 3 * grpi]);
+      const int un = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.w : th[3 + 3 * grpi]);
+      unsigned mymask = mask;
+      if constexpr (KS == 2) {                               // every second offset of the group
+        mymask = 0;
+        unsigned m = mask;
+        int r = 0;
+        while (m) {
+          const unsigned low = m & (0u - m);
+          if ((r & 1) == kg) mymask |= low;
+          m ^= low;
+          ++r;
+        }
+      }
+      u32x4_t bf[NB][2][2];
+      int kk[NB];
+      unsigned rest = mymask;
+      const int n_off = __popc(mymask);
+      int k_last = 0;
+      auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { kk[j] = pop(); load_b(bf[j], kk[j], slice); }
+      __syncthreads();                                       // the previous stage's fragment reads are done
+      if (STAMP && dbg) go_stamp(dbg, n_stamp++);              // 1 + 3 i: metadata / previous phase done, weights requested
+      // ---- the union rows of the group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight.  Row numbers:
+      // group 0 in its first slice from memory (the first batch was requested at the top of the kernel) and kept in LDS for
+      // the later slices; other groups (tiles without locality) from memory every time
+      const bool cached = grpi == 0 && slice != s_lo, keep = grpi == 0 && slice == s_lo && s_hi - s_lo > 1;
+      const int tasks = un * 8;
+      for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
+        float4 v[4];
+        int32_t src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tk = t0 + i * 256 + tid;
+          const int r = tk < tasks ? (tk >> 3) : 0;
+          if (cached) src[i] = Rs[r];
+          else if (grpi == 0 && t0 == 0) src[i] = tk < tasks ? pre[i] : tr[0];
+          else src[i] = tr[ub + r];
+          if (keep && (tk & 7) == 0 && tk < tasks) Rs[r] = src[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tk = t0 + i * 256 + tid;
+          v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (tk & 7) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // every loaded value is consumed on every path (tasks behind the union go to the dump row), see the first form
+          const int tk = t0 + i * 256 + tid;
+          const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tk & 7;
+          uint2 h, m;
+          split2(v[i], a_scale, h, m);
+          __bf16* d = Us + lds_slot(u, kc >> 1) + (kc & 1) * 4;
+          *reinterpret_cast<uint2*>(d) = h;
+          *reinterpret_cast<uint2*>(d + GO2_US) = m;
+        }
+      }
+      __syncthreads();
+      if (STAMP && dbg) go_stamp(dbg, n_stamp++);              // 2 + 3 i: union image staged
+      // ---- the group's offsets back to back: no barrier, no LDS store, no index load from memory; the local indices of an
+      // offset are read while the offset before it runs
+      int lin[TM];
+      load_li(lin, kk[0]);
+      int i = 0;
+      for (; i + NB < n_off; i += NB) {                        // steady state: NB offsets per turn, their successors prefetched
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          int li[TM];
+#pragma unroll
+          for (int a = 0; a < TM; ++a) li[a] = lin[a];
+          load_li(lin, kk[(j + 1) % NB]);                      // j + 1 < NB: this turn's next offset; else the next turn's first
+          go_waitn<(NB - 1) * 4>(bf[j]);                       // bf[j] has landed; the NB - 1 sets behind it may still fly
+          mfma_k(bf[j], li);
+          kk[j] = pop();                                       // behind the last offset: the last one again (never used)
+          load_b(bf[j], kk[j], slice);
+        }
+      }
+      // the last <= NB offsets: nothing more to prefetch, and NO load may be left in flight (the asm loads are invisible to the
+      // compiler, which is free to reuse their destination registers from here on)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) go_drain(bf[j]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int li[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) li[a] = lin[a];
+        if (j + 1 < NB) load_li(lin, kk[j + 1]);
+        if (i + j < n_off) mfma_k(bf[j], li);
+      }
+      if (STAMP && dbg) go_stamp(dbg, n_stamp++);              // 3 + 3 i: this wave's offsets issued
+    }
+  }
+
+  if constexpr (KS == 2) {
+    // the two offset halves meet: each wave hands the row tile it does not finish to its partner through LDS (the image is
+    // dead) and finishes the other -- wave (kg, wc) writes rows 32 * kg .. + 31 of columns 32 * wc .. + 31
+    __syncthreads();
+    float* X = reinterpret_cast<float*>(go2_smem);           // 4 x 4 KB
+    float* mine = X + (wc * 2 + kg) * 1024;
+    const float* theirs = X + (wc * 2 + (kg ^ 1)) * 1024;
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[1][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[0][i];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] += theirs[i * 64 + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[1][i] += theirs[i * 64 + lane];
+    }
+  }
+
+  float mx = 0.0f;
+  if (p.splits > 1) {                                        // partial tile into this split's slab; conv_reduce_kernel follows
+    float* slab = p.slab + (int64_t)zs * p.no_cap * Cout;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      if (KS == 2 && a != kg) continue;
+      const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
+        if (col_ok && row < n_live) slab[row * Cout + col] = acc[a][i] * out_scale;
+      }
+    }
+    if (STAMP && dbg) go_stamp(dbg, 15);
+    return;
+  }
+  const int act = p.act;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    if (KS == 2 && a != kg) continue;
+    const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float res[4];
+      if (HAS_RES) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = row0 + q + 8 * rg;
+          const int64_t rc = row < n_live ? row : n_live - 1;
+          res[q] = p.residual[rc * Cout + colc];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t row = row0 + q + 8 * rg;
+        float v = acc[a][rg * 4 + q];
+        v = v * out_scale;
+        v = v * sc;
+        v = v + sh;
+        if (HAS_RES) v = v + res[q];
+        v = apply_act(v, act);
+        if (col_ok && row < n_live) {
+          p.out[row * Cout + col] = v;
+          mx = fmaxf(mx, fabsf(v));
+        }
+      }
+    }
+  }
+  if (STAMP && dbg) go_stamp(dbg, 15);                         // 15: epilogue stores issued
+  if (p.out_amax != nullptr) {
+    __syncthreads();
+    block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(go2_smem));
   }
 }
 
@@ -3152,8 +3489,10 @@ extern "C" int cnrma_debug_conv_tuning(const int* v, int n) {
   // v = {tile shape (0 128x128, 1 128x64, 2 64x64, 3 128x32, 4 64x128), splits over the kernel offsets, prefetch depth}; -1 or
   // missing = the launcher's own choice; n == 0 restores the product configuration.  Host-side global state: A/B runs only.
   ConvTune t;
-  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate, &t.ws, &t.xcd};
-  if (n < 0 || n > 6 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
+  // ... {..., ablation mask, warp-specialised ring, XCD order (0 plain, 1 groups -> XCDs, 2 row tiles -> XCDs), gather-once form
+  // (0 first form, 1 / 2 = second form with 1 / 2 row tiles per block), weight offsets in flight (2 / 4)}
+  int* f[] = {&t.shape, &t.splits, &t.pf, &t.ablate, &t.ws, &t.xcd, &t.go, &t.nb};
+  if (n < 0 || n > 8 || (n > 0 && v == nullptr)) return CNRMA_EINVAL;
   for (int i = 0; i < n; ++i) *f[i] = v[i];
   g_conv_tune = t;
   return 0;
@@ -3463,6 +3802,101 @@ extern "C" int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float*
   return 0;
 }
 
+// ---- second form of the gather-once kernel: instantiation table, work order, splits ---------------------------------------------
+constexpr int GO_FORM_DEFAULT = 1;      // the second form everywhere (scripts/go_forms.py, profiles/r05_go_forms2_*.log: 0.93x summed over
+                                        // the layer classes of an S scene, never slower than the first form in its best work order)
+static int go_form_default(int64_t no_cap, int Cin, int Cout) { (void)no_cap; (void)Cin; (void)Cout; return GO_FORM_DEFAULT; }
+
+template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false>
+static int launch_go2_one(unsigned blocks, const ConvArgs& p, const GoArgs& g, const uint16_t* wfrag, const Go2Map& mp, hipStream_t st) {
+  hipLaunchKernelGGL((sparse_conv_go2_kernel<WAVES_N, KS, HAS_RES, NB, STAMP>), dim3(blocks), dim3(256), GO2_LDS, st, p, g, wfrag, mp);
+  return 0;
+}
+static_assert(GO2_LDS <= 48 * 1024 && 4 * GO2_LDS <= 160 * 1024, "four blocks per CU without raising the dynamic LDS limit");
+
+// what the gather-once launcher runs for a layer: a pure function of the CAPACITY of the output, the widths and the workspace
+// (a captured launch sequence replays the same kernels; cnrma_sparse_conv_go_plan exposes it to the tests)
+struct Go2Plan { int form, bn, ks, splits, slices_per_split, mode, nb; int64_t tiles; unsigned blocks; Go2Map mp; };
+static Go2Plan go2_plan(int64_t no_cap, int Cin, int Cout, bool has_ws, size_t workspace_bytes) {
+  const ConvTune tune = g_conv_tune;
+  Go2Plan pl{};
+  pl.form = tune.go >= 0 ? tune.go : go_form_default(no_cap, Cin, Cout);
+  pl.bn = Cout >= 128 ? 128 : 64;
+  pl.ks = pl.bn == 128 ? 1 : 2;
+  pl.tiles = ceil_div(no_cap, GO_BM);
+  const int ns = Cin / BK;
+  Go2Map& mp = pl.mp;
+  mp.tiles = (int)pl.tiles;
+  mp.ncol = (int)ceil_div(Cout, pl.bn);
+  // short layers: split over the 32-channel slices (every block runs all 27 offsets of its slices); conv_reduce_kernel adds the
+  // partial slabs in slab order
+  int splits = 1;
+  const int64_t blocks0 = pl.tiles * mp.ncol;
+  if (has_ws && ns > 1 && (blocks0 < 384 || tune.splits > 0)) {
+    splits = tune.splits > 0 ? tune.splits : (int)ceil_div(768, blocks0);
+    if (splits > ns) splits = ns;
+    const size_t per = (size_t)no_cap * Cout * sizeof(float);
+    if (per > 0 && (size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+    if (splits < 2) splits = 1;
+  }
+  pl.slices_per_split = (int)ceil_div(ns, splits);
+  pl.splits = (int)ceil_div(ns, pl.slices_per_split);
+  mp.ng = mp.ncol * pl.splits;
+  mp.per = (int)ceil_div(pl.tiles, 8);
+  // work order, measured per layer class (profiles/r05_go_forms2_*.log): a handful of tiles under a 7-28 MB weight tensor (the
+  // 541-966-row level): groups -> XCDs (35 vs 69 us for tiles -> XCDs); the 200-500 k-row layers: plain order (188 vs 205 us);
+  // everything between: each XCD one contiguous eighth of the tiles (38-105 us classes: 3-10 % under the plain order)
+  mp.mode = tune.xcd >= 0 ? tune.xcd : (pl.tiles < 32 && mp.ng >= 8 ? 1 : (pl.tiles >= 2048 ? 0 : 2));
+  pl.mode = mp.mode;
+  if (mp.mode == 1) pl.blocks = 8u * (unsigned)mp.tiles * (unsigned)ceil_div(mp.ng, 8);
+  else if (mp.mode == 2) pl.blocks = 8u * (unsigned)mp.per * (unsigned)mp.ng;
+  else pl.blocks = (unsigned)mp.tiles * (unsigned)mp.ng;
+  pl.nb = tune.nb == 4 ? 4 : 2;
+  return pl;
+}
+
+static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, void* stamps, hipStream_t st) {
+  const Go2Map& mp = pl.mp;
+  g.slices_per_split = pl.slices_per_split;
+  p.splits = pl.splits;
+  g.counters = reinterpret_cast<unsigned*>(stamps);          // diagnostic build: the stamp buffer (16 x 8 bytes per block)
+  if ((p.ablate & 64) && stamps == nullptr) return CNRMA_EINVAL;
+  const unsigned blocks = pl.blocks;
+  const bool has_res = residual && pl.splits == 1;
+  int rc = CNRMA_EINVAL;
+#define CNRMA_GO2(WN, KS_, NB_)                                                                              \
+  rc = stamps != nullptr && !has_res ? launch_go2_one<WN, KS_, false, NB_, true>(blocks, p, g, wfrag, mp, st) \
+       : has_res ? launch_go2_one<WN, KS_, true, NB_>(blocks, p, g, wfrag, mp, st)                           \
+                 : launch_go2_one<WN, KS_, false, NB_>(blocks, p, g, wfrag, mp, st)
+  if (pl.bn == 128) {
+    if (pl.nb == 2) CNRMA_GO2(4, 1, 2);
+    else CNRMA_GO2(4, 1, 4);
+  } else {
+    if (pl.nb == 2) CNRMA_GO2(2, 2, 2);
+    else CNRMA_GO2(2, 2, 4);
+  }
+#undef CNRMA_GO2
+  if (rc != 0) return rc;
+  if (pl.splits > 1) {
+    int64_t rb = ceil_div(p.no_cap * p.Cout / 4 + 1, 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size_t workspace_bytes, int has_residual, int* out8) {
+  // what cnrma_sparse_conv_go_f16x3 launches for these sizes: out8 = {form (0 first, 1 second), tile columns (64: the four waves
+  // are 2 column tiles x 2 offset halves, 128: 4 column tiles), splits over channel slices, slices per split, work order (0
+  // plain, 1 groups -> XCDs, 2 tiles -> XCDs), residual fused in the kernel (0: in conv_reduce_kernel), blocks, weight offsets in flight}
+  if (out8 == nullptr || no_cap <= 0 || Cin <= 0 || Cin % BK != 0 || Cout < 64) return CNRMA_EINVAL;
+  const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace_bytes > 0, workspace_bytes);
+  out8[0] = pl.form >= 1 ? 1 : 0; out8[1] = pl.bn; out8[2] = pl.splits; out8[3] = pl.slices_per_split;
+  out8[4] = pl.form >= 1 ? pl.mode : 0; out8[5] = has_residual && pl.splits == 1; out8[6] = (int)pl.blocks; out8[7] = pl.nb;
+  return 0;
+}
+
 // ---- gather-once convolution: tile unions, fragment-order weights, launcher -----------------------------------------------
 static size_t go_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -3529,6 +3963,12 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   p.w_amax = reinterpret_cast<const float*>(wfrag + 2 * (int64_t)K * Cin * conv_cout_padded(Cout));
   const int bn = Cout >= 128 ? 128 : 64;
   const int ns = Cin / BK;
+  {
+    const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace != nullptr, workspace_bytes);
+    // the other ablation masks (diagnostic kernels with phases switched off) exist in the first form only
+    if (pl.form >= 1 && (g_conv_tune.ablate & ~64) == 0)
+      return launch_go2(pl, p, g, wfrag, residual != nullptr, (g_conv_tune.ablate & 64) ? tile_counters : nullptr, st);
+  }
   // short layers: split over the 32-channel slices (every block still runs all 27 offsets of its slices); partial slabs are
   // reduced by conv_reduce_kernel in a fixed order
   int splits = 1;

@@ -654,26 +654,46 @@ def conv_plan(n_out, Cin, Cout, K, precision=None, slices=1):
     return dict(tile=(out[0], out[1]), splits=out[2], k_per_split=out[3], prefetch=out[4], shape=CONV_SHAPES[out[5]])
 
 
-def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1):
+def conv_go_plan(n_out, Cin, Cout, residual=False):
+    """which gather-once kernel variant conv() launches for an output capacity of n_out rows (3x3x3, stride 1, f16x3):
+    dict(form, columns, ks, splits, slices_per_split, order, residual_in_kernel, blocks, offsets_in_flight, workspace) --
+    cnrma_sparse_conv_go_plan, a pure host function"""
+    import ctypes
+    ws = n_out * Cout * 4 * (Cin // 32) if n_out < GO_WS_ROWS else 0
+    out = (ctypes.c_int * 8)()
+    call("cnrma_sparse_conv_go_plan", int(n_out), int(Cin), int(Cout), ws, int(bool(residual)), out)
+    return dict(form=out[0], columns=out[1], ks=2 if out[1] == 64 else 1, splits=out[2], slices_per_split=out[3],
+                order=("plain", "groups->xcd", "tiles->xcd")[out[4]], residual_in_kernel=bool(out[5]), blocks=out[6],
+                offsets_in_flight=out[7], workspace=ws)
+
+
+def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1, go=-1, nb=-1):
     """debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): force the tile shape ("128x128", ...), the split count
     and the prefetch depth of every later convolution launch; no arguments = the product configuration"""
     import ctypes
-    if shape is None and splits < 0 and pf < 0 and not ablate and ws < 0 and xcd < 0:
+    if shape is None and splits < 0 and pf < 0 and not ablate and ws < 0 and xcd < 0 and go < 0 and nb < 0:
         call("cnrma_debug_conv_tuning", None, 0)
         return
     # ablate (diagnostic kernels, timing only -- results are wrong): bit 0 no MFMAs, 1 no A loads, 2 no B loads, 3 no LDS
     # stores, 4 no barriers after a block's first stage
     # ws: LDS ring slots of the warp-specialised f16x3 kernel (2..4; 0 = the stage kernel; -1 = the launcher's default)
-    # xcd: 1 = each XCD works on one contiguous eighth of the row tiles (0 = tiles dealt round-robin)
-    arr = (ctypes.c_int * 6)(CONV_SHAPES.index(shape) if shape is not None else -1, int(splits), int(pf), int(ablate), int(ws), int(xcd))
-    call("cnrma_debug_conv_tuning", arr, 6)
+    # xcd: stage kernel: 1 = each XCD works on one contiguous eighth of the row tiles (0 = tiles dealt round-robin);
+    #      gather-once second form: 0 plain order, 1 (column tile, slice split) groups -> XCDs, 2 row tiles -> XCDs
+    # go: gather-once kernel form (0 = first form, 1 / 2 = second form with 1 / 2 row tiles per block); nb: weight offsets in
+    #     flight per wave of the second form (2 / 4)
+    arr = (ctypes.c_int * 8)(CONV_SHAPES.index(shape) if shape is not None else -1, int(splits), int(pf), int(ablate), int(ws),
+                             int(xcd), int(go), int(nb))
+    call("cnrma_debug_conv_tuning", arr, 8)
 
 
 GO_CONV = "auto"     # gather-once kernel for the 3x3x3 stride-1 convolutions in f16x3 (csrc/sparse.hip): "auto" = on coordinate sets
                      # whose rows are compact (CoordSet.compact) with >= GO_MIN_ROWS rows; True / False force it (tests, A/B runs)
 GO_UMAX = 280        # csrc/sparse.hip GO_UMAX: rows of a tile's union image in LDS (the local index of "no neighbour")
 GO_WS_ROWS = 65536   # below: a workspace for the split over channel slices is handed to the kernel (it decides)
-GO_MIN_ROWS = 1024   # below: the stage kernel split over the 27 offsets fills the chip better (541-row level: 0.95x)
+GO_STAMPS = None     # diagnostic build of the second form (conv_tuning(ablate=64)): an int64 tensor of 16 words per block
+GO_MIN_ROWS = 256    # below: the stage kernel split over the 27 offsets.  (Round 4: 1024 -- the first form ran the 541-row level at
+                     # 0.95x of the stage kernel; the second form with its (column tile, slice) groups pinned to XCDs runs it at 35 us
+                     # against 56: profiles/r05_go_forms2_S.log)
 PAIR_HDR_BYTES, PAIR_OVERFLOW_WORD = 512, 64 + 34      # csrc/sparse.hip: PAIR_HDR ints, hdr[64 + 34] = "an entry was dropped"
 PAIR_CONV = True     # pair-list kernel for stride-2 convolutions whose kernel map is nearly empty (the stem)
 # regrouping the table costs ~0.2 ms per 450 k output rows (count, plan, fill, reduce: MI355X); the tile kernel wastes
@@ -754,7 +774,7 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
                 go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < GO_WS_ROWS else 0
                 go_ws = _workspace(go_ws_bytes, x.device) if go_ws_bytes else None
                 counters = _tile_counters(x.device) if GO_INKERNEL_REDUCE and go_ws_bytes and \
-                    -(-out_cs.n // 64) * -(-Cout // 64) <= _COUNTER_WORDS else None
+                    -(-out_cs.n // 64) * -(-Cout // 64) <= _COUNTER_WORDS else GO_STAMPS
                 call("cnrma_sparse_conv_go_f16x3", ptr(x.F.contiguous()), ptr(x.absmax()), Cin,
                      ptr(tile_union(in_cs, out_cs, kernel_size, in_cs.stride)), ptr(split_weights_f16_frag(weight)), Cout,
                      ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_amax), out_cs.n, ptr(out_cs.n_dev),

@@ -437,6 +437,15 @@ int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int 
                                const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
                                const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* tile_counters,
                                void* stream);
+/* What cnrma_sparse_conv_go_f16x3 launches for an output CAPACITY of no_cap rows (a pure host function of the sizes and the
+ * workspace: captured launch sequences replay the same kernels; the tests prove variant coverage with it): out8 = {form (1 = the
+ * round-5 kernel: metadata requested up front, cached row numbers, scalar offset loop; 0 = the round-4 kernel, kept for the
+ * bit-identity test), tile columns (64: the block's four waves are 2 column tiles x 2 offset halves; 128: 4 column tiles),
+ * splits over the 32-channel slices (> 1: partial slabs in the workspace + conv_reduce_kernel), slices per split, work order of
+ * the one-dimensional grid (0 plain, 1 (column tile, split) groups -> XCDs, 2 row tiles -> XCDs), residual added inside the
+ * kernel (0: by the reduce launch), blocks, weight offsets in flight per wave}.  No reference counterpart (ME picks its kernels
+ * inside MinkowskiConvolution, fcaf3d_backbone.py:26-31). */
+int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size_t workspace_bytes, int has_residual, int* out8);
 int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax, int64_t n_cap,
                                   const int32_t* n_dev, int Cin, int half_stride, const void* weight_split, int Cout,
                                   const float* scale, const float* shift, int act, int32_t* out_coords,

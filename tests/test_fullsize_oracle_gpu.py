@@ -3,10 +3,13 @@
 level 0 pruned to 200 000 rows -- and the north-star stem (C = 256 pair-list convolution, ~474 k output rows) against
 oracle/sparse_torch.py (fp32 on the host cores, pinned to the fp64 oracle by tests/test_sparse_oracle_cpu.py): every level's
 coordinate set bit-exact, features / head outputs / decoded boxes ELEMENT-WISE within 1e-4 (absolute or relative), in the
-default f16x3 arithmetic and in exact fp32.  The test also proves WHICH kernel variants ran (sparse.conv_plan: the launcher's
-choice is a pure function of the capacities): the 128x64 tile (>= 200 k rows), the 128x128 tile (16 k-40 k rows), 64x128,
-64x64, the un-split path and the split-over-offsets path are all covered here -- the small-size oracle tests never reach the
-first two.  Reference: fcaf3d_backbone.py:89-107, fcaf3d_head.py:107-139, :275-349."""
+default f16x3 arithmetic and in exact fp32; the same for the FULL north-star network (500 000 points x 256 channels -> levels
+109 k / 15.7 k / 4.0 k / 970 rows, head 495 k -> 200 k rows).  The tests also prove WHICH kernels ran: every convolution's
+C-ABI entry point is recorded (sparse.call) together with the launcher's own choice for it (sparse.conv_go_plan /
+sparse.conv_plan: pure functions of the capacities) -- gather-once kernel with 4 column tiles (KS = 1), with 2 column tiles x 2
+offset halves (KS = 2) with and without a fused residual, split over channel slices with a workspace, and the stage kernel
+where the gather-once kernel does not apply (stride 2, 1x1, generative transpose), the pair-list stem at C = 256.
+Reference: fcaf3d_backbone.py:89-107, fcaf3d_head.py:107-139, :275-349."""
 import copy
 
 import numpy as np
@@ -50,32 +53,136 @@ def s_scene(device):
     return dict(P=P, F=F, backbone=backbone, head=head, n_vox=len(Cq), levels=levels, results=results, boxes=boxes, scores=scores)
 
 
-def _record_plans(S):
-    """wrap sparse.conv / conv_transpose_generative: the launcher's plan of every convolution that runs"""
-    plans = []
-    orig_conv, orig_tr = S.conv, S.conv_transpose_generative
+CONV_ENTRIES = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_conv_pairs_f16x3",
+                "cnrma_sparse_conv_bf16x6", "cnrma_sparse_convtr_gen_f32", "cnrma_sparse_convtr_gen_f16x3", "cnrma_sparse_convtr_gen_bf16x6")
 
-    def conv(x, weight, kernel_size=3, stride=1, *a, **k):
-        y = orig_conv(x, weight, kernel_size, stride, *a, **k)
+
+def _record_plans(S):
+    """wrap sparse.conv / conv_transpose_generative / sparse.call: per convolution that runs, the C-ABI entry point it went
+    through and what the launcher behind that entry point picks for its sizes"""
+    plans, entries = [], []
+    orig_conv, orig_tr, orig_call = S.conv, S.conv_transpose_generative, S.call
+
+    def call(name, *a):
+        if name in CONV_ENTRIES:
+            entries.append(name)
+        return orig_call(name, *a)
+
+    def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=None, *a, **k):
+        n0 = len(entries)
+        y = orig_conv(x, weight, kernel_size, stride, scale, shift, residual, *a, **k)
         Cin, Cout = x.F.shape[1], y.F.shape[1]
-        if Cin % 32 == 0:
-            pair = (S.PAIR_CONV and stride == 2 and kernel_size == 3 and Cin >= S.PAIR_CONV_MIN_CIN and S.CONV_PRECISION == "f16x3")
-            plans.append(dict(S.conv_plan(y.cs.n, Cin, Cout, kernel_size ** 3), rows=y.cs.n, Cin=Cin, Cout=Cout, pair_list=pair))
+        entry = entries[n0] if len(entries) > n0 else None
+        rec = dict(entry=entry, rows=y.cs.n, Cin=Cin, Cout=Cout, K=kernel_size ** 3, stride=stride, residual=residual is not None)
+        if entry == "cnrma_sparse_conv_go_f16x3":
+            rec.update(go=S.conv_go_plan(y.cs.n, Cin, Cout, residual is not None))
+        elif Cin % 32 == 0 and entry is not None and "pairs" not in entry:
+            rec.update(S.conv_plan(y.cs.n, Cin, Cout, kernel_size ** 3))
+        plans.append(rec)
         return y
 
     def convtr(x, weight, *a, **k):
+        n0 = len(entries)
         y = orig_tr(x, weight, *a, **k)
-        plans.append(dict(S.conv_plan(x.cs.n, x.F.shape[1], y.F.shape[1], 1, slices=8), rows=x.cs.n, Cin=x.F.shape[1], Cout=y.F.shape[1],
-                          pair_list=False))
+        plans.append(dict(S.conv_plan(x.cs.n, x.F.shape[1], y.F.shape[1], 1, slices=8), entry=entries[n0] if len(entries) > n0 else None,
+                          rows=x.cs.n, Cin=x.F.shape[1], Cout=y.F.shape[1], K=8, stride=-2, residual=False))
         return y
     import sys
-    S.conv, S.conv_transpose_generative = conv, convtr
+    S.conv, S.conv_transpose_generative, S.call = conv, convtr, call
     sys.modules["cnrma_amd.nn"].S.conv = conv
 
     def undo():
-        S.conv, S.conv_transpose_generative = orig_conv, orig_tr
+        S.conv, S.conv_transpose_generative, S.call = orig_conv, orig_tr, orig_call
         sys.modules["cnrma_amd.nn"].S.conv = orig_conv
     return plans, undo
+
+
+def _assert_variant_coverage(plans, workload):
+    """which kernels the captured launch sequence holds (static trace: capacities, not live rows, decide)"""
+    go = [p for p in plans if p["entry"] == "cnrma_sparse_conv_go_f16x3"]
+    stage = [p for p in plans if p["entry"] == "cnrma_sparse_conv_f16x3"]
+    # every 3x3x3 stride-1 convolution on >= GO_MIN_ROWS compact rows with Cout >= 64 runs the gather-once kernel, in its round-5 form
+    assert go and all(p["K"] == 27 and p["stride"] == 1 and p["Cout"] >= 64 and p["go"]["form"] == 1 for p in go)
+    assert any(p["go"]["columns"] == 128 and p["go"]["splits"] == 1 for p in go), "KS = 1 (4 column tiles), unsplit"
+    assert any(p["go"]["columns"] == 64 and p["go"]["residual_in_kernel"] for p in go), "KS = 2 with the residual fused"
+    assert any(p["go"]["columns"] == 64 and not p["residual"] and p["go"]["splits"] == 1 for p in go), "KS = 2 without residual"
+    assert any(p["go"]["splits"] > 1 and p["go"]["workspace"] > 0 for p in go), "split over channel slices with a workspace"
+    assert any(p["go"]["splits"] > 1 and p["residual"] and not p["go"]["residual_in_kernel"] for p in go), "residual in the reduce launch"
+    assert any(p["rows"] >= 200000 and p["go"]["workspace"] == 0 and p["go"]["order"] == "plain" for p in go), "200 k-row layers"
+    assert {"tiles->xcd", "groups->xcd"} <= {p["go"]["order"] for p in go}        # mid levels / the 534-970-row level
+    # the stage kernel where the gather-once kernel does not apply
+    assert any(p["K"] == 27 and p["stride"] == 2 for p in stage), "stride 2"
+    assert any(p["K"] == 1 for p in stage), "1x1"
+    assert any(p["splits"] > 1 for p in stage) and any(p["splits"] == 1 for p in stage)
+    assert any(p["entry"] == "cnrma_sparse_convtr_gen_f16x3" for p in plans), "generative transpose"
+    if workload == "NS":
+        assert any(p["entry"] == "cnrma_sparse_conv_pairs_f16x3" and p["Cin"] == 256 for p in plans), "pair-list stem"
+    cover = sorted({(p["entry"].replace("cnrma_sparse_", ""), p.get("go", {}).get("columns", p.get("shape")),
+                     p.get("go", {}).get("splits", p.get("splits")), p.get("go", {}).get("order", "")) for p in plans if p["entry"]})
+    print(f"\n[{workload}] kernels in the trace: {cover}")
+
+
+def _compare_with_oracle(out, info, b, s, d, tag):
+    """coordinate sets of every backbone level bit-exact; features, head outputs, boxes and scores element-wise within TOL"""
+    assert info["M_unique"] == d["n_vox"]
+    worst, frac = {}, {}
+    for li, (o, n, (cs, f)) in enumerate(zip(out["levels"], info["level_rows"], d["levels"])):
+        c = cs.C.numpy()
+        assert n == len(c) and o.cs.stride == cs.stride
+        got_c = o.cs.C[:n].cpu().numpy().astype(np.int64)
+        k1, k2 = np.argsort(SO._key(got_c), kind="stable"), np.argsort(SO._key(c), kind="stable")
+        assert (got_c[k1] == c[k2]).all()
+        worst[f"level{li}"] = _within(o.F[:n].cpu().numpy()[k1], f.numpy()[k2])
+    # ---- head: rows of a pruned level may differ at ties of the pruning score; compare through the coordinate key
+    hd = out["head"]
+    for i in range(4):
+        e, n = d["results"][i], info["head_rows"][i]
+        got_pts = hd["points"][i][:n].cpu().numpy()
+        got_c4 = np.concatenate((np.zeros((n, 1)), np.round(got_pts / 0.01)), axis=1).astype(np.int64)
+        ck = SO._key(got_c4)
+        ek = SO._key(e["coords"].numpy())
+        assert len(ck) == len(ek), (i, len(ck), len(ek))
+        common = np.intersect1d(ck, ek)
+        frac[f"head{i}"] = len(common) / max(1, len(ek))
+        assert len(common) >= 0.999 * len(ek), (i, len(common), len(ek))
+        # A row kept on one side and pruned on the other (a tie of the pruning score at the 200 000-row cut) changes the 3x3x3
+        # neighbourhood of the rows around it: their head outputs differ for that reason, on both sides legitimately.  Such rows
+        # (within one tensor stride of a coordinate of the symmetric difference) are left out of the element-wise comparison --
+        # counted, and bounded by 27 per differing coordinate.
+        diff = np.concatenate((got_c4[~np.isin(ck, common)], e["coords"].numpy()[~np.isin(ek, common)]))
+        if len(diff):
+            st_i = int(d["levels"][i][0].stride)
+            offs = np.array([(0, a, b_, c_) for a in (-1, 0, 1) for b_ in (-1, 0, 1) for c_ in (-1, 0, 1)], dtype=np.int64) * st_i
+            near = SO._key((diff[:, None, :] + offs[None, :, :]).reshape(-1, 4))
+            touched = np.isin(common, near)
+            frac[f"head{i}.rows_beside_a_pruning_tie"] = int(touched.sum())
+            assert touched.sum() <= 27 * len(diff)
+            common = common[~touched]
+        gi = np.argsort(ck)[np.searchsorted(np.sort(ck), common)]
+        ei = np.argsort(ek)[np.searchsorted(np.sort(ek), common)]
+        for key in ("centerness", "bbox_pred", "cls_score"):
+            g_, e_ = hd[key][i][:n].cpu().numpy()[gi].astype(np.float64), e[key].numpy()[ei].astype(np.float64)
+            if key == "bbox_pred":                   # exp(scale * reg): the regression itself is the exponent
+                g_ = np.concatenate((np.log(g_[:, :6]), g_[:, 6:]), axis=1)
+                e_ = np.concatenate((np.log(e_[:, :6]), e_[:, 6:]), axis=1)
+            worst[f"head{i}.{key}"] = _within(g_, e_)
+    # ---- decoded boxes + scores (nms_pre = 1000 per level): rows matched through (level, box centre); membership may differ at
+    # score ties of the top-k cut
+    bx, sx = b.cpu().numpy(), s.cpu().numpy()
+    eb, es = d["boxes"].numpy(), d["scores"].numpy()
+    assert bx.shape == eb.shape and sx.shape == es.shape
+    kg = {tuple(np.round(r[:6] * 1e4).astype(np.int64)): j for j, r in enumerate(bx)}
+    pairs = [(kg[k], j) for j, r in enumerate(eb) for k in [tuple(np.round(r[:6] * 1e4).astype(np.int64))] if k in kg]
+    frac["boxes"] = len(pairs) / max(1, len(eb))
+    assert len(pairs) >= 0.98 * len(eb), (len(pairs), len(eb))
+    gi, ei = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+    worst["boxes"] = _within(bx[gi], eb[ei])
+    worst["scores"] = _within(sx[gi], es[ei])
+    print(f"\n[{tag}] rows per level {list(info['level_rows'])}, head rows {list(info['head_rows'])}; matched-row fractions "
+          f"(head rows by coordinate, boxes by centre): {({k: round(v, 5) for k, v in frac.items()})}")
+    print(f"[{tag}] worst element-wise min(abs, rel) error vs oracle/sparse_torch.py:", {k: f"{v:.2e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v > TOL}
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
@@ -98,57 +205,65 @@ def test_graph_replay_of_the_full_scannet_scene_vs_oracle(device, s_scene, preci
         b, s, info = pipeline.StaticScene.detections(out)
     finally:
         S.CONV_PRECISION = prev
-    # ---- which kernel variants this covered (static trace = the graph's launches; capacities, not live rows, decide)
     if precision == "f16x3":
-        shapes = {(p["shape"], p["splits"] > 1) for p in plans}
-        big = [p for p in plans if p["rows"] >= 200000 and p["Cin"] > 32 and p["Cout"] == 64]
-        mid = [p for p in plans if 16384 <= p["rows"] < 40000 and p["Cout"] >= 128 and p["Cin"] >= 64 and p["tile"] != (128, 32)]
-        assert big and all(p["shape"] == "128x64" and p["splits"] == 1 for p in big), big           # T128x64, no split
-        assert mid and any(p["shape"] == "128x128" for p in mid), mid                                # T128x128
-        assert {("64x128", True), ("64x128", False), ("64x64", False)} <= shapes, shapes
-        assert any(p["splits"] >= 9 for p in plans)                                                  # deep split of the short layers
-    # ---- coordinate sets of every backbone level: bit-exact; features element-wise
-    assert info["M_unique"] == d["n_vox"]
-    worst = {}
-    for li, (o, n, (cs, f)) in enumerate(zip(out["levels"], info["level_rows"], d["levels"])):
-        c = cs.C.numpy()
-        assert n == len(c) and o.cs.stride == cs.stride
-        got_c = o.cs.C[:n].cpu().numpy().astype(np.int64)
-        k1, k2 = np.argsort(SO._key(got_c), kind="stable"), np.argsort(SO._key(c), kind="stable")
-        assert (got_c[k1] == c[k2]).all()
-        worst[f"level{li}"] = _within(o.F[:n].cpu().numpy()[k1], f.numpy()[k2])
-    # ---- head: rows of a pruned level may differ at ties of the pruning score; compare through the coordinate key
-    hd = out["head"]
-    for i in range(4):
-        e, n = d["results"][i], info["head_rows"][i]
-        got_pts = hd["points"][i][:n].cpu().numpy()
-        ck = SO._key(np.concatenate((np.zeros((n, 1)), np.round(got_pts / 0.01)), axis=1).astype(np.int64))
-        ek = SO._key(e["coords"].numpy())
-        assert len(ck) == len(ek), (i, len(ck), len(ek))
-        common = np.intersect1d(ck, ek)
-        assert len(common) >= 0.999 * len(ek), (i, len(common), len(ek))
-        gi = np.argsort(ck)[np.searchsorted(np.sort(ck), common)]
-        ei = np.argsort(ek)[np.searchsorted(np.sort(ek), common)]
-        for key in ("centerness", "bbox_pred", "cls_score"):
-            g_, e_ = hd[key][i][:n].cpu().numpy()[gi].astype(np.float64), e[key].numpy()[ei].astype(np.float64)
-            if key == "bbox_pred":                   # exp(scale * reg): the regression itself is the exponent
-                g_ = np.concatenate((np.log(g_[:, :6]), g_[:, 6:]), axis=1)
-                e_ = np.concatenate((np.log(e_[:, :6]), e_[:, 6:]), axis=1)
-            worst[f"head{i}.{key}"] = _within(g_, e_)
-    # ---- decoded boxes + scores (nms_pre = 1000 per level): rows matched through (level, box centre); membership may differ at
-    # score ties of the top-k cut
-    bx, sx = b.cpu().numpy(), s.cpu().numpy()
-    eb, es = d["boxes"].numpy(), d["scores"].numpy()
-    assert bx.shape == eb.shape and sx.shape == es.shape
-    kg = {tuple(np.round(r[:6] * 1e4).astype(np.int64)): j for j, r in enumerate(bx)}
-    pairs = [(kg[k], j) for j, r in enumerate(eb) for k in [tuple(np.round(r[:6] * 1e4).astype(np.int64))] if k in kg]
-    assert len(pairs) >= 0.98 * len(eb), (len(pairs), len(eb))
-    gi, ei = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
-    worst["boxes"] = _within(bx[gi], eb[ei])
-    worst["scores"] = _within(sx[gi], es[ei])
-    print(f"\n[{precision}] worst element-wise min(abs, rel) error vs oracle/sparse_torch.py:", {k: f"{v:.2e}" for k, v in worst.items()})
-    bad = {k: v for k, v in worst.items() if v > TOL}
-    assert not bad, bad
+        _assert_variant_coverage(plans, "S")
+    _compare_with_oracle(out, info, b, s, d, f"S {precision}")
+
+
+@pytest.fixture(scope="module")
+def ns_scene(device):
+    """the north-star network's input: the 500 000 points of an NS-geometry scene (40 views of 480 x 640 rays into a 192^3 grid;
+    the coordinates do not depend on the channel count, so the aggregation runs on 32-channel maps) with 256-channel random
+    features, + the oracle's levels / head outputs / boxes for the benchmark's 256-channel model"""
+    import bench
+    from cnrma_amd import rma, synth
+    V, C, H, W, dims, stride = synth.SHAPES["NS"]
+    sc = synth.make_scene((V, 32, H, W, dims, stride), seed=2, boxes=4, device=device)
+    nhwc = rma.to_nhwc(sc["features"][:, 0].to(device))
+    pinv = rma.projection_inverse(sc["projection"][:, 0], sc["stride"]).to(device)
+    P, _, info = rma.aggregate_points(nhwc, pinv, sc["tsdf"][0, 0].to(device), sc["dims"], 0.04, sc["origin"],
+                                      max_points=500000, sampler="device", seed=7)
+    del nhwc, sc
+    torch.cuda.empty_cache()
+    assert P.shape[0] == 500000 and info["M"] > 50_000_000
+    F = torch.randn(P.shape[0], 256, generator=torch.Generator().manual_seed(11)).to(device)
+    backbone, head = bench.build_model(256, device)
+    b_cpu, h_cpu = copy.deepcopy(backbone).cpu(), copy.deepcopy(head).cpu()
+    torch.set_num_threads(min(64, torch.get_num_threads() or 64))
+    Cq, Fq, _ = RO.voxelize(P.cpu(), F.cpu(), 0.01)
+    levels = ST.backbone_forward(b_cpu, Cq.numpy(), Fq.numpy())
+    results = ST.head_forward(h_cpu, levels)
+    boxes, scores = ST.get_bboxes(h_cpu, results)
+    return dict(P=P, F=F, backbone=backbone, head=head, n_vox=len(Cq), levels=levels, results=results, boxes=boxes, scores=scores)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_graph_replay_of_the_full_north_star_network_vs_oracle(device, ns_scene, precision):
+    """the north-star network was only compared with the oracle up to its stem.  Here the whole of it -- pair-list
+    stem on 256 channels, levels of ~109 k / 15.7 k / 4.0 k / 970 rows, head levels ~495 k -> 200 k / 62 k / 7.7 k / 970 -- as a
+    graph replay against oracle/sparse_torch.py, element-wise 1e-4"""
+    from cnrma_amd import pipeline
+    from cnrma_amd import sparse as S
+    d = ns_scene
+    prev = S.CONV_PRECISION
+    S.CONV_PRECISION = precision
+    plans, undo = _record_plans(S)
+    try:
+        net = pipeline.StaticNet(d["backbone"], d["head"], 0.01, device)
+        net.build(d["P"], d["F"])
+        assert net.graph is not None
+    finally:
+        undo()
+    try:
+        net.run(d["P"].flip(0).contiguous(), d["F"] * 0.5)                 # other inputs through the graph first
+        out = net.run(d["P"], d["F"])
+        b, s, info = pipeline.StaticScene.detections(out)
+    finally:
+        S.CONV_PRECISION = prev
+    assert info["level_rows"][0] > 90000 and info["head_rows"][0] == 200000
+    if precision == "f16x3":
+        _assert_variant_coverage(plans, "NS")
+    _compare_with_oracle(out, info, b, s, d, f"NS {precision}")
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
@@ -182,7 +297,7 @@ def test_north_star_stem_vs_oracle(device, s_scene, precision):
         S.CONV_PRECISION = prev
     assert y.cs.n == len(oc) > 400000
     if precision == "f16x3":
-        assert plans[0]["pair_list"] and plans[0]["Cin"] == 256
+        assert plans[0]["entry"] == "cnrma_sparse_conv_pairs_f16x3" and plans[0]["Cin"] == 256
     for got, (ecs, ef), name in ((y, (oc, of), "stem conv"), (z, (pc, pf), "stem conv + norm + pool")):
         c = got.cs.C.cpu().numpy().astype(np.int64)
         k1, k2 = np.argsort(SO._key(c), kind="stable"), np.argsort(SO._key(ecs.C.numpy()), kind="stable")

@@ -227,6 +227,41 @@ def test_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n
         assert hdr[:, 0].max() > 1                                              # no locality: several groups per tile
 
 
+@pytest.mark.parametrize("cin,cout,n,span", [(64, 64, 6000, 14), (128, 128, 9000, 20), (256, 512, 1500, 9), (64, 128, 20000, 14),
+                                             (64, 64, 64 * 37 + 5, 12)])
+def test_gather_once_second_form_is_bit_identical_to_the_first(device, cin, cout, n, span):
+    """sparse.conv_tuning(go=1): the second form of the gather-once kernel (metadata requested up front, row numbers of group
+    0 cached in LDS, scalar offset loop with SGPR-based weight loads, local indices one offset ahead, one-dimensional grid
+    decoded per XCD, 2 or 4 weight offsets in flight) keeps the first form's summation order: bit-identical outputs and
+    magnitude bound in every work order, with residual + ReLU, split over channel slices, on a point set without locality
+    (several offset groups per tile) and with a ragged last tile"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + n)
+    c, f = rand_sparse(rng, n=n, span=span, C=cin, ts=1)
+    W = torch.from_numpy((rng.randn(27, cin, cout) / np.sqrt(cin * 27)).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.randn(len(c), cout).astype(np.float32)).to(device)
+    x = to_st(c, f, 1, device)
+    prev = S.GO_CONV
+    try:
+        S.GO_CONV = True
+        for splits in (-1, 1, 2):
+            S.conv_tuning(splits=splits, go=0)
+            ref = S.conv(x, W, 3, 1, residual=res, act="relu")
+            ref_f, ref_amax = ref.F.clone(), float(ref.amax.max())
+            plain = S.conv(x, W, 3, 1).F.clone()
+            for go in (1,):
+                for nb in (2, 4):
+                    for xcd in (0, 1, 2):
+                        S.conv_tuning(splits=splits, go=go, nb=nb, xcd=xcd)
+                        got = S.conv(x, W, 3, 1, residual=res, act="relu")
+                        assert torch.equal(got.F, ref_f), (splits, go, nb, xcd)
+                        assert float(got.amax.max()) == ref_amax
+                        assert torch.equal(S.conv(x, W, 3, 1).F, plain), (splits, go, nb, xcd, "plain")
+    finally:
+        S.conv_tuning()
+        S.GO_CONV = prev
+
+
 def test_presplit_companions_give_identical_results(device):
     """bf16x6 with pre-split feature companions (read + written by the conv epilogue) == bf16x6 splitting in the loop"""
     from cnrma_amd import sparse as S
