@@ -2716,6 +2716,279 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
   }
 }
 
+// ================================================================================================================
+// Gather-once convolution in exact fp32 (round 5): the structure of sparse_conv_go2_kernel on v_mfma_f32_32x32x2_f32, for
+// CONV_PRECISION = "f32" -- the reference's own arithmetic (fcaf3d_backbone.py:26-31 runs ME's fp32 GEMMs), whose 3x3x3 stride-1
+// layers had stayed on the round-1 stage kernel (a barrier pair per (offset, 32-channel slice), 0.36 of the fp32 MFMA peak).
+//   * image: the tile's union rows as raw fp32, 128 bytes per row (32 channels), eight 16-byte chunks XORed with bits 1..3
+//     of the row: a lane reads its operands as ds_read_b128 (4 floats = 4 MFMAs' worth), 16 rows of a lane group on 16 distinct
+//     bank positions; no split, no scale;
+//   * one MFMA multiplies 32 rows x 2 channels; lanes 0-31 hold one channel of the pair, lanes 32-63 the other.  A lane's four
+//     floats are channels 8 i + 4 h + e (i = read 0..3, h = lane / 32, e = 0..3): MFMA (i, e) pairs channel 8 i + e with channel
+//     8 i + 4 + e.  The weight image is in the matching fragment order [k][slice][column tile][i][lane][e] -- one 16-byte load
+//     per lane and read, straight from memory into the B operand registers, prefetched two offsets ahead like the f16x3 form;
+//   * sums run over (slice, group, offset, i, e): an fp32 fma chain per output in that fixed order -- the stage kernel's order is
+//     (offset, slice, channel pair), so the two differ in rounding order only (test: 2e-6 vs the fp64 oracle, like the stage kernel).
+// ================================================================================================================
+constexpr int GOF_ROW = 32;                                 // floats per image row
+constexpr int GOF_IMG = (GO_UMAX + 2) * GOF_ROW;            // floats: union rows + zero row + dump row
+constexpr int GOF_LDS = GOF_IMG * 4 + GO_BM * 27 * 2 + GO_UMAX * 4;
+static_assert(GOF_LDS <= 48 * 1024 && 4 * GOF_LDS <= 160 * 1024, "four blocks per CU");
+__device__ __forceinline__ int gof_slot(int row, int chunk) { return row * GOF_ROW + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+// W fp32 [K][Cin][Cout] -> fragment-order image, element order [k][slice][column tile of 32][i (4)][lane (64)][e (4)]:
+// channel slice * 32 + 8 i + 4 (lane / 32) + e, column tile * 32 + lane % 32; columns padded to Cout_p with zeros
+__global__ __launch_bounds__(256) void prep_weights_f32_frag_kernel(const float* __restrict__ w, float* __restrict__ wt, int K,
+                                                                    int Cin, int Cout) {
+  const int Cp = conv_cout_padded(Cout);
+  const int64_t total = (int64_t)K * Cin * Cp;
+  const int ns = Cin / BK, nt = Cp / 32;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(t & 3), lane = (int)((t >> 2) & 63), i = (int)((t >> 8) & 3);
+    int64_t q = t >> 10;
+    const int tile = (int)(q % nt); q /= nt;
+    const int slice = (int)(q % ns);
+    const int k = (int)(q / ns);
+    const int cin = slice * BK + 8 * i + 4 * (lane >> 5) + e, co = tile * 32 + (lane & 31);
+    wt[t] = co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] : 0.0f;
+  }
+}
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int WAVES_N, int KS, bool HAS_RES>
+__global__ __launch_bounds__(256, 4) void sparse_conv_gof_kernel(ConvArgs p, GoArgs g, const float* __restrict__ wfrag, Go2Map mp) {
+  static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
+  constexpr int TM = 2, BN = 32 * WAVES_N, NB = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gof_smem[];
+  float* const Us = reinterpret_cast<float*>(gof_smem);                                      // [(GO_UMAX + 2)][32] swizzled
+  uint16_t* const Ls = reinterpret_cast<uint16_t*>(gof_smem + GOF_IMG * 4);                   // [GO_BM * 27]
+  int32_t* const Rs = reinterpret_cast<int32_t*>(gof_smem + GOF_IMG * 4 + GO_BM * 27 * 2);     // [GO_UMAX] row numbers of group 0
+  const int L = blockIdx.x;
+  int tile_i, grp;
+  if (mp.mode == 1) { grp = (L & 7) + 8 * ((L >> 3) / mp.tiles); tile_i = (L >> 3) % mp.tiles; }
+  else if (mp.mode == 2) { tile_i = (L & 7) * mp.per + (L >> 3) / mp.ng; grp = (L >> 3) % mp.ng; if ((L >> 3) / mp.ng >= mp.per) return; }
+  else { tile_i = L / mp.ng; grp = L % mp.ng; }
+  if (tile_i >= mp.tiles || grp >= mp.ng) return;
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int64_t tile = tile_i, tile0 = tile * GO_BM;
+  if (tile0 >= n_live) return;
+  const int cout0 = (grp % mp.ncol) * BN, zs = grp / mp.ncol;
+  const int Cin = p.Cin, Cout = p.Cout;
+  const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wid / WAVES_N, wc = wid % WAVES_N;
+  const int32_t* th = g.hdr + tile * GO_HDR;
+  const int32_t* tr = g.rows + tile * GO_ROWS;
+  // requests first, waits later (see sparse_conv_go2_kernel)
+  const int4 h0 = *reinterpret_cast<const int4*>(th);
+  uint4 lv = make_uint4(0u, 0u, 0u, 0u);
+  if (tid < GO_BM * 27 / 8) lv = reinterpret_cast<const uint4*>(g.lidx + tile * (GO_BM * 27))[tid];
+  int32_t pre[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pre[i] = tr[(tid >> 3) + 32 * i];
+  const int col = cout0 + wc * 32 + (lane & 31);
+  const bool col_ok = col < Cout;
+  const int colc = col_ok ? col : 0;
+  const bool use_scale = p.scale != nullptr && p.splits == 1, use_shift = p.shift != nullptr && p.splits == 1;
+  const float sc = use_scale ? p.scale[colc] : 1.0f;
+  const float sh = use_shift ? p.shift[colc] : 0.0f;
+  if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls)[tid] = lv;
+  if (tid < 32) Us[GO_UMAX * GOF_ROW + tid] = 0.0f;          // the zero row
+  const int n_groups = __builtin_amdgcn_readfirstlane(h0.x);
+  int s_lo = 0, s_hi = ns;
+  if (p.splits > 1) { s_lo = zs * g.slices_per_split; s_hi = min(ns, s_lo + g.slices_per_split); }
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+
+  const int fhalf = lane >> 5;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const uint16_t* ls0 = Ls + (lane & 31) * 27;
+  auto load_b = [&](u32x4_t (&bf)[2][2], int k, int slice) {
+    const uint64_t ba = reinterpret_cast<uint64_t>(wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc) * 1024);
+    const uint16_t* base = reinterpret_cast<const uint16_t*>(
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ba));
+    go_load_frag(bf, base, lane16);                            // reads i = 0..3, 1024 bytes apart: bf[i >> 1][i & 1]
+  };
+  auto load_li = [&](int (&li)[TM], int k) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) li[a] = ls0[a * (32 * 27) + k];
+  };
+  // one offset: 4 reads x 2 row tiles, each read one ahead of its 4 MFMAs (two registers in rotation)
+  auto mfma_k = [&](const u32x4_t (&bf)[2][2], const int (&li)[TM]) {
+    auto rd = [&](int a, int i) -> f32x4_t {
+      return *reinterpret_cast<const f32x4_t*>(Us + gof_slot(li[a], 2 * i + fhalf));
+    };
+    f32x4_t cur = rd(0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4_t b4 = __builtin_bit_cast(f32x4_t, bf[i >> 1][i & 1]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const bool last = i == 3 && a == TM - 1;
+        f32x4_t nxt = cur;
+        if (!last) nxt = a + 1 < TM ? rd(a + 1, i) : rd(0, i + 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[e], b4[e], acc[a], 0, 0, 0);
+        cur = nxt;
+      }
+    }
+  };
+
+  for (int slice = s_lo; slice < s_hi; ++slice) {
+    const int cin0 = slice * BK;
+    for (int grpi = 0; grpi < n_groups; ++grpi) {
+      const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(grpi == 0 ? h0.y : th[1 + 3 * grpi]);
+      const int ub = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.z : th[2 + 3 * grpi]);
+      const int un = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.w : th[3 + 3 * grpi]);
+      unsigned mymask = mask;
+      if constexpr (KS == 2) {                               // every second offset of the group
+        mymask = 0;
+        unsigned m = mask;
+        int r = 0;
+        while (m) {
+          const unsigned low = m & (0u - m);
+          if ((r & 1) == kg) mymask |= low;
+          m ^= low;
+          ++r;
+        }
+      }
+      u32x4_t bf[NB][2][2];
+      int kk[NB];
+      unsigned rest = mymask;
+      const int n_off = __popc(mymask);
+      int k_last = 0;
+      auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { kk[j] = pop(); load_b(bf[j], kk[j], slice); }
+      __syncthreads();                                       // the previous stage's fragment reads are done
+      const bool cached = grpi == 0 && slice != s_lo, keep = grpi == 0 && slice == s_lo && s_hi - s_lo > 1;
+      const int tasks = un * 8;
+      for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
+        float4 v[4];
+        int32_t src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tk = t0 + i * 256 + tid;
+          const int r = tk < tasks ? (tk >> 3) : 0;
+          if (cached) src[i] = Rs[r];
+          else if (grpi == 0 && t0 == 0) src[i] = tk < tasks ? pre[i] : tr[0];
+          else src[i] = tr[ub + r];
+          if (keep && (tk & 7) == 0 && tk < tasks) Rs[r] = src[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tk = t0 + i * 256 + tid;
+          v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (tk & 7) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int tk = t0 + i * 256 + tid;
+          const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tk & 7;
+          *reinterpret_cast<float4*>(Us + gof_slot(u, kc)) = v[i];
+        }
+      }
+      __syncthreads();
+      int lin[TM];
+      load_li(lin, kk[0]);
+      int i = 0;
+      for (; i + NB < n_off; i += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          int li[TM];
+#pragma unroll
+          for (int a = 0; a < TM; ++a) li[a] = lin[a];
+          load_li(lin, kk[(j + 1) % NB]);
+          go_waitn<(NB - 1) * 4>(bf[j]);
+          mfma_k(bf[j], li);
+          kk[j] = pop();
+          load_b(bf[j], kk[j], slice);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) go_drain(bf[j]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int li[TM];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) li[a] = lin[a];
+        if (j + 1 < NB) load_li(lin, kk[j + 1]);
+        if (i + j < n_off) mfma_k(bf[j], li);
+      }
+    }
+  }
+
+  if constexpr (KS == 2) {
+    __syncthreads();
+    float* X = reinterpret_cast<float*>(gof_smem);           // 4 x 4 KB
+    float* mine = X + (wc * 2 + kg) * 1024;
+    const float* theirs = X + (wc * 2 + (kg ^ 1)) * 1024;
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[1][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[0][i];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] += theirs[i * 64 + lane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[1][i] += theirs[i * 64 + lane];
+    }
+  }
+
+  if (p.splits > 1) {                                        // partial tile into this split's slab; conv_reduce_kernel follows
+    float* slab = p.slab + (int64_t)zs * p.no_cap * Cout;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      if (KS == 2 && a != kg) continue;
+      const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
+        if (col_ok && row < n_live) slab[row * Cout + col] = acc[a][i];
+      }
+    }
+    return;
+  }
+  const int act = p.act;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    if (KS == 2 && a != kg) continue;
+    const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float res[4];
+      if (HAS_RES) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t row = row0 + q + 8 * rg;
+          const int64_t rc = row < n_live ? row : n_live - 1;
+          res[q] = p.residual[rc * Cout + colc];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t row = row0 + q + 8 * rg;
+        float v = acc[a][rg * 4 + q];
+        v = v * sc;
+        v = v + sh;
+        if (HAS_RES) v = v + res[q];
+        v = apply_act(v, act);
+        if (col_ok && row < n_live) p.out[row * Cout + col] = v;
+      }
+    }
+  }
+}
+
 // children coordinates of the generative transposed conv: child k (x fastest) of parent i is row 8 * i + morton_child(k)
 __global__ __launch_bounds__(256) void convtr_coords_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
                                                             const int32_t* __restrict__ n_dev, int half,
@@ -3897,8 +4170,64 @@ extern "C" int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size
   return 0;
 }
 
-// ---- gather-once convolution: tile unions, fragment-order weights, launcher -----------------------------------------------
 static size_t go_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// ---- exact-fp32 gather-once convolution: weight image, launcher -------------------------------------------------------------
+extern "C" size_t cnrma_sparse_conv_f32_frag_weight_bytes(int K, int Cin, int Cout) {
+  return (size_t)K * Cin * conv_cout_padded(Cout) * sizeof(float);
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_f32_frag(const float* weight, int K, int Cin, int Cout, void* weight_frag,
+                                                          void* stream) {
+  if (weight == nullptr || weight_frag == nullptr || K <= 0 || Cin <= 0 || Cin % BK != 0 || Cout <= 0) return CNRMA_EINVAL;
+  const int64_t total = (int64_t)K * Cin * conv_cout_padded(Cout);
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_f32_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
+                     reinterpret_cast<float*>(weight_frag), K, Cin, Cout);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_go_f32(const float* in_feats, int Cin, const void* tile_union, const void* weight_frag, int Cout,
+                                        const float* scale, const float* shift, const float* residual, int act, float* out_feats,
+                                        int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream) {
+  if (in_feats == nullptr || tile_union == nullptr || weight_frag == nullptr || out_feats == nullptr || Cin <= 0 || Cin % BK != 0 ||
+      Cout < 64 || no_cap <= 0)
+    return CNRMA_EINVAL;
+  const int K = 27;
+  hipStream_t st = as_stream(stream);
+  const size_t tiles = (size_t)ceil_div(no_cap, GO_BM);
+  const char* w = reinterpret_cast<const char*>(tile_union);
+  GoArgs g;
+  g.hdr = reinterpret_cast<const int32_t*>(w);      w += go_align(tiles * GO_HDR * 4);
+  g.rows = reinterpret_cast<const int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
+  g.lidx = reinterpret_cast<const uint16_t*>(w);
+  g.counters = nullptr;
+  ConvArgs p{in_feats, Cin, nullptr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1, 1, K,
+             reinterpret_cast<float*>(workspace), nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace != nullptr, workspace_bytes);
+  g.slices_per_split = pl.slices_per_split;
+  p.splits = pl.splits;
+  const bool has_res = residual != nullptr && pl.splits == 1;
+  const float* wf = reinterpret_cast<const float*>(weight_frag);
+  if (pl.bn == 128) {
+    if (has_res) hipLaunchKernelGGL((sparse_conv_gof_kernel<4, 1, true>), dim3(pl.blocks), dim3(256), GOF_LDS, st, p, g, wf, pl.mp);
+    else hipLaunchKernelGGL((sparse_conv_gof_kernel<4, 1, false>), dim3(pl.blocks), dim3(256), GOF_LDS, st, p, g, wf, pl.mp);
+  } else {
+    if (has_res) hipLaunchKernelGGL((sparse_conv_gof_kernel<2, 2, true>), dim3(pl.blocks), dim3(256), GOF_LDS, st, p, g, wf, pl.mp);
+    else hipLaunchKernelGGL((sparse_conv_gof_kernel<2, 2, false>), dim3(pl.blocks), dim3(256), GOF_LDS, st, p, g, wf, pl.mp);
+  }
+  if (pl.splits > 1) {
+    int64_t rb = ceil_div(no_cap * Cout / 4 + 1, 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- gather-once convolution: tile unions, fragment-order weights, launcher -----------------------------------------------
 
 extern "C" size_t cnrma_sparse_tile_union_bytes(int64_t no_cap) {
   if (no_cap <= 0) return 0;

@@ -594,6 +594,21 @@ def split_weights_f16_frag(weight):
     return _pinned(ws)
 
 
+def weights_f32_frag(weight):
+    """weight fp32 [27,Cin,Cout] -> the fp32 image in MFMA-fragment order (exact-fp32 gather-once convolution), cached like
+    split_weights_f16()"""
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    hit = _cache_get(weight, "_cnrma_frag_f32")
+    if hit is not None and hit[0] == tag:
+        return _pinned(hit[1])
+    w = weight.detach().contiguous().float()
+    K, Cin, Cout = w.shape
+    ws = torch.empty(_lib.load().cnrma_sparse_conv_f32_frag_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+    call("cnrma_sparse_conv_prepare_weights_f32_frag", ptr(w), K, Cin, Cout, ptr(ws), stream())
+    _cache_put(weight, "_cnrma_frag_f32", (tag, ws))
+    return _pinned(ws)
+
+
 def weights_bf16(weight):
     """weight fp32 [K,Cin,Cout] (or [Cin,Cout]) -> bf16 [K,Cout_p,Cin] (round to nearest) for the "bf16" convolutions;
     cached on the weight tensor like the other prepared images"""
@@ -690,6 +705,7 @@ GO_CONV = "auto"     # gather-once kernel for the 3x3x3 stride-1 convolutions in
                      # whose rows are compact (CoordSet.compact) with >= GO_MIN_ROWS rows; True / False force it (tests, A/B runs)
 GO_UMAX = 280        # csrc/sparse.hip GO_UMAX: rows of a tile's union image in LDS (the local index of "no neighbour")
 GO_WS_ROWS = 65536   # below: a workspace for the split over channel slices is handed to the kernel (it decides)
+GO_F32 = True        # CONV_PRECISION = "f32": the exact-fp32 gather-once kernel where the f16x3 one would run (False: the stage kernel)
 GO_STAMPS = None     # diagnostic build of the second form (conv_tuning(ablate=64)): an int64 tensor of 16 words per block
 GO_MIN_ROWS = 256    # below: the stage kernel split over the 27 offsets.  (Round 4: 1024 -- the first form ran the 541-row level at
                      # 0.95x of the stage kernel; the second form with its (column tile, slice) groups pinned to XCDs runs it at 35 us
@@ -793,6 +809,13 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             call("cnrma_sparse_conv_bf16x6", ptr(x.F.contiguous()), ptr(in_split), x.cs.n, Cin, ptr(nbr), K, ptr(split_weights(weight)),
                  Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_split), out_cs.n, ptr(out_cs.n_dev), ptr(ws),
                  ws_bytes, stream())
+        elif prec == "f32" and GO_F32 and K == 27 and stride == 1 and Cout >= 64 and Cin % 32 == 0 and _gather_once(in_cs, out_cs):
+            # exact fp32 on the gather-once structure (v_mfma_f32_32x32x2_f32 over the tile unions)
+            go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < GO_WS_ROWS else 0
+            go_ws = _workspace(go_ws_bytes, x.device) if go_ws_bytes else None
+            call("cnrma_sparse_conv_go_f32", ptr(x.F.contiguous()), Cin, ptr(tile_union(in_cs, out_cs, kernel_size, in_cs.stride)),
+                 ptr(weights_f32_frag(weight)), Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), out_cs.n,
+                 ptr(out_cs.n_dev), ptr(go_ws), go_ws_bytes, stream())
         else:
             call("cnrma_sparse_conv_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
                  ptr(res), ACT[act], ptr(out), out_cs.n, ptr(out_cs.n_dev), ptr(ws), ws_bytes, stream())

@@ -446,6 +446,18 @@ int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int 
  * kernel (0: by the reduce launch), blocks, weight offsets in flight per wave}.  No reference counterpart (ME picks its kernels
  * inside MinkowskiConvolution, fcaf3d_backbone.py:26-31). */
 int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size_t workspace_bytes, int has_residual, int* out8);
+/* Exact-fp32 gather-once convolution (`v_mfma_f32_32x32x2_f32`): the reference's own arithmetic for the 3x3x3 stride-1
+ * MinkowskiConvolutions (fcaf3d_backbone.py:26-31, :59-87; fcaf3d_head.py:61-83) on the tile unions of
+ * cnrma_sparse_tile_union_build -- same operands / epilogue as cnrma_sparse_conv_f32, an fp32 fma chain per output in the order
+ * (32-channel slice, offset group, offset, channel pair).  Weights in MFMA-fragment order, prepared once per layer
+ * (cnrma_sparse_conv_prepare_weights_f32_frag into cnrma_sparse_conv_f32_frag_weight_bytes bytes: [K][Cin/32][Cout_p/32][4][64][4]
+ * floats).  Cin % 32 == 0, Cout >= 64.  workspace: slabs of the split over channel slices (short layers), as
+ * cnrma_sparse_conv_go_f16x3; cnrma_sparse_conv_go_plan describes the launch (the form / in-flight fields do not apply). */
+size_t cnrma_sparse_conv_f32_frag_weight_bytes(int K, int Cin, int Cout);
+int cnrma_sparse_conv_prepare_weights_f32_frag(const float* weight, int K, int Cin, int Cout, void* weight_frag, void* stream);
+int cnrma_sparse_conv_go_f32(const float* in_feats, int Cin, const void* tile_union, const void* weight_frag, int Cout,
+                             const float* scale, const float* shift, const float* residual, int act, float* out_feats,
+                             int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
 int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feats, const float* in_amax, int64_t n_cap,
                                   const int32_t* n_dev, int Cin, int half_stride, const void* weight_split, int Cout,
                                   const float* scale, const float* shift, int act, int32_t* out_coords,

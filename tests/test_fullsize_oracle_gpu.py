@@ -53,7 +53,7 @@ def s_scene(device):
     return dict(P=P, F=F, backbone=backbone, head=head, n_vox=len(Cq), levels=levels, results=results, boxes=boxes, scores=scores)
 
 
-CONV_ENTRIES = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_conv_pairs_f16x3",
+CONV_ENTRIES = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_go_f32", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_conv_pairs_f16x3",
                 "cnrma_sparse_conv_bf16x6", "cnrma_sparse_convtr_gen_f32", "cnrma_sparse_convtr_gen_f16x3", "cnrma_sparse_convtr_gen_bf16x6")
 
 
@@ -74,7 +74,7 @@ def _record_plans(S):
         Cin, Cout = x.F.shape[1], y.F.shape[1]
         entry = entries[n0] if len(entries) > n0 else None
         rec = dict(entry=entry, rows=y.cs.n, Cin=Cin, Cout=Cout, K=kernel_size ** 3, stride=stride, residual=residual is not None)
-        if entry == "cnrma_sparse_conv_go_f16x3":
+        if entry in ("cnrma_sparse_conv_go_f16x3", "cnrma_sparse_conv_go_f32"):
             rec.update(go=S.conv_go_plan(y.cs.n, Cin, Cout, residual is not None))
         elif Cin % 32 == 0 and entry is not None and "pairs" not in entry:
             rec.update(S.conv_plan(y.cs.n, Cin, Cout, kernel_size ** 3))
@@ -207,6 +207,8 @@ def test_graph_replay_of_the_full_scannet_scene_vs_oracle(device, s_scene, preci
         S.CONV_PRECISION = prev
     if precision == "f16x3":
         _assert_variant_coverage(plans, "S")
+    else:               # exact fp32: every 3x3x3 stride-1 layer of the trace on the fp32 gather-once kernel, none on the f16x3 one
+        assert sum(p["entry"] == "cnrma_sparse_conv_go_f32" for p in plans) >= 29 and not any("f16x3" in (p["entry"] or "") for p in plans)
     _compare_with_oracle(out, info, b, s, d, f"S {precision}")
 
 
@@ -263,6 +265,8 @@ def test_graph_replay_of_the_full_north_star_network_vs_oracle(device, ns_scene,
     assert info["level_rows"][0] > 90000 and info["head_rows"][0] == 200000
     if precision == "f16x3":
         _assert_variant_coverage(plans, "NS")
+    else:
+        assert sum(p["entry"] == "cnrma_sparse_conv_go_f32" for p in plans) >= 29 and not any("f16x3" in (p["entry"] or "") for p in plans)
     _compare_with_oracle(out, info, b, s, d, f"NS {precision}")
 
 

@@ -262,6 +262,47 @@ def test_gather_once_second_form_is_bit_identical_to_the_first(device, cin, cout
         S.GO_CONV = prev
 
 
+@pytest.mark.parametrize("cin,cout,n,span", [(64, 64, 6000, 14), (128, 128, 9000, 20), (256, 512, 1500, 9), (64, 128, 20000, 14),
+                                             (64, 64, 64 * 37 + 5, 12)])
+def test_exact_fp32_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n, span):
+    """CONV_PRECISION = "f32" on the gather-once structure (cnrma_sparse_conv_go_f32: raw fp32 union rows in LDS,
+    v_mfma_f32_32x32x2_f32, fragment-order fp32 weights) against the fp64 oracle (2e-6, the stage kernel's bound) and against the
+    fp32 stage kernel (same products, another summation order), with residual + ReLU, forced splits over channel slices, on a
+    point set without locality (several offset groups per tile) and with a ragged last tile; run to run bit-identical"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + n + 1)
+    c, f = rand_sparse(rng, n=n, span=span, C=cin, ts=1)
+    W = torch.from_numpy((rng.randn(27, cin, cout) / np.sqrt(cin * 27)).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.randn(len(c), cout).astype(np.float32)).to(device)
+    x = to_st(c, f, 1, device)
+    seen = []
+    orig_call = S.call
+
+    def call(name, *a):
+        seen.append(name)
+        return orig_call(name, *a)
+    prev = S.GO_CONV, S.GO_F32
+    try:
+        S.GO_CONV, S.GO_F32, S.call = True, False, call
+        ref = S.conv(x, W, 3, 1, residual=res, act="relu", precision="f32").F.clone()
+        assert "cnrma_sparse_conv_f32" in seen and "cnrma_sparse_conv_go_f32" not in seen
+        S.GO_F32 = True
+        for splits in (-1, 1, 2):
+            S.conv_tuning(splits=splits)
+            del seen[:]
+            got = S.conv(x, W, 3, 1, residual=res, act="relu", precision="f32").F
+            assert "cnrma_sparse_conv_go_f32" in seen and "cnrma_sparse_conv_f32" not in seen
+            assert torch.allclose(got, ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max())), splits
+            assert torch.equal(got, S.conv(x, W, 3, 1, residual=res, act="relu", precision="f32").F)
+            plain = S.conv(x, W, 3, 1, precision="f32")
+            oc, of = SO.conv(c, f, W.cpu().numpy(), 3, 1, 1)
+            check(S.SparseTensor(plain.F, x.cs), oc, of, tol=2e-6)
+    finally:
+        S.conv_tuning()
+        S.GO_CONV, S.GO_F32 = prev
+        S.call = orig_call
+
+
 def test_presplit_companions_give_identical_results(device):
     """bf16x6 with pre-split feature companions (read + written by the conv epilogue) == bf16x6 splitting in the loop"""
     from cnrma_amd import sparse as S
