@@ -145,7 +145,7 @@ def build_model(C, device, n_classes=18, n_reg=6):
 # per-kernel profile of ONE eager scene (outside the timed region): HIP events around every C-ABI call on the launch
 # stream + the algorithmic work of every convolution (rows, kernel-map pairs)
 # ------------------------------------------------------------------------------------------------------------------
-CONV_CALLS = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_pairs_f16x3",
+CONV_CALLS = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_go_f32", "cnrma_sparse_conv_pairs_f32", "cnrma_sparse_conv_bf16x6", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_pairs_f16x3",
               "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_convtr_gen_f32",
               "cnrma_sparse_convtr_gen_bf16x6", "cnrma_sparse_convtr_gen_f16x3")
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "cnrma_sparse_conv_go_plan": (c_int, [L, I, I, c_size_t, I, P]),
     "cnrma_sparse_conv_go_f16x3": (c_int, [P, P, I, P, P, I, P, P, P, I, P, P, L, P, P, c_size_t, P, P]),
     "cnrma_sparse_conv_pairs_workspace_bytes": (c_size_t, [L, I, I, L]),
+    "cnrma_sparse_conv_pairs_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, L, P, c_size_t, P]),
     "cnrma_sparse_conv_pairs_f16x3": (c_int, [P, P, I, P, I, P, I, P, P, P, I, P, P, L, P, L, P, c_size_t, P]),
     "cnrma_sparse_conv_bf16_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights_bf16": (c_int, [P, I, I, I, P, P]),

@@ -436,7 +436,10 @@ __global__ __launch_bounds__(256) void sparse_conv_mfma_kernel(ConvArgs p) {
   const int cout0 = blockIdx.y * BN;
   const int zs = blockIdx.z;
   const int Cin = p.Cin, Cout = p.Cout, K = p.K;
-  const float* Wz = p.weight + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout : 0);
+  // pair-list mode (cnrma_sparse_conv_pairs_f32): a K = 1 convolution over (output, input) pairs regrouped by kernel offset in runs
+  // padded to 128 rows; the run's offset picks the weight slice
+  const float* Wz = p.weight + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout : 0) +
+                    (p.tile_tap ? (int64_t)p.tile_tap[tile0 >> 7] * Cin * Cout : 0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid / WAVES_N, wc = wid % WAVES_N;
 
@@ -4067,6 +4070,47 @@ extern "C" int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float*
   ConvArgs p{};
   p.K = K; p.Cout = Cout; p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.out = out_feats;
   p.no_cap = no_cap; p.no_dev = no_dev; p.out_amax = out_amax;
+  int64_t rb = ceil_div(no_cap * (Cout / 4), 256);
+  if (rb > 16384) rb = 16384;
+  if (K == 27) hipLaunchKernelGGL(pairs_reduce_kernel<27>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);
+  else hipLaunchKernelGGL(pairs_reduce_kernel<0>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// the same regrouping in exact fp32: the fp32 MFMA stage kernel over the pair runs (the north-star stem at CONV_PRECISION = "f32"
+// ran the tile kernel over a 5 %-full table: 3.1 ms of the 11.1 ms of convolutions per scene)
+extern "C" int cnrma_sparse_conv_pairs_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight, int Cout,
+                                           const float* scale, const float* shift, const float* residual, int act, float* out_feats,
+                                           int64_t no_cap, const int32_t* no_dev, int64_t pair_cap, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (weight == nullptr || Cin % 32 != 0 || Cout % 4 != 0 || in_feats == nullptr || nbr == nullptr || K <= 1 || K > 27 || no_cap <= 0 ||
+      pair_cap <= 0 || pair_cap % 128 != 0 || pair_cap > 0x7fffff00LL)
+    return CNRMA_EINVAL;
+  if (workspace == nullptr || workspace_bytes < cnrma_sparse_conv_pairs_workspace_bytes(no_cap, K, Cout, pair_cap))
+    return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  char* w = reinterpret_cast<char*>(workspace);
+  int32_t* hdr = reinterpret_cast<int32_t*>(w);        w += pairs_align(PAIR_HDR * 4);
+  int32_t* tile_tap = reinterpret_cast<int32_t*>(w);   w += pairs_align((size_t)(pair_cap / 128 + 1) * 4);
+  int32_t* pair_src = reinterpret_cast<int32_t*>(w);   w += pairs_align((size_t)pair_cap * 4);
+  int32_t* pos = reinterpret_cast<int32_t*>(w);        w += pairs_align((size_t)no_cap * K * 4);
+  float* prod = reinterpret_cast<float*>(w);
+  const hipError_t fe = cnrma_fill_bytes(hdr, 0, PAIR_HDR * 4, st);
+  if (fe != hipSuccess) return -(int)fe;
+  if (no_cap * K >= 0x7fffffffLL) return CNRMA_EINVAL;
+  const int64_t blocks = ceil_div(no_cap * K, 256 * PAIR_EPT);
+  hipLaunchKernelGGL(pairs_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr);
+  hipLaunchKernelGGL(pairs_plan_kernel, dim3(1), dim3(256), 0, st, K, hdr, tile_tap, pair_src, pair_cap);
+  hipLaunchKernelGGL(pairs_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nbr, no_cap, no_dev, K, hdr, pair_src, pos,
+                     pair_cap);
+  CNRMA_LAUNCH_CHECK();
+  const int rc = launch_conv(in_feats, Cin, pair_src, 1, weight, Cout, nullptr, nullptr, nullptr, 0, prod, pair_cap, hdr + 64 + 33,
+                             1, nullptr, 0, st, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, tile_tap, K);
+  if (rc != 0) return rc;
+  ConvArgs p{};
+  p.K = K; p.Cout = Cout; p.scale = scale; p.shift = shift; p.residual = residual; p.act = act; p.out = out_feats;
+  p.no_cap = no_cap; p.no_dev = no_dev; p.out_amax = nullptr;
   int64_t rb = ceil_div(no_cap * (Cout / 4), 256);
   if (rb > 16384) rb = 16384;
   if (K == 27) hipLaunchKernelGGL(pairs_reduce_kernel<27>, dim3((unsigned)rb), dim3(256), 0, st, p, pos, prod);

@@ -809,6 +809,16 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
             call("cnrma_sparse_conv_bf16x6", ptr(x.F.contiguous()), ptr(in_split), x.cs.n, Cin, ptr(nbr), K, ptr(split_weights(weight)),
                  Cout, ptr(scale), ptr(shift), ptr(res), ACT[act], ptr(out), ptr(out_split), out_cs.n, ptr(out_cs.n_dev), ptr(ws),
                  ws_bytes, stream())
+        elif prec == "f32" and PAIR_CONV and stride == 2 and K == 27 and Cout % 4 == 0 and Cin % 32 == 0 and \
+                Cin >= PAIR_CONV_MIN_CIN and _nearly_empty_map(in_cs, out_cs):
+            # pair-list kernel in exact fp32 (the stem of the 256-channel configuration)
+            pair_cap = (min(27 * out_cs.n, 8 * in_cs.n) + 128 * K + 127) // 128 * 128
+            pw_bytes = _lib.load().cnrma_sparse_conv_pairs_workspace_bytes(out_cs.n, K, Cout, pair_cap)
+            pw = _workspace(pw_bytes, x.device)
+            call("cnrma_sparse_conv_pairs_f32", ptr(x.F.contiguous()), Cin, ptr(nbr), K, ptr(w), Cout, ptr(scale), ptr(shift),
+                 ptr(res), ACT[act], ptr(out), out_cs.n, ptr(out_cs.n_dev), pair_cap, ptr(pw), pw_bytes, stream())
+            if P.static():                          # as in the f16x3 branch: a dropped pair entry must never be silent
+                P.current().watch(pw[:PAIR_HDR_BYTES].view(torch.int32)[PAIR_OVERFLOW_WORD:PAIR_OVERFLOW_WORD + 1].clone(), 0, 0)
         elif prec == "f32" and GO_F32 and K == 27 and stride == 1 and Cout >= 64 and Cin % 32 == 0 and _gather_once(in_cs, out_cs):
             # exact fp32 on the gather-once structure (v_mfma_f32_32x32x2_f32 over the tile unions)
             go_ws_bytes = out_cs.n * Cout * 4 * (Cin // 32) if out_cs.n < GO_WS_ROWS else 0

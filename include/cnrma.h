@@ -387,6 +387,12 @@ int cnrma_sparse_conv_pairs_f16x3(const float* in_feats, const float* in_amax, i
                                   const float* residual, int act, float* out_feats, float* out_amax, int64_t no_cap,
                                   const int32_t* no_dev, int64_t pair_cap, void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* The same regrouping in exact fp32 (`v_mfma_f32_32x32x2_f32` over the pair runs; weight = ME layout fp32 [K][Cin][Cout]): the
+ * stem of the 256-channel configuration at the reference's own arithmetic (fcaf3d_backbone.py:79-80). */
+int cnrma_sparse_conv_pairs_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* weight, int Cout,
+                                const float* scale, const float* shift, const float* residual, int act, float* out_feats,
+                                int64_t no_cap, const int32_t* no_dev, int64_t pair_cap, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* 22-bit convolution on the fp16 matrix cores ("f16x3"): each operand is scaled by a power of two taken from an upper
  * bound of its tensor's magnitude (so that the largest element sits at 2^13..2^14) and split into two fp16 pieces

@@ -53,7 +53,7 @@ def s_scene(device):
     return dict(P=P, F=F, backbone=backbone, head=head, n_vox=len(Cq), levels=levels, results=results, boxes=boxes, scores=scores)
 
 
-CONV_ENTRIES = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_go_f32", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_conv_pairs_f16x3",
+CONV_ENTRIES = ("cnrma_sparse_conv_f32", "cnrma_sparse_conv_go_f32", "cnrma_sparse_conv_pairs_f32", "cnrma_sparse_conv_f16x3", "cnrma_sparse_conv_go_f16x3", "cnrma_sparse_conv_pairs_f16x3",
                 "cnrma_sparse_conv_bf16x6", "cnrma_sparse_convtr_gen_f32", "cnrma_sparse_convtr_gen_f16x3", "cnrma_sparse_convtr_gen_bf16x6")
 
 
@@ -300,8 +300,8 @@ def test_north_star_stem_vs_oracle(device, s_scene, precision):
         undo()
         S.CONV_PRECISION = prev
     assert y.cs.n == len(oc) > 400000
-    if precision == "f16x3":
-        assert plans[0]["entry"] == "cnrma_sparse_conv_pairs_f16x3" and plans[0]["Cin"] == 256
+    assert plans[0]["entry"] == ("cnrma_sparse_conv_pairs_f16x3" if precision == "f16x3" else "cnrma_sparse_conv_pairs_f32")
+    assert plans[0]["Cin"] == 256
     for got, (ecs, ef), name in ((y, (oc, of), "stem conv"), (z, (pc, pf), "stem conv + norm + pool")):
         c = got.cs.C.cpu().numpy().astype(np.int64)
         k1, k2 = np.argsort(SO._key(c), kind="stable"), np.argsort(SO._key(ecs.C.numpy()), kind="stable")

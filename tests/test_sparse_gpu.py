@@ -399,11 +399,12 @@ def test_conv_fused_epilogue(device):
         check(out, c, fn(o * scale + shift + res))
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 @pytest.mark.parametrize("cin,cout,ts,n,span", [(32, 64, 1, 6000, 40), (256, 64, 1, 3000, 30), (64, 128, 2, 5000, 25), (32, 64, 1, 1, 4)])
-def test_pair_list_conv_vs_oracle_and_tile_kernel(device, cin, cout, ts, n, span):
+def test_pair_list_conv_vs_oracle_and_tile_kernel(device, cin, cout, ts, n, span, precision):
     """the stem's kernel (stride 2 on a sparse point sample -> nearly empty kernel map): pair-list path vs the fp64 oracle,
     vs the output-stationary tile kernel, with the fused epilogue, and bit-reproducible from run to run (the pair slots are
-    handed out by atomics: the list layout varies, the sums must not)"""
+    handed out by atomics: the list layout varies, the sums must not) -- in f16x3 and in exact fp32 (cnrma_sparse_conv_pairs_f32)"""
     from cnrma_amd import sparse as S
     rng = np.random.RandomState(cin + n)
     c, f = rand_sparse(rng, n=n, span=span, C=cin, ts=ts, batch=2)
@@ -413,28 +414,31 @@ def test_pair_list_conv_vs_oracle_and_tile_kernel(device, cin, cout, ts, n, span
     Wd, sd, hd = (torch.from_numpy(a).to(device) for a in (W, scale, shift))
     x = to_st(c, f, ts, device)
     assert S._nearly_empty_map(x.cs, x.cs.strided(2)), "test inputs must be sparse enough to take the pair-list path"
+    pairs, tile_entry = ("cnrma_sparse_conv_pairs_f16x3", "cnrma_sparse_conv_f16x3") if precision == "f16x3" else \
+        ("cnrma_sparse_conv_pairs_f32", "cnrma_sparse_conv_f32")
     calls = []
     orig, prev_min = S.call, S.PAIR_CONV_MIN_CIN
     S.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
     S.PAIR_CONV_MIN_CIN = 32
     try:
-        out = S.conv(x, Wd, 3, 2, sd, hd, None, "relu", precision="f16x3")
-        again = S.conv(to_st(c, f, ts, device), Wd, 3, 2, sd, hd, None, "relu", precision="f16x3")
+        out = S.conv(x, Wd, 3, 2, sd, hd, None, "relu", precision=precision)
+        again = S.conv(to_st(c, f, ts, device), Wd, 3, 2, sd, hd, None, "relu", precision=precision)
     finally:
         S.call, S.PAIR_CONV_MIN_CIN = orig, prev_min
-    assert calls.count("cnrma_sparse_conv_pairs_f16x3") == 2 and "cnrma_sparse_conv_f16x3" not in calls
+    assert calls.count(pairs) == 2 and tile_entry not in calls
     check(out, oc, SO.relu(of * scale + shift), tol=2e-6)
     assert torch.equal(out.F, again.F)
     prev = S.PAIR_CONV
     S.PAIR_CONV = False
     try:
-        tile = S.conv(to_st(c, f, ts, device), Wd, 3, 2, sd, hd, None, "relu", precision="f16x3")
+        tile = S.conv(to_st(c, f, ts, device), Wd, 3, 2, sd, hd, None, "relu", precision=precision)
     finally:
         S.PAIR_CONV = prev
     assert torch.equal(tile.C, out.C)
     assert float((tile.F - out.F).abs().max()) <= 2e-6 * max(1.0, float(tile.F.abs().max()))
-    # the magnitude bound published for the consumers covers the output
-    assert float(out.amax.max()) == float(out.F.abs().max())
+    # the magnitude bound published for the consumers covers the output (f16x3: the next layer's operand scale)
+    if precision == "f16x3":
+        assert float(out.amax.max()) == float(out.F.abs().max())
 
 
 def test_generative_transpose_vs_oracle(device):
