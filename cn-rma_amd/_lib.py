@@ -28,8 +28,10 @@ SIGNATURES = {
     "cnrma_rma_neus_rows_backward_f32": (c_int, [P, I, I, I, I, I, P, P, I, P, P, P, P]),
     "cnrma_rma_sigmoid_table_f32": (c_int, [P, L, P, P]),
     "cnrma_debug_div_by_voxel_size_f32": (c_int, [P, L, F, P, P, P]),
-    "cnrma_rma_neus_march_f32": (c_int, [P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
-    "cnrma_nchw_to_nhwc_march_f32": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P]),
+    "cnrma_rma_skip_table_bytes": (c_size_t, [I, I, I]),
+    "cnrma_rma_march_tables_f32": (c_int, [P, I, I, I, P, P, P]),
+    "cnrma_rma_neus_march_f32": (c_int, [P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P, P]),
+    "cnrma_nchw_to_nhwc_march_f32": (c_int, [P, P, I, P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P, P]),
     "cnrma_rma_neus_emit_rows_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, P, I, P, L, P, P, F, F, F, P, I, P, I, P, I, P, P]),
     "cnrma_rma_neus_emit_rows_ref_f32": (c_int, [P, P, I, I, I, I, I, F, P, L, P, P, I, P, L, P, P, F, F, F, P, I, P, I, P, I, P, P]),
     "cnrma_sample_workspace_bytes": (c_size_t, []),

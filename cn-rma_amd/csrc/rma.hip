@@ -217,10 +217,21 @@ __device__ __forceinline__ float div_by_vs(float a, float vs, float y) {
   return fmaf(r, y, q);
 }
 
-struct TabSample { float s; bool valid; };
+struct TabSample { float s; bool valid; int rad; };
+
+// Free-space skipping (round 5).  skip[block] (one byte per 4 x 4 x 4 block of voxels, cnrma_rma_march_tables_f32) = R in {0, 4, 8,
+// 12, 16}: every voxel within Chebyshev distance R of ANY voxel of the block holds the block's table value, bit for bit.  A
+// sample whose successor has the same table value is a no-op of the march (alpha = 0, w = 0 < thr, transmittance x 1.0: the
+// `still` test below), so a ray standing in a voxel of radius R may jump over the next j steps without evaluating them
+// whenever they are certain to land inside that radius: the rounded voxel index moves by at most |delta| + 1 per axis for a
+// displacement of delta voxels, the displacement of j steps is j * m with m = t_one * max|d_axis| / vs, so j < (R - 1) / m
+// suffices (taken with a margin of 1 % + 0.01 voxel; the fp32 error of the positions is ~1e-5 voxel).  The records and sums
+// are those of the step-by-step march, bit for bit (tests: golden vectors, oracle, skip on / off).
+constexpr int SKIP_B = 4, SKIP_RMAX = 16;
 
 __device__ __forceinline__ TabSample fetch_step(const Ray& r, int n, const MarchParams& p, float inv_vs,
-                                                const float* __restrict__ tab, float s_out) {
+                                                const float* __restrict__ tab, float s_out,
+                                                const uint8_t* __restrict__ skip = nullptr, int by = 0, int bz = 0) {
   const float t = (float)n * p.t_one;
   const float x = r.ox + r.dx * t, y = r.oy + r.dy * t, z = r.oz + r.dz * t;
   const float fx = rintf(div_by_vs(x - p.ox, p.vs, inv_vs));
@@ -229,7 +240,11 @@ __device__ __forceinline__ TabSample fetch_step(const Ray& r, int n, const March
   TabSample o;
   o.valid = (fx >= 0.0f) && (fx < (float)p.X) && (fy >= 0.0f) && (fy < (float)p.Y) && (fz >= 0.0f) && (fz < (float)p.Z);
   o.s = s_out;
-  if (o.valid) o.s = tab[((int)fx * p.Y + (int)fy) * p.Z + (int)fz];      // X*Y*Z < 2^31 (checked by the entry point)
+  o.rad = 0;
+  if (o.valid) {
+    o.s = tab[((int)fx * p.Y + (int)fy) * p.Z + (int)fz];                   // X*Y*Z < 2^31 (checked by the entry point)
+    if (skip != nullptr) o.rad = skip[(((int)fx >> 2) * by + ((int)fy >> 2)) * bz + ((int)fz >> 2)];
+  }
   return o;
 }
 
@@ -237,7 +252,7 @@ __device__ __forceinline__ void neus_march_block(const MarchParams& p, const flo
                                                  const float* __restrict__ tab, int32_t* __restrict__ count,
                                                  double* __restrict__ wsum, int2* __restrict__ kept, int cap,
                                                  int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view,
-                                                 unsigned vblock) {
+                                                 unsigned vblock, const uint8_t* __restrict__ skip = nullptr) {
   // thread -> ray: a wave marches an 8 x 8 pixel tile (a block a 16 x 16 tile) instead of 64 consecutive pixels of an image
   // row: the bundle stays a compact patch of voxels at every step, so one table line serves more lanes
   int64_t r;
@@ -261,9 +276,13 @@ __device__ __forceinline__ void neus_march_block(const MarchParams& p, const flo
   int a, b;
   if (clip_steps(ray, p, &a, &b)) {
     double acc = 1.0;
-    TabSample cur = fetch_step(ray, a, p, inv_vs, tab, s_out);
+    const int by = (p.Y + SKIP_B - 1) / SKIP_B, bz = (p.Z + SKIP_B - 1) / SKIP_B;
+    // steps a jump may cover per unit of safe radius (see SKIP_B above): j <= (R - 1.01) / (1.01 m)
+    const float m_vox = p.t_one * fmaxf(fmaxf(fabsf(ray.dx), fabsf(ray.dy)), fabsf(ray.dz)) * inv_vs * 1.01f;
+    const float per_vox = m_vox > 1e-6f ? 1.0f / m_vox : 0.0f;
+    TabSample cur = fetch_step(ray, a, p, inv_vs, tab, s_out, skip, by, bz);
     TabSample n1 = cur, n2 = cur;                       // samples a+1, a+2 (only used when inside [a, b])
-    if (a + 1 <= b) n1 = fetch_step(ray, a + 1, p, inv_vs, tab, s_out);
+    if (a + 1 <= b) n1 = fetch_step(ray, a + 1, p, inv_vs, tab, s_out, skip, by, bz);
     // a step whose successor has the same table value has alpha = max((s - s) / s, 0) = 0: w = 0 < thr (nothing kept) and
     // the transmittance is multiplied by 1.0 -- the whole body is a no-op (given 0 < thr <= 1, so that neither "w >= thr"
     // nor the exit test can change).  Rays spend most of their steps in free space (tsdf == -1: one table value); when every
@@ -271,8 +290,20 @@ __device__ __forceinline__ void neus_march_block(const MarchParams& p, const flo
     // instructions per step; the kernel is VALU-issue bound).
     const bool can_skip = p.thr > 0.0f && p.thr <= 1.0f;
     for (int n = a; n <= b; ++n) {
-      if (n + 2 <= b) n2 = fetch_step(ray, n + 2, p, inv_vs, tab, s_out);     // in flight during this step
       const bool still = can_skip && (n + 1 <= b) && (n1.s == cur.s);
+      if (still && cur.rad > 0) {
+        // every step up to n + j lands in a voxel holding cur.s: steps n .. n + j - 1 are no-ops; go on at n + j with the same
+        // sample value (its own radius is not known: one plain step follows before the next jump)
+        int j = (int)(((float)cur.rad - 1.01f) * per_vox);
+        j = min(j, b - 2 - n);
+        if (j >= 3) {
+          n += j - 1;                                                           // the loop's ++n lands on n + j
+          cur.rad = 0;
+          n1 = fetch_step(ray, n + 2, p, inv_vs, tab, s_out, skip, by, bz);     // sample (n + j) + 1
+          continue;
+        }
+      }
+      if (n + 2 <= b) n2 = fetch_step(ray, n + 2, p, inv_vs, tab, s_out, skip, by, bz);     // in flight during this step
       if (!still) {
         float s_next;
         if (n + 1 <= b) s_next = n1.s;
@@ -300,8 +331,9 @@ __device__ __forceinline__ void neus_march_block(const MarchParams& p, const flo
 __global__ __launch_bounds__(256) void neus_march_kernel(MarchParams p, const float* __restrict__ proj_inv,
                                                          const float* __restrict__ tab, int32_t* __restrict__ count,
                                                          double* __restrict__ wsum, int2* __restrict__ kept, int cap,
-                                                         int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view) {
-  neus_march_block(p, proj_inv, tab, count, wsum, kept, cap, overflow, tiles_x, tiles_per_view, blockIdx.x);
+                                                         int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view,
+                                                         const uint8_t* __restrict__ skip) {
+  neus_march_block(p, proj_inv, tab, count, wsum, kept, cap, overflow, tiles_x, tiles_per_view, blockIdx.x, skip);
 }
 
 // Layout pass + march in ONE launch.  The NCHW -> channels-last pass is a pure HBM stream (25 GB at the north-star shape);
@@ -319,11 +351,12 @@ __global__ __launch_bounds__(256) void layout_march_kernel(MarchParams p, const 
                                                            int32_t* __restrict__ overflow, int tiles_x, int tiles_per_view,
                                                            unsigned n_march, unsigned stride,
                                                            const float* __restrict__ src, float* __restrict__ dst, int C,
-                                                           int64_t HW, unsigned n_px_tiles, unsigned n_c_blocks) {
+                                                           int64_t HW, unsigned n_px_tiles, unsigned n_c_blocks,
+                                                           const uint8_t* __restrict__ skip) {
   __shared__ float tile[64][65];
   const unsigned b = blockIdx.x;
   if (b % stride == stride - 1 && b / stride < n_march) {
-    neus_march_block(p, proj_inv, tab, count, wsum, kept, cap, overflow, tiles_x, tiles_per_view, b / stride);
+    neus_march_block(p, proj_inv, tab, count, wsum, kept, cap, overflow, tiles_x, tiles_per_view, b / stride, skip);
     return;
   }
   const unsigned before = (b + 1) / stride < n_march ? (b + 1) / stride : n_march;       // march blocks at smaller indices
@@ -357,6 +390,59 @@ __global__ __launch_bounds__(256) void layout_march_kernel(MarchParams p, const 
 __global__ __launch_bounds__(256) void sigmoid_table_kernel(const float* __restrict__ tsdf, int64_t n, float* __restrict__ tab) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     tab[i] = sigmoid_neg(tsdf[i]);
+}
+
+// skip table, pass 1: blockval[b] = the table value shared by all voxels of the 4 x 4 x 4 block b (bit pattern), or 0xFFFFFFFF when
+// they differ / the block sticks out of the grid (a sigmoid is never NaN).  One thread per block, 16-byte reads along z.
+__global__ __launch_bounds__(256) void skip_blockval_kernel(const float* __restrict__ tab, int X, int Y, int Z, int bx, int by, int bz,
+                                                            uint32_t* __restrict__ blockval) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (int64_t)bx * by * bz) return;
+  const int kz = (int)(b % bz), ky = (int)((b / bz) % by), kx = (int)(b / ((int64_t)bz * by));
+  const int x0 = kx * SKIP_B, y0 = ky * SKIP_B, z0 = kz * SKIP_B;
+  uint32_t v = 0xFFFFFFFFu;
+  if (x0 + SKIP_B <= X && y0 + SKIP_B <= Y && z0 + SKIP_B <= Z) {
+    const uint32_t* t = reinterpret_cast<const uint32_t*>(tab);
+    v = t[((int64_t)x0 * Y + y0) * Z + z0];
+    bool same = true;
+    for (int i = 0; i < SKIP_B; ++i)
+      for (int j = 0; j < SKIP_B; ++j) {
+        const uint32_t* q = t + ((int64_t)(x0 + i) * Y + (y0 + j)) * Z + z0;
+#pragma unroll
+        for (int k = 0; k < SKIP_B; ++k) same = same && (q[k] == v);
+      }
+    if (!same) v = 0xFFFFFFFFu;
+  }
+  blockval[b] = v;
+}
+// pass 2: skip[b] = 4 r for the largest r <= 4 such that every block within Chebyshev distance r of b exists and holds b's value
+__global__ __launch_bounds__(256) void skip_radius_kernel(const uint32_t* __restrict__ blockval, int bx, int by, int bz,
+                                                          uint8_t* __restrict__ skip) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (int64_t)bx * by * bz) return;
+  const int kz = (int)(b % bz), ky = (int)((b / bz) % by), kx = (int)(b / ((int64_t)bz * by));
+  const uint32_t v = blockval[b];
+  int r = 0;
+  if (v != 0xFFFFFFFFu) {
+    constexpr int RB = SKIP_RMAX / SKIP_B;
+    for (r = 0; r < RB; ++r) {                               // does the shell at distance r + 1 hold v everywhere?
+      const int d = r + 1;
+      if (kx - d < 0 || ky - d < 0 || kz - d < 0 || kx + d >= bx || ky + d >= by || kz + d >= bz) break;
+      bool ok = true;
+      for (int i = -d; i <= d && ok; ++i)
+        for (int j = -d; j <= d && ok; ++j) {
+          const bool face = i == -d || i == d || j == -d || j == d;
+          const uint32_t* q = blockval + ((int64_t)(kx + i) * by + (ky + j)) * bz + kz;
+          if (face) {
+            for (int k = -d; k <= d; ++k) ok = ok && q[k] == v;
+          } else {
+            ok = q[-d] == v && q[d] == v;
+          }
+        }
+      if (!ok) break;
+    }
+  }
+  skip[b] = (uint8_t)(r * SKIP_B);
 }
 
 // Emission from the kept-sample records, two small kernels:
@@ -632,9 +718,33 @@ extern "C" int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* 
   return 0;
 }
 
+extern "C" size_t cnrma_rma_skip_table_bytes(int X, int Y, int Z) {
+  const size_t nb = (size_t)ceil_div(X, SKIP_B) * (size_t)ceil_div(Y, SKIP_B) * (size_t)ceil_div(Z, SKIP_B);
+  return ((nb + 255) & ~(size_t)255) + nb * sizeof(uint32_t);               // radii, then the pass-1 scratch
+}
+
+extern "C" int cnrma_rma_march_tables_f32(const float* tsdf, int X, int Y, int Z, float* table, void* skip_table, void* stream) {
+  if (tsdf == nullptr || table == nullptr || X <= 0 || Y <= 0 || Z <= 0) return CNRMA_EINVAL;
+  const int64_t n = (int64_t)X * Y * Z;
+  hipStream_t st = as_stream(stream);
+  int64_t blocks = ceil_div(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sigmoid_table_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tsdf, n, table);
+  if (skip_table != nullptr) {
+    const int bx = (int)ceil_div(X, SKIP_B), by = (int)ceil_div(Y, SKIP_B), bz = (int)ceil_div(Z, SKIP_B);
+    const int64_t nb = (int64_t)bx * by * bz;
+    uint8_t* skip = reinterpret_cast<uint8_t*>(skip_table);
+    uint32_t* blockval = reinterpret_cast<uint32_t*>(skip + ((nb + 255) & ~(int64_t)255));
+    hipLaunchKernelGGL(skip_blockval_kernel, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, st, table, X, Y, Z, bx, by, bz, blockval);
+    hipLaunchKernelGGL(skip_radius_kernel, dim3((unsigned)ceil_div(nb, 256)), dim3(256), 0, st, blockval, bx, by, bz, skip);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 static int launch_march(const MarchParams& p, const float* proj_inv, const float* tsdf, const float* sig_table,
                         int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow, const float* feat_nchw,
-                        float* feat_nhwc, int C, hipStream_t st) {
+                        float* feat_nhwc, int C, hipStream_t st, const uint8_t* skip = nullptr) {
   const int64_t R = (int64_t)p.V * p.H * p.W, HW = (int64_t)p.H * p.W;
   hipError_t e = cnrma_fill_bytes(overflow, 0, 4 * sizeof(int32_t), st);     // [0] violations, [1..3] reserved
   if (e != hipSuccess) return -(int)e;
@@ -650,7 +760,7 @@ static int launch_march(const MarchParams& p, const float* proj_inv, const float
       if (stride % 2 == 0) --stride;                                 // odd: march blocks on all 8 XCDs
       hipLaunchKernelGGL(layout_march_kernel, dim3((unsigned)(n_layout + n_march)), dim3(256), 0, st, p, proj_inv, sig_table,
                          count, wsum, reinterpret_cast<int2*>(kept), cap, overflow, tx, tx * ty, (unsigned)n_march, stride,
-                         feat_nchw, feat_nhwc, C, HW, (unsigned)npx, (unsigned)ncb);
+                         feat_nchw, feat_nhwc, C, HW, (unsigned)npx, (unsigned)ncb, skip);
       CNRMA_LAUNCH_CHECK();
       return 0;
     }
@@ -659,7 +769,7 @@ static int launch_march(const MarchParams& p, const float* proj_inv, const float
   }
   if (table) {
     hipLaunchKernelGGL(neus_march_kernel, dim3((unsigned)n_march), dim3(256), 0, st, p, proj_inv, sig_table, count, wsum,
-                       reinterpret_cast<int2*>(kept), cap, overflow, tx, tx * ty);
+                       reinterpret_cast<int2*>(kept), cap, overflow, tx, tx * ty, skip);
   } else {
     if (tsdf == nullptr) return CNRMA_EINVAL;
     hipLaunchKernelGGL(neus_count_kernel, dim3((unsigned)ceil_div(R, 256)), dim3(256), 0, st, p, proj_inv, tsdf, count, wsum,
@@ -672,24 +782,26 @@ static int launch_march(const MarchParams& p, const float* proj_inv, const float
 extern "C" int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const float* sig_table, int V, int H,
                                         int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
                                         int n_steps, float t_one, float thr, int32_t* count, double* wsum, void* kept,
-                                        int cap, int32_t* overflow, void* stream) {
+                                        int cap, int32_t* overflow, const void* skip_table, void* stream) {
   if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr) return CNRMA_EINVAL;
   if (tsdf == nullptr && sig_table == nullptr) return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
-  return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, nullptr, nullptr, 0, as_stream(stream));
+  return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, nullptr, nullptr, 0, as_stream(stream),
+                      sig_table ? reinterpret_cast<const uint8_t*>(skip_table) : nullptr);
 }
 
 extern "C" int cnrma_nchw_to_nhwc_march_f32(const float* feat_nchw, float* feat_nhwc, int C, const float* proj_inv,
                                             const float* tsdf, const float* sig_table, int V, int H, int W, int X, int Y,
                                             int Z, float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
                                             float thr, int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow,
-                                            void* stream) {
+                                            const void* skip_table, void* stream) {
   if (bad_dims(V, H, W, X, Y, Z, n_steps) || kept == nullptr || cap <= 0 || overflow == nullptr || C <= 0 ||
       feat_nchw == nullptr || feat_nhwc == nullptr)
     return CNRMA_EINVAL;
   if (tsdf == nullptr && sig_table == nullptr) return CNRMA_EINVAL;
   MarchParams p = make_params(V, H, W, X, Y, Z, voxel_size, ox, oy, oz, n_steps, t_one, thr);
-  return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, feat_nchw, feat_nhwc, C, as_stream(stream));
+  return launch_march(p, proj_inv, tsdf, sig_table, count, wsum, kept, cap, overflow, feat_nchw, feat_nhwc, C, as_stream(stream),
+                      sig_table ? reinterpret_cast<const uint8_t*>(skip_table) : nullptr);
 }
 
 static int neus_emit_rows_any(const float* proj_inv, const float* feat_nhwc, const float* const* feat_ref, int V, int C, int H, int W,

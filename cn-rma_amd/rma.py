@@ -21,6 +21,11 @@ from ._lib import call, ptr, stream
 
 
 SIGMOID_TABLE = True     # production march: table-driven kernel (False: the per-step sigmoid kernel, kept for A/B runs)
+MARCH_SKIP = "auto"      # free-space skipping in the table-driven march (cnrma_rma_march_tables_f32): "auto" = from MARCH_SKIP_MIN_RAYS rays
+                         # on (north-star shape, 12.3 M rays: 2.71 -> 1.26 ms with the table builds; ScanNet shape, 0.77 M rays on a
+                         # stride-4 grid of maps: 0.30 -> 0.39 ms, the two extra launches cost more than the skipped steps save:
+                         # profiles/r05_march_ab_*.log); True / False force it (A/B, parity tests)
+MARCH_SKIP_MIN_RAYS = 4_000_000
 
 
 def _f32(t):
@@ -246,10 +251,16 @@ class _March:
             tab = torch.empty_like(self.tsdf) if SIGMOID_TABLE else None
         overflow_all, overflow = overflow, overflow[:1]
         self._overflow = overflow
-        if tab is not None:      # sigmoid(-tsdf) once per voxel instead of once per marched step (bit-identical)
-            call("cnrma_rma_sigmoid_table_f32", ptr(self.tsdf), self.tsdf.numel(), ptr(tab), stream())
+        skip = None
+        if tab is not None:      # sigmoid(-tsdf) once per voxel instead of once per marched step (bit-identical) + the free-space
+            if (self.R >= MARCH_SKIP_MIN_RAYS) if MARCH_SKIP == "auto" else bool(MARCH_SKIP):   # skip table (radius per 4^3 block)
+                if getattr(self, "_skip", None) is None:
+                    self._skip = torch.empty(_lib.load().cnrma_rma_skip_table_bytes(self.X, self.Y, self.Z), dtype=torch.uint8,
+                                             device=self.dev)
+                skip = self._skip
+            call("cnrma_rma_march_tables_f32", ptr(self.tsdf), self.X, self.Y, self.Z, ptr(tab), ptr(skip), stream())
         tail = (ptr(self.pinv), ptr(self.tsdf), ptr(tab), self.V, self.H, self.W, self.X, self.Y, self.Z, self.vs, *self.org,
-                self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow_all), stream())
+                self.N, self.t_one, self.thr, ptr(cnt), ptr(wsum), ptr(kept), cap, ptr(overflow_all), ptr(skip), stream())
         if layout_from is not None:
             src = _f32(layout_from)
             assert tuple(src.shape) == (self.V, self.C, self.H, self.W) and self.feat is not None and self.feat.is_contiguous()

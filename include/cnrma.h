@@ -131,12 +131,20 @@ int cnrma_rma_neus_emit_f32(const float* proj_inv, const float* tsdf, const floa
  * cnrma_rma_sigmoid_table_f32 -- the march then reads it instead of evaluating the sigmoid at every step (same function of
  * the same value: bit-identical weights).  With sig_table == NULL the TSDF is read and the sigmoid evaluated per step. */
 int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* table, void* stream);
+/* The march's per-scene tables in one call: the sigmoid table and (skip_table != NULL) the free-space skip table -- one byte per
+ * 4 x 4 x 4 block of voxels = a radius R in {0, 4, .., 16} such that every voxel within Chebyshev distance R of any voxel of the
+ * block holds the block's table value bit for bit.  Samples whose successor has the same table value are no-ops of the march
+ * (ray_marching.py:759-767: alpha = 0, w = 0 < thr, transmittance x 1), so a ray standing in such a block jumps over the steps
+ * that are certain to stay inside the radius without evaluating them: same records, same sums, fewer evaluated steps (rays spend
+ * most of their steps in free space).  skip_table: cnrma_rma_skip_table_bytes(X, Y, Z) bytes (radii + scratch of the build). */
+size_t cnrma_rma_skip_table_bytes(int X, int Y, int Z);
+int cnrma_rma_march_tables_f32(const float* tsdf, int X, int Y, int Z, float* table, void* skip_table, void* stream);
 /* parity aid: the march's division by the voxel size (reciprocal + two quotient refinements) next to the IEEE division */
 int cnrma_debug_div_by_voxel_size_f32(const float* a, int64_t n, float voxel_size, float* q_fast, float* q_ref, void* stream);
 int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const float* sig_table, int V, int H, int W, int X,
                              int Y, int Z, float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
                              float thr, int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow,
-                             void* stream);
+                             const void* skip_table, void* stream);       /* skip_table: may be NULL; needs sig_table */
 
 /* The layout pass (cnrma_nchw_to_nhwc_f32) and the march (cnrma_rma_neus_march_f32) of one scene in ONE launch: the two
  * are independent (the march does not read the feature maps), one is a pure HBM stream and the other VALU-bound on
@@ -145,7 +153,7 @@ int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const flo
 int cnrma_nchw_to_nhwc_march_f32(const float* feat_nchw, float* feat_nhwc, int C, const float* proj_inv, const float* tsdf,
                                  const float* sig_table, int V, int H, int W, int X, int Y, int Z, float voxel_size, float ox,
                                  float oy, float oz, int n_steps, float t_one, float thr, int32_t* count, double* wsum,
-                                 void* kept, int cap, int32_t* overflow, void* stream);
+                                 void* kept, int cap, int32_t* overflow, const void* skip_table, void* stream);
 
 /* Backward of cnrma_rma_neus_emit_rows_f32 w.r.t. the feature maps (training; the weights carry no
  * gradient: the reference computes them under torch.no_grad(), ray_marching.py:705).

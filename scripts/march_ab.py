@@ -1,4 +1,5 @@
-"""A/B of the march kernels (per-step sigmoid vs table-driven) at a workload shape: HIP-event times, interleaved"""
+"""A/B of the march kernels (per-step sigmoid vs table-driven, free-space skipping off / on) at a workload shape: HIP-event
+times (table builds included), interleaved; counts / sums / kept-sample records compared bit for bit"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,19 +12,26 @@ feat = rma.to_nhwc(sc["features"][:, 0].to(dev))
 pinv = rma.projection_inverse(sc["projection"][:, 0], stride).to(dev)
 tsdf = sc["tsdf"][0, 0].to(dev)
 m = rma._March(feat, pinv, tsdf, dims, 0.04, (0, 0, 0), 300, 0.05, "neus", 0)
+MODES = {"per-step sigmoid": (False, False), "table": (True, False), "table + free-space skip": (True, True)}
 res = {}
 for rep in range(4):
-    for mode in (False, True):          # (the image-row variant of the table kernel was removed with its environment switch)
-        rma.SIGMOID_TABLE = bool(mode)
+    for name, (table, skip) in MODES.items():
+        rma.SIGMOID_TABLE, rma.MARCH_SKIP = table, skip
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); out = m.march(); b.record(); torch.cuda.synchronize()
-        res.setdefault(mode, []).append(a.elapsed_time(b))
-        res[("out", mode)] = out
-print(wl, "per-step sigmoid kernel ms:", [round(x, 3) for x in res[False]])
-print(wl, "table kernel, 8x8-pixel tiles per wave (+table build) ms:", [round(x, 3) for x in res[True]])
-c0, w0, k0, _ = res[("out", False)]
-for mode in (True,):
-    c1, w1, k1, _ = res[("out", mode)]
+        res.setdefault(name, []).append(a.elapsed_time(b))
+        res[("out", name)] = out
+for name in MODES:
+    print(wl, f"{name:26s} ms:", [round(x, 3) for x in res[name]])
+c0, w0, k0, _ = res[("out", "per-step sigmoid")]
+for name in list(MODES)[1:]:
+    c1, w1, k1, _ = res[("out", name)]
     live = torch.arange(k0.shape[1], device=dev)[None, :] < c0[:, None].clamp(max=k0.shape[1])
-    print(mode, "counts equal", torch.equal(c0, c1), "wsum equal", torch.equal(w0, w1), "records equal", bool((k0[live] == k1[live]).all()),
+    print(name, ": counts equal", torch.equal(c0, c1), "wsum equal", torch.equal(w0, w1), "records equal", bool((k0[live] == k1[live]).all()),
           "rays", c0.numel(), "kept", int(c0.sum()))
+if getattr(m, "_skip", None) is not None:
+    nb = 1
+    for d in dims:
+        nb *= -(-d // 4)
+    r = m._skip[:nb]
+    print("skip radii (blocks of 4^3 voxels):", {int(v): int((r == v).sum()) for v in (0, 4, 8, 12, 16)})

@@ -401,3 +401,61 @@ def test_select_records_equals_mask_index_scatter(device, name):
         n = int(n_a)
         assert n == int(n_b) == min(M, n_keep)
         assert torch.equal(ca[:n], cb[:n]) and torch.equal(fa[:n], fb[:n]) and torch.equal(wa[:n], wb[:n])
+
+
+@pytest.mark.parametrize("shape,seed", [("tiny", 0), ("S", 1), ("St", 2)])
+def test_free_space_skipping_changes_nothing_in_the_march(device, shape, seed):
+    """rma.MARCH_SKIP: rays jump over steps that are certain to land in voxels of the same table value (no-ops of the march,
+    ray_marching.py:759-767) -- counts, fp64 weight sums and every kept-sample record (weight bits, step) equal those of the
+    step-by-step march bit for bit, on furnished rooms at the plumbing, ScanNet-train and ScanNet-test shapes; the skip table
+    itself is checked against its definition on the host"""
+    import numpy as np
+    from cnrma_amd import rma, synth
+    V, C, H, W, dims, stride = synth.SHAPES[shape]
+    sc = synth.make_scene((V, 8, H, W, dims, stride), seed=seed, boxes=3)
+    feat = rma.to_nhwc(sc["features"][:, 0].to(device))
+    pinv = rma.projection_inverse(sc["projection"][:, 0], stride).to(device)
+    tsdf = sc["tsdf"][0, 0].to(device)
+    m = rma._March(feat, pinv, tsdf, dims, 0.04, sc["origin"], 300, 0.05, "neus", 0)
+    prev = rma.MARCH_SKIP
+    try:
+        rma.MARCH_SKIP = False
+        c0, w0, k0, o0 = m.march()
+        rma.MARCH_SKIP = True
+        c1, w1, k1, o1 = m.march()
+    finally:
+        rma.MARCH_SKIP = prev
+    assert int(o0[0]) == 0 and int(o1[0]) == 0
+    assert torch.equal(c0, c1) and torch.equal(w0, w1) and int(c0.sum()) > 500
+    live = torch.arange(k0.shape[1], device=device)[None, :] < c0[:, None]
+    assert torch.equal(k0[live], k1[live])
+    # ---- the table against its definition: radius R of a block = 4 x the largest r <= 4 with every block within Chebyshev
+    # distance r inside the grid, uniform, and of the block's value
+    X, Y, Z = dims
+    bx, by, bz = -(-X // 4), -(-Y // 4), -(-Z // 4)
+    radii = m._skip[:bx * by * bz].cpu().numpy().reshape(bx, by, bz)
+    sig = torch.empty_like(tsdf)
+    from cnrma_amd._lib import call, ptr
+    from cnrma_amd.rma import stream
+    call("cnrma_rma_sigmoid_table_f32", ptr(tsdf), tsdf.numel(), ptr(sig), stream())
+    bits = sig.cpu().numpy().view(np.uint32).reshape(X, Y, Z)
+    val = np.full((bx, by, bz), 0xFFFFFFFF, dtype=np.uint64)
+    for i in range(X // 4):
+        for j in range(Y // 4):
+            blk = bits[4 * i:4 * i + 4, 4 * j:4 * j + 4, :Z // 4 * 4].reshape(4, 4, Z // 4, 4)
+            same = (blk == blk[0:1, 0:1, :, 0:1]).all(axis=(0, 1, 3))
+            val[i, j, :Z // 4] = np.where(same, blk[0, 0, :, 0].astype(np.uint64), 0xFFFFFFFF)
+    rng = np.random.RandomState(seed)
+    for _ in range(300):
+        i, j, k = rng.randint(bx), rng.randint(by), rng.randint(bz)
+        r = 0
+        if val[i, j, k] != 0xFFFFFFFF:
+            while r < 4:
+                d = r + 1
+                if min(i, j, k) - d < 0 or i + d >= bx or j + d >= by or k + d >= bz:
+                    break
+                if not (val[i - d:i + d + 1, j - d:j + d + 1, k - d:k + d + 1] == val[i, j, k]).all():
+                    break
+                r += 1
+        assert radii[i, j, k] == 4 * r, (i, j, k, radii[i, j, k], r)
+    assert (radii > 0).mean() > 0.05                                  # furnished rooms still have free space to skip
