@@ -37,7 +37,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0
 # HBM-side traffic of the dominant kernel per launch: READ from the per-kernel sums of the PMC passes committed under
 # profiles/ (scripts/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs folded by scripts/pmc_sum.py;
 # counter unit KB; FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM")
-PMC_TAG = "r04b"
+PMC_TAG = "r05"
 PMC_KERNELS = {"dense": ("backproject_accum",), "conv": ("sparse_conv_",)}
 
 
@@ -65,6 +65,37 @@ def pmc_traffic(workload, family, tag=None, profiles=None):
         launches = n
         files.append(os.path.relpath(path, ROOT))
     return total, f"{files[0]} (x2) + {files[1]}: per-kernel sums over {launches} dispatches of {'/'.join(PMC_KERNELS[family])}*"
+
+
+SQ_FAMILIES = {"gather_once_conv": ("sparse_conv_go2_kernel", "sparse_conv_go_kernel"), "stage_conv": ("sparse_conv_bf16x6_kernel",),
+               "dense": ("backproject_accum",), "march": ("neus_march_kernel", "layout_march_kernel")}
+
+
+def pmc_sq(workload, tag=None, profiles=None):
+    """per kernel family, from the SQ counter pass committed under profiles/ (scripts/profile_sq.sh, one slot): MFMA-busy fraction
+    = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), the split of the wave cycles (parked in s_waitcnt / issue-stalled /
+    issuing) and LDS bank-conflict cycles per LDS-active cycle.  None when the pass is not there."""
+    import csv
+    path = os.path.join(profiles or os.path.join(ROOT, "profiles"), f"{tag or PMC_TAG}_{workload.lower()}_pmc_SQ.csv")
+    if not os.path.exists(path):
+        return None
+    acc = {}
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            for fam, pats in SQ_FAMILIES.items():
+                if any(p_ in r["Kernel_Name"] for p_ in pats):
+                    d = acc.setdefault(fam, {})
+                    d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Sum"])
+    out = {"source": os.path.relpath(path, ROOT)}
+    for fam, d in acc.items():
+        wc = d.get("SQ_WAVE_CYCLES", 0.0)
+        if not wc or not d.get("SQ_BUSY_CU_CYCLES"):
+            continue
+        out[fam] = dict(mfma_busy=d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * d["SQ_BUSY_CU_CYCLES"]),
+                        wave_cycles_waitcnt=d.get("SQ_WAIT_ANY", 0.0) / wc, wave_cycles_issue_stall=d.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                        wave_cycles_issuing=d.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                        lds_conflict_per_active=d.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, d.get("SQ_LDS_IDX_ACTIVE", 0.0)))
+    return out
 
 
 PASS_DEFAULT = {}             # workload -> scenes per sparse-network pass (measured: see DESIGN.md "Scenes per pass")
@@ -653,6 +684,9 @@ def profile_block(wl, block, name):
     block["kernels"] = kern
     block["stage_ms"] = stage
     block["conv"] = conv
+    block["pmc_sq"] = pmc_sq(name)
+    if block["pmc_sq"] and "gather_once_conv" in block["pmc_sq"]:
+        conv["mfma_busy_gather_once"] = block["pmc_sq"]["gather_once_conv"]["mfma_busy"]
     block["conv_layers"] = [dict(K=L["K"], Cin=L["Cin"], Cout=L["Cout"], rows=L["n_out"], pairs=L["pairs"], ms=round(L["ms"], 4))
                             for L in layers]
     ms_scene = block["ms_per_scene"]
@@ -737,6 +771,7 @@ def compact_line(result):
             line[k] = result[k]
     if result.get("conv"):
         line["conv_ms_per_scene"] = result["conv"].get("ms_per_scene")
+        line["conv_mfma_busy"] = result["conv"].get("mfma_busy_gather_once")
     if result.get("whole_path_hbm"):
         line["whole_path_hbm_frac"] = result["whole_path_hbm"].get("frac_of_8TBps")
     line["roofline"] = _roof(result.get("roofline"))
@@ -746,6 +781,7 @@ def compact_line(result):
         line["S"] = dict(value=s["value"], ms_per_step=s["ms_per_step"], ms_per_scene=s.get("ms_per_scene"),
                          graph_nodes_per_scene=s.get("graph_nodes_per_scene"),
                          conv_ms_per_scene=(s.get("conv") or {}).get("ms_per_scene"),
+                         conv_mfma_busy=(s.get("conv") or {}).get("mfma_busy_gather_once"),
                          roofline=_roof(s.get("roofline")), cpu_baseline=_cpu(s.get("cpu_baseline"), sample=False))
     for k in ("through_plugin", "nchw_input", "f32_conv", "train_S"):
         if result.get(k):
@@ -860,7 +896,7 @@ def main():
     if rank == 0 and not args.no_profile:
         log("per-kernel profile (eager pass)")
         result["roofline"] = profile_block(wl, main_block, args.workload)
-        for k in ("kernels", "stage_ms", "conv", "conv_layers", "algorithmic_GB_per_scene", "whole_path_hbm"):
+        for k in ("kernels", "stage_ms", "conv", "conv_layers", "algorithmic_GB_per_scene", "whole_path_hbm", "pmc_sq"):
             result[k] = main_block[k]
     Ms_full = main_block["M_selected"]
     main_layout = wl.layout
