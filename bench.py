@@ -722,6 +722,63 @@ def profile_block(wl, block, name):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] on one GPU: forward + backward + optimiser step of the detector at the ScanNet shape, bf16 autocast
+# ------------------------------------------------------------------------------------------------------------------
+def train_block(device, steps=8, warm=3):
+    """RayMarching.train_step built from projects/configs/mvsdetection/ray_marching_scannet.py's model section (2D / Atlas networks
+    not built: feature maps and TSDF are the inputs, gradients flow back into the feature maps), synthetic scene + 12 boxes, SGD;
+    the eager path (the static trace covers inference only).  Returns ms per step and scenes/s (one scene per step)."""
+    import runpy
+    import numpy as np
+    import torch
+    import projects.mvsdetection  # noqa: F401
+    from projects.mvsdetection.registry import build_model as build_registered
+    from cnrma_amd import synth
+    sc = synth.make_scene("S", seed=0)
+    C = sc["features"].shape[2]
+    cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+    m = dict(cfg["model"])
+    m.update(backbone2d=None, feature_2d=None, backbone_3d=None, tsdf_head=None, save_path="/tmp/cnrma_bench_train",
+             voxel_dim_test=list(sc["dims"]), voxel_dim_train=list(sc["dims"]), use_feature_transform=False,
+             detection_backbone=dict(type="FCAF3DBackbone", in_channels=C, depth=34))
+    torch.manual_seed(0)
+    model = build_registered(m)
+    model.detection_backbone.init_weights()
+    model.detection_head.init_weights()
+    model = model.to(device).train()
+    ext = np.array(sc["dims"], dtype=np.float32) * 0.04
+    rng = np.random.RandomState(0)
+    boxes = torch.tensor([[rng.uniform(.2, .8) * ext[0], rng.uniform(.2, .8) * ext[1], rng.uniform(0, .3) * ext[2], .8, .6, .7, 0.]
+                          for _ in range(12)], dtype=torch.float32, device=device)
+    labels = torch.from_numpy(rng.randint(0, 18, size=12)).to(device)
+    feats = sc["features"][:, 0].to(device).requires_grad_(True)
+    data = dict(features=[feats], projection=[sc["projection"][:, 0].to(device)], tsdf=sc["tsdf"].to(device),
+                offset=[torch.zeros(3, device=device)], gt_bboxes_3d=[boxes], gt_labels_3d=[labels])
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model.train_step(dict(data), None)
+        opt.zero_grad()
+        feats.grad = None
+        out["loss"].backward()
+        opt.step()
+        return out["loss"].detach()
+    for _ in range(warm):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return dict(value=1e3 / ms, unit="scenes/s", ms_per_step=ms, steps=steps, loss=float(loss), dtype="bf16 autocast (fp32 master weights)",
+                peak_memory_GiB=torch.cuda.max_memory_allocated() / 2 ** 30,
+                note="BASELINE configs[4] on ONE GPU: forward + backward (aggregation, sparse convolutions dgrad + wgrad, losses) + SGD "
+                     "step per scene at the ScanNet shape, eager path (~2 k launches per step)")
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # output: ONE stdout line of <= 4 KB (what the driver parses) + everything else in bench_detail.json beside bench.py
 # ------------------------------------------------------------------------------------------------------------------
 LINE_LIMIT = 4096
@@ -952,6 +1009,15 @@ def main():
             result["S"] = bs
             del wls
             torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_secondary and not args.through_plugin:
+        log("training step at the ScanNet shape (bf16 autocast)")
+        try:
+            result["train_S"] = train_block(device)
+            log(f"train_S: {result['train_S']['ms_per_step']:.1f} ms per step")
+        except Exception as e:                                           # noqa: BLE001 -- a secondary block must not cost the line
+            log(f"train_S failed: {e!r}")
+            result["train_S"] = None
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         name = args.workload if args.workload in ("NS", "S", "St") else "tiny"
         log("cpu baseline (oracle on the host cores)")

@@ -14,6 +14,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 
 # name -> (restype, argtypes); mirrors include/cnrma.h one to one
 SIGNATURES = {
+    "cnrma_fill_bytes_u8": (c_int, [P, I, c_size_t, P]),
     "cnrma_abi_version": (c_int, []),
     "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
     "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
@@ -51,13 +52,13 @@ SIGNATURES = {
     "cnrma_select_rows_f32": (c_int, [P, L, I, P, F, F, F, P, P, P]),
     "cnrma_voxelize_workspace_bytes": (c_size_t, [L]),
     "cnrma_voxelize_f32": (c_int, [P, P, L, P, I, F, I, I, P, P, L, P, P, P, L, P, P, P]),
-    "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, P]),
+    "cnrma_sparse_build_map": (c_int, [P, L, P, P, P, L, I, P]),
     "cnrma_sparse_stride_coords": (c_int, [P, L, P, I, P, P, L, P, L, P, P, P]),
     "cnrma_sparse_stride_coords_sorted": (c_int, [P, L, P, I, P, L, P, P, P]),
     "cnrma_sparse_kernel_map": (c_int, [P, L, P, P, P, L, P, I, P, P]),
-    "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, P]),
+    "cnrma_sparse_kernel_map_symmetric": (c_int, [P, L, P, P, P, L, P, I, P, I, P]),
     "cnrma_sparse_kernel_map_children": (c_int, [P, L, P, P, P]),
-    "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, P]),
+    "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, I, P]),
     "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
     "cnrma_sparse_conv_plan": (c_int, [L, I, I, I, I, I, c_size_t, P]),
     "cnrma_debug_conv_tuning": (c_int, [P, I]),

@@ -3615,11 +3615,13 @@ extern "C" int cnrma_voxelize_f32(const float* coords, const float* feats, int64
 }
 
 extern "C" int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, const int32_t* n_dev, uint64_t* hash_keys,
-                                      int32_t* hash_vals, int64_t hash_cap, void* stream) {
+                                      int32_t* hash_vals, int64_t hash_cap, int precleared, void* stream) {
   if (n_cap <= 0 || hash_cap < 2 || (hash_cap & (hash_cap - 1)) != 0) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  hipError_t e = cnrma_fill_bytes(hash_keys, 0xFF, (size_t)hash_cap * sizeof(uint64_t), st);
-  if (e != hipSuccess) return -(int)e;
+  if (!precleared) {                                         // precleared: the caller's arena holds 0xFF bytes already (cnrma_fill_bytes_u8)
+    hipError_t e = cnrma_fill_bytes(hash_keys, 0xFF, (size_t)hash_cap * sizeof(uint64_t), st);
+    if (e != hipSuccess) return -(int)e;
+  }
   hipLaunchKernelGGL(build_map_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, st, coords, n_cap, n_dev,
                      hash_keys, hash_vals, hash_cap);
   CNRMA_LAUNCH_CHECK();
@@ -3699,11 +3701,13 @@ extern "C" int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap
 
 extern "C" int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t n_cap, const int32_t* n_dev,
                                                  const uint64_t* hash_keys, const int32_t* hash_vals, int64_t hash_cap,
-                                                 const int32_t* offsets, int K, int32_t* nbr, void* stream) {
+                                                 const int32_t* offsets, int K, int32_t* nbr, int precleared, void* stream) {
   if (n_cap <= 0 || K <= 0 || (K & 1) == 0) return CNRMA_EINVAL;
   hipStream_t st = as_stream(stream);
-  hipError_t e = cnrma_fill_bytes(nbr, 0xFF, (size_t)n_cap * K * sizeof(int32_t), st);
-  if (e != hipSuccess) return -(int)e;
+  if (!precleared) {
+    hipError_t e = cnrma_fill_bytes(nbr, 0xFF, (size_t)n_cap * K * sizeof(int32_t), st);
+    if (e != hipSuccess) return -(int)e;
+  }
   hipLaunchKernelGGL(kernel_map_symmetric_kernel, dim3((unsigned)ceil_div(n_cap * (K / 2 + 1), 256)), dim3(256), 0, st,
                      coords, n_cap, n_dev, hash_keys, hash_vals, hash_cap, offsets, K, nbr);
   CNRMA_LAUNCH_CHECK();
@@ -3743,12 +3747,14 @@ extern "C" int cnrma_sparse_kernel_map_children(const int32_t* parent_nbr, int64
 extern "C" int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev,
                                                int in_stride, int kernel_size, const uint64_t* out_hash_keys,
                                                const int32_t* out_hash_vals, int64_t hash_cap, int32_t* nbr,
-                                               int64_t no_cap, void* stream) {
+                                               int64_t no_cap, int precleared, void* stream) {
   if (n_cap <= 0 || no_cap <= 0 || in_stride <= 0 || kernel_size < 1 || kernel_size > 3) return CNRMA_EINVAL;
   const int K = kernel_size * kernel_size * kernel_size;
   hipStream_t st = as_stream(stream);
-  hipError_t e = cnrma_fill_bytes(nbr, 0xFF, (size_t)no_cap * K * sizeof(int32_t), st);
-  if (e != hipSuccess) return -(int)e;
+  if (!precleared) {
+    hipError_t e = cnrma_fill_bytes(nbr, 0xFF, (size_t)no_cap * K * sizeof(int32_t), st);
+    if (e != hipSuccess) return -(int)e;
+  }
   hipLaunchKernelGGL(kernel_map_strided_kernel, dim3((unsigned)ceil_div(n_cap, 256)), dim3(256), 0, st, in_coords,
                      n_cap, n_dev, in_stride, kernel_size, out_hash_keys, out_hash_vals, hash_cap, nbr);
   CNRMA_LAUNCH_CHECK();

@@ -4,6 +4,13 @@
 
 extern "C" int cnrma_abi_version(void) { return CNRMA_ABI_VERSION; }
 
+extern "C" int cnrma_fill_bytes_u8(void* dst, int byte, size_t n_bytes, void* stream) {
+  if (dst == nullptr || (n_bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(dst) & 3) != 0) return CNRMA_EINVAL;
+  if (n_bytes == 0) return 0;
+  const hipError_t e = cnrma_fill_bytes(dst, byte, n_bytes, reinterpret_cast<hipStream_t>(stream));
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 namespace {
 
 constexpr int SCAN_BLOCK = 256;

@@ -45,6 +45,9 @@ def _round_up(n, q):
     return (n + q - 1) // q * q
 
 
+ARENA = True      # static traces clear ONE 0xFF arena per scene instead of one table at a time (False: A/B, tests)
+
+
 class Plan:
     def __init__(self, margin=1.2, slack=256):
         self.margin, self.slack = float(margin), int(slack)
@@ -64,6 +67,13 @@ class Plan:
         self._i = self._j = self._c = 0
         self._watch = []
         self._amax = None
+        # 0xFF arena of the static trace (hash tables, neighbour tables): the first static run of a plan sizes it (its tables
+        # are allocated and cleared one by one), every later run -- the captured one -- takes its tables from ONE buffer that
+        # is cleared by one launch at its first use
+        if getattr(self, "static", False) and getattr(self, "_arena_need", 0) > 0 and getattr(self, "_arena", None) is None:
+            self._arena = torch.empty(self._arena_need, dtype=torch.uint8, device=self._arena_dev)
+        self._arena_off = 0
+        self._arena_filled = False
 
     # ---- recording (eager calibration run) --------------------------------------------------------------------------
     def record(self, n):
@@ -156,6 +166,26 @@ class Plan:
             buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
             self.workspaces[device] = buf
         return buf
+
+    def arena_ff(self, nbytes, device):
+        """static trace only: `nbytes` of device memory that hold 0xFF when the caller's kernel runs, or None when the caller has
+        to allocate and clear by itself (calibration / eager runs; the first static run, which only sizes the arena)"""
+        if not self.static or not ARENA:
+            return None
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        if getattr(self, "_arena", None) is None:
+            self._arena_need = getattr(self, "_arena_need", 0) + nbytes
+            self._arena_dev = device
+            return None
+        if self._arena_off + nbytes > self._arena.numel():          # a trace that asks for more than it did when it was sized
+            return None
+        if not self._arena_filled:
+            from . import _lib
+            _lib.call("cnrma_fill_bytes_u8", _lib.ptr(self._arena), 0xFF, self._arena.numel(), _lib.stream())
+            self._arena_filled = True
+        view = self._arena[self._arena_off:self._arena_off + nbytes]
+        self._arena_off += nbytes
+        return view
 
     def counters(self, device, words):
         """zeroed 32-bit words for kernels that count arrivals and leave them zero again (one buffer per plan: the launches

@@ -48,9 +48,14 @@ def kernel_offsets(kernel_size, tensor_stride):
 class CoordMap:
     """Open-addressing hash table on the device: uint64 key -> int32 row."""
 
-    def __init__(self, n, device):
+    def __init__(self, n, device, arena=False):
+        """arena: take the keys from the static trace's pre-cleared 0xFF arena when there is one (self.precleared)"""
         self.cap = _next_pow2(max(2 * n, 16))
-        self.keys = torch.empty(self.cap, dtype=torch.int64, device=device)   # reinterpreted as uint64
+        plan = P.current() if arena else None
+        a = plan.arena_ff(self.cap * 8, device) if plan is not None else None
+        self.precleared = a is not None
+        self.keys = a[:self.cap * 8].view(torch.int64) if a is not None else \
+            torch.empty(self.cap, dtype=torch.int64, device=device)            # reinterpreted as uint64
         self.vals = torch.empty(self.cap, dtype=torch.int32, device=device)
 
 
@@ -144,8 +149,9 @@ class CoordSet:
     @property
     def cmap(self):
         if self._map is None:
-            m = CoordMap(self.n, self.device)
-            call("cnrma_sparse_build_map", ptr(self.C), self.n, ptr(self.n_dev), ptr(m.keys), ptr(m.vals), m.cap, stream())
+            m = CoordMap(self.n, self.device, arena=True)
+            call("cnrma_sparse_build_map", ptr(self.C), self.n, ptr(self.n_dev), ptr(m.keys), ptr(m.vals), m.cap, int(m.precleared),
+                 stream())
             self._map = m
         return self._map
 
@@ -229,9 +235,17 @@ class CoordSet:
         if key not in self._nbr:
             offs = _offsets_tensor(kernel_size, offset_stride, self.device)
             K = offs.shape[0]
-            nbr = torch.empty((out_set.n, K), dtype=torch.int32, device=self.device)
             strided = out_set is not self and out_set.stride == 2 * self.stride and offset_stride == self.stride
             par = self._gen_parent
+            # tables that their builder pre-fills with -1 come from the static trace's pre-cleared arena when there is one
+            prefilled = method == "auto" and out_set.n > 0 and self.n > 0 and not (
+                out_set is self and kernel_size == 3 and par is not None and offset_stride == self.stride and self.n == 8 * par.n) and (
+                (out_set is self and kernel_size % 2 == 1 and kernel_size > 1) or (strided and kernel_size in (1, 2, 3)))
+            plan = P.current()
+            a = plan.arena_ff(out_set.n * K * 4, self.device) if (prefilled and plan is not None) else None
+            nbr = a[:out_set.n * K * 4].view(torch.int32).view(out_set.n, K) if a is not None else \
+                torch.empty((out_set.n, K), dtype=torch.int32, device=self.device)
+            pre = int(a is not None)
             if out_set.n == 0 or self.n == 0:
                 nbr.fill_(-1)
             elif method == "auto" and out_set is self and kernel_size == 3 and par is not None and \
@@ -242,11 +256,11 @@ class CoordSet:
             elif method == "auto" and out_set is self and kernel_size % 2 == 1 and kernel_size > 1:
                 m = self.cmap
                 call("cnrma_sparse_kernel_map_symmetric", ptr(self.C), self.n, ptr(self.n_dev), ptr(m.keys), ptr(m.vals), m.cap,
-                     ptr(offs), K, ptr(nbr), stream())
+                     ptr(offs), K, ptr(nbr), pre, stream())
             elif method == "auto" and strided and kernel_size in (1, 2, 3):
                 m = out_set.cmap
                 call("cnrma_sparse_kernel_map_strided", ptr(self.C), self.n, ptr(self.n_dev), self.stride, kernel_size,
-                     ptr(m.keys), ptr(m.vals), m.cap, ptr(nbr), out_set.n, stream())
+                     ptr(m.keys), ptr(m.vals), m.cap, ptr(nbr), out_set.n, pre, stream())
             else:
                 m = self.cmap
                 call("cnrma_sparse_kernel_map", ptr(out_set.C), out_set.n, ptr(out_set.n_dev), ptr(m.keys), ptr(m.vals), m.cap,
@@ -1165,15 +1179,28 @@ def union_add(a, b):
     assert a.cs.stride == b.cs.stride and a.F.shape[1] == b.F.shape[1]
     if a.cs is b.cs:
         return SparseTensor(a.F + b.F, a.cs)
-    if b.cs.n > a.cs.n:
-        # the result keeps the first operand's rows and appends the other's new ones: start from the larger set (in the neck
-        # the generated children, whole 8-blocks) so that the appended tail -- thin, without locality -- stays short.  The
-        # reference's row order is a hash map's; the sum is commutative, bit for bit.
+    # the result keeps the first operand's rows and appends the other's new ones: start from the generated children (the neck:
+    # whole 8-blocks in Morton order), else from the larger set, so that the appended tail -- thin, without locality -- stays
+    # short.  The reference's row order is a hash map's; the sum is commutative, bit for bit.  The choice must be the SAME in
+    # the eager run and in the static trace of a scene (row order feeds the top-k tie-break): `cs.n` is a live count in one and
+    # a capacity in the other, so the size comparison is a recorded branch of the plan.
+    gen_a, gen_b = a.cs._gen_parent is not None, b.cs._gen_parent is not None
+    if gen_a != gen_b:
+        swap = gen_b
+    else:
+        plan = P.current()
+        if plan is not None and plan.static:
+            swap = bool(plan.next_flag())                    # None (calibration scenes disagreed) -> keep the operand order
+        else:
+            swap = b.cs.n > a.cs.n
+            if plan is not None:
+                plan.record_flag(swap)
+    if swap:
         a, b = b, a
     na, nb, C = a.cs.n, b.cs.n, a.F.shape[1]
     dev = a.device
-    m = CoordMap(na + nb, dev)
-    call("cnrma_sparse_build_map", ptr(a.C), na, ptr(a.cs.n_dev), ptr(m.keys), ptr(m.vals), m.cap, stream())
+    m = CoordMap(na + nb, dev, arena=True)
+    call("cnrma_sparse_build_map", ptr(a.C), na, ptr(a.cs.n_dev), ptr(m.keys), ptr(m.vals), m.cap, int(m.precleared), stream())
     out_c = torch.empty((na + nb, 4), dtype=torch.int32, device=dev)
     out_f = torch.empty((na + nb, C), dtype=torch.float32, device=dev)
     n_out = torch.empty(1, dtype=torch.int32, device=dev)

@@ -30,6 +30,12 @@ extern "C" {
 
 int cnrma_abi_version(void);
 
+/* A kernel launch that sets n_bytes (a multiple of 4, 4-byte aligned) to `byte` -- unlike a hipMemsetAsync node it re-executes
+ * reliably when a captured graph is replayed.  The static trace clears ONE arena per scene with it (all hash tables and
+ * neighbour tables of the scene: 0xFF = empty slot / no neighbour) and passes precleared = 1 to the builders below, which
+ * then skip their own clearing launch (27 launches per scene). */
+int cnrma_fill_bytes_u8(void* dst, int byte, size_t n_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * layout helper: feat_nchw[V][C][H][W] -> feat_nhwc[V][H][W][C]
  * (the reference keeps NCHW: projects/mvsdetection/models/ray_marching.py:64 and :799 gather [b,:,py,px])
@@ -285,7 +291,8 @@ int cnrma_voxelize_f32(const float* coords, const float* feats, int64_t M, const
 
 /* coordinate map: build a hash table key(coords[i]) -> i for N unique coordinates */
 int cnrma_sparse_build_map(const int32_t* coords, int64_t n_cap, const int32_t* n_dev, uint64_t* hash_keys,
-                           int32_t* hash_vals, int64_t hash_cap, void* stream);
+                           int32_t* hash_vals, int64_t hash_cap, int precleared /* hash_keys already hold 0xFF bytes */,
+                           void* stream);
 
 /* strided output coordinate set: unique(floor(p / new_stride) * new_stride) in first-occurrence order
  * (MinkowskiConvolution / MinkowskiMaxPooling with stride 2: fcaf3d_backbone.py:26-31, BasicBlock stride 2).
@@ -314,10 +321,11 @@ int cnrma_sparse_kernel_map(const int32_t* out_coords, int64_t no_cap, const int
  *             output); probes go to the OUTPUT set's map.  in_stride = tensor stride of the input. */
 int cnrma_sparse_kernel_map_symmetric(const int32_t* coords, int64_t n_cap, const int32_t* n_dev,
                                       const uint64_t* hash_keys, const int32_t* hash_vals, int64_t hash_cap,
-                                      const int32_t* offsets, int K, int32_t* nbr, void* stream);
+                                      const int32_t* offsets, int K, int32_t* nbr, int precleared /* nbr holds 0xFF bytes */,
+                                      void* stream);
 int cnrma_sparse_kernel_map_strided(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int in_stride,
                                     int kernel_size, const uint64_t* out_hash_keys, const int32_t* out_hash_vals,
-                                    int64_t hash_cap, int32_t* nbr, int64_t no_cap, void* stream);
+                                    int64_t hash_cap, int32_t* nbr, int64_t no_cap, int precleared, void* stream);
 /* _children: the 3x3x3 stride-1 table of the set cnrma_sparse_convtr_gen_* generates (fcaf3d_head.py:61-70 up blocks: all 8
  *             children of every parent, child m of parent p at row 8 p + m) from the PARENTS' 3x3x3 table parent_nbr
  *             [np_cap][27]: nbr[8 p + m][k] = 8 * parent_nbr[p][k'] + m' with (k', m') the parent offset / child rank of
