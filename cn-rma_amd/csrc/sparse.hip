@@ -951,6 +951,7 @@ template <int N, int NT> struct AStageRegs<false, N, NT> {        // fp32 featur
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // first-class vector: stays in VGPRs across the loop
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int N, int NT> struct AStageRegs<true, N, NT> {         // pre-split companion: (row, 8 channels) per task, 3 x 16 B
   u32x4_t h[N], m[N], l[N];
@@ -2757,7 +2758,6 @@ __global__ __launch_bounds__(256) void prep_weights_f32_frag_kernel(const float*
   }
 }
 
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <int WAVES_N, int KS, bool HAS_RES>
 __global__ __launch_bounds__(256, 4) void sparse_conv_gof_kernel(ConvArgs p, GoArgs g, const float* __restrict__ wfrag, Go2Map mp) {
@@ -2989,6 +2989,382 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_gof_kernel(ConvArgs p, GoA
         if (col_ok && row < n_live) p.out[row * Cout + col] = v;
       }
     }
+  }
+}
+
+// ================================================================================================================
+// Gather-once convolution, third form (round 5, sparse.conv_tuning(go=2)): persistent blocks, two union images, the next
+// stage's gather under the current stage's MFMAs.
+// The second form's blocks still spend more than half of their life outside the offset loops (stamps: header + first barrier,
+// two gathers, the barrier between the slices, merge + epilogue), and inside them a wave alone reaches ~46 % of the matrix
+// pipe's rate (every MFMA group waits for its own LDS round trip); four blocks per CU average that out to an MFMA-busy
+// fraction of 0.54-0.58 (profiles/r05_*_pmc_SQ.csv).  This form spends the LDS of a CU on TWO blocks with two images each, and
+// the registers that frees on deeper software pipelines:
+//   * a block is persistent: it walks its share of the (row tile, column / split group) items; a *stage* = one (item,
+//     32-channel slice, offset group).  While the offsets of stage s run from image s % 2, the union rows of stage s + 1 are
+//     fetched and split into image (s + 1) % 2 by the same waves: per offset step a thread issues one 16-byte row load (inline
+//     asm, like the weight loads) and finishes the load issued three steps earlier (split to two fp16 planes, two ds_write).
+//     The vector-memory issue pattern of a step is constant -- four weight loads, then one row load, dummies behind the last
+//     real one -- so the waits are counted: vmcnt(6) before a step's weights, vmcnt(15) before the row load three steps old;
+//   * the metadata of the next item (header, local indices, the row numbers of its first offset group) is requested behind the
+//     first barrier of an item's first stage and parked in LDS behind that stage's offsets, so that the item's LAST stage can
+//     already gather the next item's first image; items with one stage only (single-slice splits) and offset groups other
+//     than the first fall back to a gather in front of their stage, as in the second form;
+//   * the A fragments of a whole offset are read one offset ahead (two register sets): the MFMAs of an offset never wait for LDS.
+// Same sums in the same order as the other two forms (bit-identical: the test).
+// ================================================================================================================
+struct Go3Map { int tiles, ncol, ng, n_items, per_xcd, bpx; };   // item = tile * ng + group; XCD x owns items [x per_xcd, (x + 1) per_xcd)
+constexpr int GO3_RS = 288;                                       // row numbers parked per tile (>= GO_UMAX, two 256-thread loads)
+constexpr int GO3_IMG = 2 * GO2_US * 2;                           // bytes of one image (two planes)
+constexpr int GO3_LDS = 2 * GO3_IMG + 2 * (GO_BM * 27 * 2) + 2 * (GO3_RS * 4);
+static_assert(2 * GO3_LDS <= 160 * 1024 && GO_UMAX <= GO3_RS, "two blocks per CU");
+
+// one 16-byte row load: SGPR base (the feature tensor) + 32-bit byte offset per lane
+__device__ __forceinline__ void go_load_row(f32x4_t& d, const float* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
+}
+
+template <int WAVES_N, int KS, bool HAS_RES>
+__global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag, Go3Map mp) {
+  static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
+  constexpr int TM = 2, BN = 32 * WAVES_N, NB = 2, RD = 4;   // weight sets in flight; row-load ring (a load is finished 3 steps later)
+  extern __shared__ __attribute__((aligned(16))) unsigned char go3_smem[];
+  auto Us = [&](int b) { return reinterpret_cast<__bf16*>(go3_smem + (size_t)b * GO3_IMG); };
+  auto Ls = [&](int b) { return reinterpret_cast<uint16_t*>(go3_smem + 2 * GO3_IMG + (size_t)b * (GO_BM * 27 * 2)); };
+  auto Rs = [&](int b) { return reinterpret_cast<int32_t*>(go3_smem + 2 * GO3_IMG + 2 * (GO_BM * 27 * 2) + (size_t)b * (GO3_RS * 4)); };
+  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
+  const int Cin = p.Cin, Cout = p.Cout;
+  const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wid / WAVES_N, wc = wid % WAVES_N;
+  const int fhalf = lane >> 5;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const float a_scale = f16_scale_for(read_amax(p.in_amax));
+  const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
+  // ---- this block's items
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int it_end = min(mp.n_items, (xcd + 1) * mp.per_xcd);
+  int it = xcd * mp.per_xcd + jb;
+  auto live_item = [&](int i) { return i < it_end && (int64_t)(i / mp.ng) * GO_BM < n_live; };
+  if (!live_item(it)) return;                                // items are in tile order: behind a dead tile nothing is alive
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+    if (tid < 16) {                                          // the zero row of both planes of both images
+      reinterpret_cast<uint32_t*>(Us(b) + GO_UMAX * LDK)[tid] = 0u;
+      reinterpret_cast<uint32_t*>(Us(b) + GO2_US + GO_UMAX * LDK)[tid] = 0u;
+    }
+  // ---- metadata of the first item, waited for (every later item's arrives under the stages of the item before it)
+  int buf = 0;                                               // Ls / Rs buffer of the current item
+  int4 h0;
+  {
+    const int64_t tile = it / mp.ng;
+    h0 = *reinterpret_cast<const int4*>(g.hdr + tile * GO_HDR);
+    if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls(0))[tid] = reinterpret_cast<const uint4*>(g.lidx + tile * (GO_BM * 27))[tid];
+    const int32_t* tr = g.rows + tile * GO_ROWS;
+    Rs(0)[tid] = tr[tid];
+    if (tid < GO3_RS - 256) Rs(0)[256 + tid] = tr[256 + tid];
+  }
+  int img = 0;                                               // image of the next stage to run
+  bool have_img = false;                                     // ... already gathered by the stage before it
+  float mx = 0.0f;
+
+  auto load_b = [&](u32x4_t (&bf)[2][2], int k, int slice, int cout0) {
+    const uint64_t ba = reinterpret_cast<uint64_t>(wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc) * 2048);
+    const uint16_t* base = reinterpret_cast<const uint16_t*>(
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ba));
+    go_load_frag(bf, base, lane16);
+  };
+  // a gather that is waited for: union rows [q0 * 256 / 8 ..) of `un` (row numbers from `rows`, LDS or memory) into image `dst`
+  auto gather_now = [&](__bf16* dst, const int32_t* rows, int un, int cin0, int q0) {
+    const int tasks = un * 8;
+    for (int t0 = q0 * 256; t0 < tasks; t0 += 256 * 4) {
+      float4 v[4];
+      int32_t src[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tk = t0 + i * 256 + tid;
+        src[i] = rows[tk < tasks ? (tk >> 3) : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (tid & 7) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tk = t0 + i * 256 + tid;
+        const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tid & 7;
+        uint2 h, m;
+        split2(v[i], a_scale, h, m);
+        __bf16* d = dst + lds_slot(u, kc >> 1) + (kc & 1) * 4;
+        *reinterpret_cast<uint2*>(d) = h;
+        *reinterpret_cast<uint2*>(d + GO2_US) = m;
+      }
+    }
+  };
+
+  for (;;) {                                                 // ---- items
+    const int64_t tile = it / mp.ng, tile0 = tile * GO_BM;
+    const int grp = it % mp.ng;
+    const int cout0 = (grp % mp.ncol) * BN, zs = grp / mp.ncol;
+    const int32_t* th = g.hdr + tile * GO_HDR;
+    const int32_t* tr = g.rows + tile * GO_ROWS;
+    const int n_groups = __builtin_amdgcn_readfirstlane(h0.x);
+    int s_lo = 0, s_hi = ns;
+    if (p.splits > 1) { s_lo = zs * g.slices_per_split; s_hi = min(ns, s_lo + g.slices_per_split); }
+    const int n_stages = (s_hi - s_lo) * n_groups;
+    const int col = cout0 + wc * 32 + (lane & 31);
+    const bool col_ok = col < Cout;
+    const int colc = col_ok ? col : 0;
+    const bool use_scale = p.scale != nullptr && p.splits == 1, use_shift = p.shift != nullptr && p.splits == 1;
+    const float sc = use_scale ? p.scale[colc] : 1.0f;
+    const float sh = use_shift ? p.shift[colc] : 0.0f;
+    const uint16_t* ls0 = Ls(buf) + (lane & 31) * 27;
+    // the next item; its metadata is requested in this item's first stage and parked in the other Ls / Rs buffer behind it
+    const int it2 = it + mp.bpx;
+    const bool more = live_item(it2);
+    const int64_t tile2 = more ? it2 / mp.ng : tile;
+    int s_lo2 = 0;
+    if (p.splits > 1) s_lo2 = ((it2 % mp.ng) / mp.ncol) * g.slices_per_split;
+    int4 h0n = h0;
+    uint4 lvn = make_uint4(0u, 0u, 0u, 0u);
+    int32_t rn0 = 0, rn1 = 0;
+    bool meta_parked = !more;
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+
+    int stage = 0;
+    for (int slice = s_lo; slice < s_hi; ++slice) {
+      const int cin0 = slice * BK;
+      for (int grpi = 0; grpi < n_groups; ++grpi, ++stage) {
+        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(grpi == 0 ? h0.y : th[1 + 3 * grpi]);
+        const int ub = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.z : th[2 + 3 * grpi]);
+        const int un = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.w : th[3 + 3 * grpi]);
+        unsigned mymask = mask;
+        if constexpr (KS == 2) {                             // every second offset of the group
+          mymask = 0;
+          unsigned m = mask;
+          int r = 0;
+          while (m) {
+            const unsigned low = m & (0u - m);
+            if ((r & 1) == kg) mymask |= low;
+            m ^= low;
+            ++r;
+          }
+        }
+        u32x4_t bf[NB][2][2];
+        int kk[NB];
+        unsigned rest = mymask;
+        const int n_off = __popc(mymask);
+        int k_last = 0;
+        auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
+        // prime the issue pattern of the steps -- four weight loads, one row load -- so that their counted waits hold from the
+        // first step on (the two row loads are dummies into ring slots that are waited for before they are reused)
+        f32x4_t ring[RD];
+        static_assert(NB == 2 && RD == 4, "priming order below");
+        kk[0] = pop(); load_b(bf[0], kk[0], slice, cout0);
+        go_load_row(ring[2], p.in, (unsigned)(tid & 7) * 16u);
+        kk[1] = pop(); load_b(bf[1], kk[1], slice, cout0);
+        go_load_row(ring[3], p.in, (unsigned)(tid & 7) * 16u);
+        __bf16* const U = Us(img);
+        if (!have_img) {                                     // nobody gathered this stage's image ahead of time
+          __syncthreads();                                   // (the image's previous readers are done)
+          if (grpi == 0) gather_now(U, Rs(buf), un, cin0, 0);
+          else gather_now(U, tr + ub, un, cin0, 0);
+        }
+        __syncthreads();
+        const bool park_here = !meta_parked;                 // this item's first stage: ask for the next item's metadata now
+        if (park_here) {
+          h0n = *reinterpret_cast<const int4*>(g.hdr + tile2 * GO_HDR);
+          if (tid < GO_BM * 27 / 8) lvn = reinterpret_cast<const uint4*>(g.lidx + tile2 * (GO_BM * 27))[tid];
+          const int32_t* tr2 = g.rows + tile2 * GO_ROWS;
+          rn0 = tr2[tid];
+          if (tid < GO3_RS - 256) rn1 = tr2[256 + tid];
+        }
+        // ---- what this stage gathers for its successor: the next slice's first group of this item, or -- on the item's last
+        // stage, with the next item's metadata parked -- the next item's first stage
+        const bool last_stage = stage == n_stages - 1;
+        bool ahead = false;
+        const int32_t* rows_n = Rs(buf);
+        int un_n = 0, cin0_n = 0;
+        if (!last_stage) {
+          if (grpi == n_groups - 1) { ahead = true; un_n = __builtin_amdgcn_readfirstlane(h0.w); cin0_n = (slice + 1) * BK; }
+        } else if (more && meta_parked) {
+          ahead = true; rows_n = Rs(buf ^ 1); un_n = __builtin_amdgcn_readfirstlane(h0n.w); cin0_n = s_lo2 * BK;
+        }
+        __bf16* const Un = Us(img ^ 1);
+        const int tasks_n = ahead ? un_n * 8 : 0;
+        const int nq = (tasks_n + 255) >> 8;                 // row loads per thread of the successor's gather
+        const unsigned kc16 = (unsigned)(tid & 7) * 16u + (unsigned)cin0_n * 4u;
+        auto g_issue = [&](f32x4_t& dreg, int q) {           // task q of this thread (a dummy behind the last: row 0, dump row)
+          const int tk = q * 256 + tid;
+          const bool real = q < nq && tk < tasks_n;
+          const int32_t srow = real ? rows_n[tk >> 3] : 0;
+          go_load_row(dreg, p.in, (unsigned)srow * (unsigned)(Cin * 4) + kc16);
+        };
+        auto g_finish = [&](const f32x4_t& dreg, int q) {
+          const int tk = q * 256 + tid;
+          const int u = (q >= 0 && q < nq && tk < tasks_n) ? (tk >> 3) : GO_UMAX + 1, kc = tid & 7;
+          uint2 h, m;
+          split2(make_float4(dreg[0], dreg[1], dreg[2], dreg[3]), a_scale, h, m);
+          __bf16* d = Un + lds_slot(u, kc >> 1) + (kc & 1) * 4;
+          *reinterpret_cast<uint2*>(d) = h;
+          *reinterpret_cast<uint2*>(d + GO2_US) = m;
+        };
+        // ---- the offsets: A fragments of offset j + 1 are read while offset j multiplies
+        auto load_li = [&](int (&li)[TM], int k) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) li[a] = ls0[a * (32 * 27) + k];
+        };
+        f16x8_t A[2][TM][2][2];                                // [set][row tile][plane][k-step]
+        auto read_a = [&](f16x8_t (&dst)[TM][2][2], const int (&li)[TM]) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks)
+                dst[a][pl][ks] = *reinterpret_cast<const f16x8_t*>(U + pl * GO2_US + lds_slot(li[a], ks * 2 + fhalf));
+        };
+        auto mfma_k = [&](const u32x4_t (&b)[2][2], const f16x8_t (&fa)[TM][2][2]) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const f16x8_t bh = __builtin_bit_cast(f16x8_t, b[0][ks]), bm = __builtin_bit_cast(f16x8_t, b[1][ks]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+              acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a][1][ks], bh, acc[a], 0, 0, 0);       // m*h
+              acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a][0][ks], bm, acc[a], 0, 0, 0);       // h*m
+              acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a][0][ks], bh, acc[a], 0, 0, 0);       // h*h
+            }
+          }
+        };
+        int li[TM];
+        load_li(li, kk[0]);
+        read_a(A[0], li);
+        load_li(li, kk[1]);                                  // the second offset (the first again when there is only one)
+        // one step = one offset.  t: index of the step inside the stage (ring / set indices are t % 4, t % 2: the steps run in
+        // turns of RD so that they are compile-time constants)
+        auto step = [&](int j, int t) {
+          go_waitn<(NB - 1) * 5 + 1>(bf[j % NB]);            // this step's weights have landed; newer: 1 row load + the step before's 5
+          read_a(A[(j + 1) & 1], li);                        // fragments of the next offset
+          mfma_k(bf[j % NB], A[j & 1]);
+          kk[j % NB] = pop();                                // two offsets ahead (behind the last offset: the last one again)
+          load_li(li, kk[j % NB]);                           // ... its local indices are turned into fragment reads one step later
+          load_b(bf[j % NB], kk[j % NB], slice, cout0);
+          g_issue(ring[j], t);
+          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[(j + 1) % RD]) : "n"((RD - 1) * 5));   // the row load RD - 1 steps old
+          g_finish(ring[(j + 1) % RD], t - (RD - 1));
+        };
+        int i = 0;
+        for (; i + RD <= n_off; i += RD) {
+#pragma unroll
+          for (int j = 0; j < RD; ++j) step(j, i + j);
+        }
+#pragma unroll
+        for (int j = 0; j < RD - 1; ++j)
+          if (i + j < n_off) step(j, i + j);
+        // ---- nothing may stay in flight (the asm loads are invisible to the compiler); then the row loads not yet finished
+        // (the last RD - 1 issued) and the ones never issued (more tasks than offsets), without overlap
+#pragma unroll
+        for (int j = 0; j < NB; ++j) go_drain(bf[j]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]));
+#pragma unroll
+        for (int jj = 0; jj < RD; ++jj) {
+          const int q = (n_off - 1) - (((n_off - 1 - jj) % RD + RD) % RD);      // the newest issued task that sits in ring[jj]
+          if (n_off > 0 && q >= 0 && q >= n_off - (RD - 1)) g_finish(ring[jj], q);
+        }
+        if (ahead && n_off < nq) gather_now(Un, rows_n, un_n, cin0_n, n_off);
+        if (park_here) {                                     // the next item's metadata has landed: park it
+          if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls(buf ^ 1))[tid] = lvn;
+          Rs(buf ^ 1)[tid] = rn0;
+          if (tid < GO3_RS - 256) Rs(buf ^ 1)[256 + tid] = rn1;
+          meta_parked = true;
+        }
+        have_img = ahead;
+        img ^= 1;
+      }
+    }
+
+    // ---- the item's tile is complete: merge (KS = 2), epilogue.  The image just used is free; the other one may already
+    // hold the next item's first stage.
+    unsigned char* const scratch = reinterpret_cast<unsigned char*>(Us(img ^ 1));
+    if constexpr (KS == 2) {
+      __syncthreads();
+      float* X = reinterpret_cast<float*>(scratch);          // 4 x 4 KB
+      float* mine = X + (wc * 2 + kg) * 1024;
+      const float* theirs = X + (wc * 2 + (kg ^ 1)) * 1024;
+      if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[1][i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[0][i];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] += theirs[i * 64 + lane];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[1][i] += theirs[i * 64 + lane];
+      }
+    }
+    if (p.splits > 1) {                                      // partial tile into this split's slab; conv_reduce_kernel follows
+      float* slab = p.slab + (int64_t)zs * p.no_cap * Cout;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if (KS == 2 && a != kg) continue;
+        const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
+          if (col_ok && row < n_live) slab[row * Cout + col] = acc[a][i] * out_scale;
+        }
+      }
+    } else {
+      const int act = p.act;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if (KS == 2 && a != kg) continue;
+        const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float res[4];
+          if (HAS_RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int64_t row = row0 + q + 8 * rg;
+              const int64_t rc = row < n_live ? row : n_live - 1;
+              res[q] = p.residual[rc * Cout + colc];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t row = row0 + q + 8 * rg;
+            float v = acc[a][rg * 4 + q];
+            v = v * out_scale;
+            v = v * sc;
+            v = v + sh;
+            if (HAS_RES) v = v + res[q];
+            v = apply_act(v, act);
+            if (col_ok && row < n_live) {
+              p.out[row * Cout + col] = v;
+              mx = fmaxf(mx, fabsf(v));
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+    it = it2;
+    h0 = h0n;
+    buf ^= 1;
+  }
+  if (p.out_amax != nullptr && p.splits == 1) {
+    __syncthreads();
+    block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(go3_smem));
   }
 }
 
@@ -4209,13 +4585,51 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
   return 0;
 }
 
+// third form (experimental until measured everywhere): persistent grid, two blocks per CU
+template <int WAVES_N, int KS, bool HAS_RES>
+static int launch_go3_one(unsigned blocks, const ConvArgs& p, const GoArgs& g, const uint16_t* wfrag, const Go3Map& mp, hipStream_t st) {
+  auto kernel = sparse_conv_go3_kernel<WAVES_N, KS, HAS_RES>;
+  static bool raised = false;               // per instantiation: dynamic LDS above the 64-KB default
+  if (!raised) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GO3_LDS);
+    if (e != hipSuccess) return -(int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), GO3_LDS, st, p, g, wfrag, mp);
+  return 0;
+}
+
+static int launch_go3(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, hipStream_t st) {
+  Go3Map mp;
+  mp.tiles = pl.mp.tiles; mp.ncol = pl.mp.ncol; mp.ng = pl.mp.ng;
+  mp.n_items = mp.tiles * mp.ng;
+  mp.per_xcd = (int)ceil_div(mp.n_items, 8);
+  mp.bpx = mp.per_xcd < 64 ? mp.per_xcd : 64;               // 2 blocks x 32 CUs per XCD
+  g.slices_per_split = pl.slices_per_split;
+  p.splits = pl.splits;
+  g.counters = nullptr;
+  const unsigned blocks = 8u * (unsigned)mp.bpx;
+  const bool has_res = residual && pl.splits == 1;
+  int rc;
+  if (pl.bn == 128) rc = has_res ? launch_go3_one<4, 1, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<4, 1, false>(blocks, p, g, wfrag, mp, st);
+  else rc = has_res ? launch_go3_one<2, 2, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<2, 2, false>(blocks, p, g, wfrag, mp, st);
+  if (rc != 0) return rc;
+  if (pl.splits > 1) {
+    int64_t rb = ceil_div(p.no_cap * p.Cout / 4 + 1, 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
+  }
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size_t workspace_bytes, int has_residual, int* out8) {
   // what cnrma_sparse_conv_go_f16x3 launches for these sizes: out8 = {form (0 first, 1 second), tile columns (64: the four waves
   // are 2 column tiles x 2 offset halves, 128: 4 column tiles), splits over channel slices, slices per split, work order (0
   // plain, 1 groups -> XCDs, 2 tiles -> XCDs), residual fused in the kernel (0: in conv_reduce_kernel), blocks, weight offsets in flight}
   if (out8 == nullptr || no_cap <= 0 || Cin <= 0 || Cin % BK != 0 || Cout < 64) return CNRMA_EINVAL;
   const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace_bytes > 0, workspace_bytes);
-  out8[0] = pl.form >= 1 ? 1 : 0; out8[1] = pl.bn; out8[2] = pl.splits; out8[3] = pl.slices_per_split;
+  out8[0] = pl.form >= 2 ? 2 : (pl.form >= 1 ? 1 : 0); out8[1] = pl.bn; out8[2] = pl.splits; out8[3] = pl.slices_per_split;
   out8[4] = pl.form >= 1 ? pl.mode : 0; out8[5] = has_residual && pl.splits == 1; out8[6] = (int)pl.blocks; out8[7] = pl.nb;
   return 0;
 }
@@ -4345,6 +4759,8 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   {
     const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace != nullptr, workspace_bytes);
     // the other ablation masks (diagnostic kernels with phases switched off) exist in the first form only
+    if (pl.form >= 2 && g_conv_tune.ablate == 0 && (uint64_t)no_cap * (uint64_t)Cin * 4u < (1ull << 32))
+      return launch_go3(pl, p, g, wfrag, residual != nullptr, st);
     if (pl.form >= 1 && (g_conv_tune.ablate & ~64) == 0)
       return launch_go2(pl, p, g, wfrag, residual != nullptr, (g_conv_tune.ablate & 64) ? tile_counters : nullptr, st);
   }

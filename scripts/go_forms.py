@@ -54,7 +54,10 @@ def timed(c):
 
 
 VARIANTS = [("f1", dict(go=0)), ("f2x0", dict(go=1, xcd=0)), ("f2x1", dict(go=1, xcd=1)), ("f2x2", dict(go=1, xcd=2)),
-            ("f2", dict(go=1)), ("f2b4", dict(go=1, nb=4))]
+            ("f2", dict(go=1)), ("f2b4", dict(go=1, nb=4)), ("f3", dict(go=2))]
+if os.environ.get("AB"):            # AB=f2,f3: only these variants, interleaved three times (order effects: a slow variant leaves the
+    names = os.environ["AB"].split(",")                       # chip in another clock / cache state for the one measured after it)
+    VARIANTS = [v for v in VARIANTS if v[0] in names] * 3
 tot = {k: 0.0 for k, _ in VARIANTS}
 best_tot = 0.0
 for c in calls:
@@ -67,10 +70,14 @@ for c in calls:
         tot[name] += t
         res.append(f"{name} {t:6.1f}")
         best = min(best, (t, name))
+    if os.environ.get("AB"):
+        S.conv_tuning()
+        print(f"rows={x.cs.n:7d} Cin={x.F.shape[1]:4d} Cout={c['weight'].shape[-1]:4d} res={int(c['residual'] is not None)} | " + "  ".join(res), flush=True)
+        continue
     # splits of the two best-looking forms on the short layers
     extra = []
     if x.cs.n < S.GO_WS_ROWS and ns > 1:
-        for name, kw in (("f1", dict(go=0)), ("f2", dict(go=1))):
+        for name, kw in (("f2", dict(go=1)), ("f3", dict(go=2))):
             for sp in (2, 4, 8, 16):
                 if sp <= ns:
                     S.conv_tuning(splits=sp, **kw)

@@ -232,9 +232,10 @@ def test_gather_once_convolution_vs_oracle_and_stage_kernel(device, cin, cout, n
 def test_gather_once_second_form_is_bit_identical_to_the_first(device, cin, cout, n, span):
     """sparse.conv_tuning(go=1): the second form of the gather-once kernel (metadata requested up front, row numbers of group
     0 cached in LDS, scalar offset loop with SGPR-based weight loads, local indices one offset ahead, one-dimensional grid
-    decoded per XCD, 2 or 4 weight offsets in flight) keeps the first form's summation order: bit-identical outputs and
-    magnitude bound in every work order, with residual + ReLU, split over channel slices, on a point set without locality
-    (several offset groups per tile) and with a ragged last tile"""
+    decoded per XCD, 2 or 4 weight offsets in flight) and go=2, the third form (persistent blocks, two images: the next stage's
+    union rows are gathered under the current stage's MFMAs with hand-counted waits, fragments read one offset ahead) keep the
+    first form's summation order: bit-identical outputs and magnitude bound in every work order, with residual + ReLU, split
+    over channel slices, on a point set without locality (several offset groups per tile) and with a ragged last tile"""
     from cnrma_amd import sparse as S
     rng = np.random.RandomState(cin + n)
     c, f = rand_sparse(rng, n=n, span=span, C=cin, ts=1)
@@ -249,9 +250,9 @@ def test_gather_once_second_form_is_bit_identical_to_the_first(device, cin, cout
             ref = S.conv(x, W, 3, 1, residual=res, act="relu")
             ref_f, ref_amax = ref.F.clone(), float(ref.amax.max())
             plain = S.conv(x, W, 3, 1).F.clone()
-            for go in (1,):
-                for nb in (2, 4):
-                    for xcd in (0, 1, 2):
+            for go, nb, xcd in [(1, nb_, x_) for nb_ in (2, 4) for x_ in (0, 1, 2)] + [(2, -1, -1)]:      # go = 2: the third form
+                if True:
+                    if True:
                         S.conv_tuning(splits=splits, go=go, nb=nb, xcd=xcd)
                         got = S.conv(x, W, 3, 1, residual=res, act="relu")
                         assert torch.equal(got.F, ref_f), (splits, go, nb, xcd)
