@@ -709,8 +709,7 @@ def profile_block(wl, block, name):
                          "stream (eager pass outside the timed region)")
     else:
         tr = pmc_traffic(name, "conv")
-        roof = dict(kernel="sparse_conv_go_kernel / sparse_conv_bf16x6_kernel<..., MODE=1> (cnrma_sparse_conv_go_f16x3, "
-                           "cnrma_sparse_conv_f16x3), all launches of one scene",
+        roof = dict(kernel="sparse_conv_go2_kernel + sparse_conv_bf16x6_kernel<.., MODE=1> (all f16x3 conv launches of a scene)",
                     bound="mfma", achieved=F_alg / 1e9 / conv_ms, peak=MFMA_F16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=F_alg / 1e9 / conv_ms / MFMA_F16_PEAK_TFLOPS, traffic=tr[0] if tr else None,
                     traffic_source=tr[1] if tr else None, launch_ms=conv_ms / max(1, len(layers)),
