@@ -8,6 +8,7 @@
 // a neighbour table nbr[No][K] (input row or -1) is built once per (coordinate set, kernel) pair and the
 // convolution is a gather-GEMM with no atomics -- deterministic, and the BatchNorm / bias / residual /
 // activation epilogue is fused into the store.
+#include <cstdio>
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -3013,7 +3014,7 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_gof_kernel(ConvArgs p, GoA
 //   * the A fragments of a whole offset are read one offset ahead (two register sets): the MFMAs of an offset never wait for LDS.
 // Same sums in the same order as the other two forms (bit-identical: the test).
 // ================================================================================================================
-struct Go3Map { int tiles, ncol, ng, n_items, per_xcd, bpx; };   // item = tile * ng + group; XCD x owns items [x per_xcd, (x + 1) per_xcd)
+struct Go3Map { int tiles, ncol, ng, n_items, per_xcd, bpx, flags; };   // flags (A/B aid): bit 0 = never gather ahead   // item = tile * ng + group; XCD x owns items [x per_xcd, (x + 1) per_xcd)
 constexpr int GO3_RS = 288;                                       // row numbers parked per tile (>= GO_UMAX, two 256-thread loads)
 constexpr int GO3_IMG = 2 * GO2_US * 2;                           // bytes of one image (two planes)
 constexpr int GO3_LDS = 2 * GO3_IMG + 2 * (GO_BM * 27 * 2) + 2 * (GO3_RS * 4);
@@ -3024,10 +3025,15 @@ __device__ __forceinline__ void go_load_row(f32x4_t& d, const float* sbase, unsi
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
 }
 
-template <int WAVES_N, int KS, bool HAS_RES>
+template <int WAVES_N, int KS, bool HAS_RES, bool STAMP = false>
 __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag, Go3Map mp) {
   static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
   constexpr int TM = 2, BN = 32 * WAVES_N, NB = 2, RD = 4;   // weight sets in flight; row-load ring (a load is finished 3 steps later)
+  // STAMP: diagnostic instantiation (conv_tuning(go=2, ablate=64)): s_memtime stamps of the block's FIRST item, 16 words per block
+  unsigned long long* const dbg = STAMP ? reinterpret_cast<unsigned long long*>(g.counters) : nullptr;
+  int n_stamp = 0;
+  bool stamp_on = STAMP;
+  if (STAMP && dbg) go_stamp(dbg, n_stamp++);                // 0: block start
   extern __shared__ __attribute__((aligned(16))) unsigned char go3_smem[];
   auto Us = [&](int b) { return reinterpret_cast<__bf16*>(go3_smem + (size_t)b * GO3_IMG); };
   auto Ls = [&](int b) { return reinterpret_cast<uint16_t*>(go3_smem + 2 * GO3_IMG + (size_t)b * (GO_BM * 27 * 2)); };
@@ -3136,6 +3142,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
       for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
 
     int stage = 0;
+    int n_off_dbg = 0;
     for (int slice = s_lo; slice < s_hi; ++slice) {
       const int cin0 = slice * BK;
       for (int grpi = 0; grpi < n_groups; ++grpi, ++stage) {
@@ -3158,6 +3165,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
         int kk[NB];
         unsigned rest = mymask;
         const int n_off = __popc(mymask);
+        n_off_dbg += n_off;
         int k_last = 0;
         auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
         // prime the issue pattern of the steps -- four weight loads, one row load -- so that their counted waits hold from the
@@ -3175,6 +3183,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
           else gather_now(U, tr + ub, un, cin0, 0);
         }
         __syncthreads();
+        if (STAMP && dbg && stamp_on) go_stamp(dbg, n_stamp++);          // 1 + 3 i: barrier passed (image ready)
         const bool park_here = !meta_parked;                 // this item's first stage: ask for the next item's metadata now
         if (park_here) {
           h0n = *reinterpret_cast<const int4*>(g.hdr + tile2 * GO_HDR);
@@ -3194,14 +3203,22 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
         } else if (more && meta_parked) {
           ahead = true; rows_n = Rs(buf ^ 1); un_n = __builtin_amdgcn_readfirstlane(h0n.w); cin0_n = s_lo2 * BK;
         }
+        if (mp.flags & 1) ahead = false;
         __bf16* const Un = Us(img ^ 1);
         const int tasks_n = ahead ? un_n * 8 : 0;
         const int nq = (tasks_n + 255) >> 8;                 // row loads per thread of the successor's gather
         const unsigned kc16 = (unsigned)(tid & 7) * 16u + (unsigned)cin0_n * 4u;
-        auto g_issue = [&](f32x4_t& dreg, int q) {           // task q of this thread (a dummy behind the last: row 0, dump row)
+        // the row number of task q is read from LDS at the TOP of a step (g_row) and used at its end (g_issue): read where it is
+        // used, behind a condition, hipcc waited lgkmcnt(0) there -- draining the eight fragment reads of the next offset issued
+        // just before -- once per step
+        auto g_row = [&](int q) -> int32_t {
+          const int tk = q * 256 + tid;
+          return rows_n[min(tk >> 3, GO3_RS - 1)];              // always a valid LDS address; selected in g_issue
+        };
+        auto g_issue = [&](f32x4_t& dreg, int q, int32_t row_q) {   // task q of this thread (a dummy behind the last: row 0, dump row)
           const int tk = q * 256 + tid;
           const bool real = q < nq && tk < tasks_n;
-          const int32_t srow = real ? rows_n[tk >> 3] : 0;
+          const int32_t srow = real ? row_q : 0;
           go_load_row(dreg, p.in, (unsigned)srow * (unsigned)(Cin * 4) + kc16);
         };
         auto g_finish = [&](const f32x4_t& dreg, int q) {
@@ -3247,13 +3264,14 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
         // one step = one offset.  t: index of the step inside the stage (ring / set indices are t % 4, t % 2: the steps run in
         // turns of RD so that they are compile-time constants)
         auto step = [&](int j, int t) {
+          const int32_t row_t = g_row(t);
           go_waitn<(NB - 1) * 5 + 1>(bf[j % NB]);            // this step's weights have landed; newer: 1 row load + the step before's 5
           read_a(A[(j + 1) & 1], li);                        // fragments of the next offset
           mfma_k(bf[j % NB], A[j & 1]);
           kk[j % NB] = pop();                                // two offsets ahead (behind the last offset: the last one again)
           load_li(li, kk[j % NB]);                           // ... its local indices are turned into fragment reads one step later
           load_b(bf[j % NB], kk[j % NB], slice, cout0);
-          g_issue(ring[j], t);
+          g_issue(ring[j], t, row_t);
           asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[(j + 1) % RD]) : "n"((RD - 1) * 5));   // the row load RD - 1 steps old
           g_finish(ring[(j + 1) % RD], t - (RD - 1));
         };
@@ -3265,6 +3283,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
 #pragma unroll
         for (int j = 0; j < RD - 1; ++j)
           if (i + j < n_off) step(j, i + j);
+        if (STAMP && dbg && stamp_on) go_stamp(dbg, n_stamp++);          // 2 + 3 i: this wave's offsets issued
         // ---- nothing may stay in flight (the asm loads are invisible to the compiler); then the row loads not yet finished
         // (the last RD - 1 issued) and the ones never issued (more tasks than offsets), without overlap
 #pragma unroll
@@ -3282,6 +3301,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
           if (tid < GO3_RS - 256) Rs(buf ^ 1)[256 + tid] = rn1;
           meta_parked = true;
         }
+        if (STAMP && dbg && stamp_on) go_stamp(dbg, n_stamp++);          // 3 + 3 i: drained, leftovers finished, metadata parked
         have_img = ahead;
         img ^= 1;
       }
@@ -3357,6 +3377,7 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoA
         }
       }
     }
+    if (STAMP && dbg && stamp_on) { go_stamp(dbg, 15); stamp_on = false; if (threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)n_off_dbg; }
     if (!more) break;
     it = it2;
     h0 = h0n;
@@ -4586,32 +4607,40 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
 }
 
 // third form (experimental until measured everywhere): persistent grid, two blocks per CU
-template <int WAVES_N, int KS, bool HAS_RES>
+template <int WAVES_N, int KS, bool HAS_RES, bool STAMP = false>
 static int launch_go3_one(unsigned blocks, const ConvArgs& p, const GoArgs& g, const uint16_t* wfrag, const Go3Map& mp, hipStream_t st) {
-  auto kernel = sparse_conv_go3_kernel<WAVES_N, KS, HAS_RES>;
+  auto kernel = sparse_conv_go3_kernel<WAVES_N, KS, HAS_RES, STAMP>;
   static bool raised = false;               // per instantiation: dynamic LDS above the 64-KB default
   if (!raised) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GO3_LDS);
     if (e != hipSuccess) return -(int)e;
     raised = true;
   }
+  if (g_conv_tune.pf == 8) {                               // A/B aid: how many of these blocks a CU holds
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 256, GO3_LDS);
+    fprintf(stderr, "sparse_conv_go3_kernel<%d, %d, %d>: %d blocks per CU at %d bytes of LDS\n", WAVES_N, KS, (int)HAS_RES, nb, GO3_LDS);
+  }
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), GO3_LDS, st, p, g, wfrag, mp);
   return 0;
 }
 
-static int launch_go3(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, hipStream_t st) {
+static int launch_go3(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, void* stamps, hipStream_t st) {
   Go3Map mp;
   mp.tiles = pl.mp.tiles; mp.ncol = pl.mp.ncol; mp.ng = pl.mp.ng;
   mp.n_items = mp.tiles * mp.ng;
   mp.per_xcd = (int)ceil_div(mp.n_items, 8);
   mp.bpx = mp.per_xcd < 64 ? mp.per_xcd : 64;               // 2 blocks x 32 CUs per XCD
+  mp.flags = g_conv_tune.pf == 7 ? 1 : 0;
   g.slices_per_split = pl.slices_per_split;
   p.splits = pl.splits;
-  g.counters = nullptr;
+  g.counters = reinterpret_cast<unsigned*>(stamps);
   const unsigned blocks = 8u * (unsigned)mp.bpx;
   const bool has_res = residual && pl.splits == 1;
   int rc;
-  if (pl.bn == 128) rc = has_res ? launch_go3_one<4, 1, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<4, 1, false>(blocks, p, g, wfrag, mp, st);
+  if (stamps != nullptr && !has_res)
+    rc = pl.bn == 128 ? launch_go3_one<4, 1, false, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<2, 2, false, true>(blocks, p, g, wfrag, mp, st);
+  else if (pl.bn == 128) rc = has_res ? launch_go3_one<4, 1, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<4, 1, false>(blocks, p, g, wfrag, mp, st);
   else rc = has_res ? launch_go3_one<2, 2, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<2, 2, false>(blocks, p, g, wfrag, mp, st);
   if (rc != 0) return rc;
   if (pl.splits > 1) {
@@ -4759,8 +4788,8 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   {
     const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace != nullptr, workspace_bytes);
     // the other ablation masks (diagnostic kernels with phases switched off) exist in the first form only
-    if (pl.form >= 2 && g_conv_tune.ablate == 0 && (uint64_t)no_cap * (uint64_t)Cin * 4u < (1ull << 32))
-      return launch_go3(pl, p, g, wfrag, residual != nullptr, st);
+    if (pl.form >= 2 && (g_conv_tune.ablate & ~64) == 0 && (uint64_t)no_cap * (uint64_t)Cin * 4u < (1ull << 32))
+      return launch_go3(pl, p, g, wfrag, residual != nullptr, (g_conv_tune.ablate & 64) ? tile_counters : nullptr, st);
     if (pl.form >= 1 && (g_conv_tune.ablate & ~64) == 0)
       return launch_go2(pl, p, g, wfrag, residual != nullptr, (g_conv_tune.ablate & 64) ? tile_counters : nullptr, st);
   }

@@ -78,6 +78,21 @@ for c in calls:
     if not len(st):
         print("no stamps", x.cs.n)
         continue
+    if form == 2:                                             # third form: stamps of every block's FIRST item; slot 14 = offsets of wave 0
+        n_off = st[:, 14].astype(np.float64)
+        life = st[:, 15] - st[:, 0]
+        n_ph = int((st[0, 1:14] != 0).sum())
+        names = ["start->barrier"] + [("offsets", "drain+finish+park", "prefetch+barrier")[(i - 1) % 3] for i in range(1, n_ph)] + ["merge+epilogue"]
+        prev, segs = st[:, 0], []
+        for i in range(1, n_ph + 1):
+            segs.append(st[:, i] - prev)
+            prev = st[:, i]
+        segs.append(st[:, 15] - prev)
+        loops = sum(s_ for n_, s_ in zip(names, segs) if n_ == "offsets")
+        print(f"rows={x.cs.n:7d} Cin={x.F.shape[1]:4d} Cout={c['weight'].shape[-1]:4d} blocks={len(st):5d} plain {t_plain:7.1f} us diag {t_diag:7.1f} us; first item: "
+              f"median life {np.median(life):8.0f} cycles, offsets of wave 0 {np.median(n_off):.0f}, cycles per offset step {np.median(loops / np.maximum(n_off, 1)):7.0f}")
+        print("    " + "  ".join(f"{n} {np.median(s_):7.0f}" for n, s_ in zip(names, segs)) + "   (median cycles)")
+        continue
     # s_memtime is not one chip-wide counter: spans are taken inside one XCD (XCC_ID read by the block), the tick from the launch's length
     xcc = st[:, 14] & 0xF
     hw = st[:, 14] >> 32
