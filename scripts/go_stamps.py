@@ -14,6 +14,7 @@ dev = torch.device("cuda:0")
 wl = sys.argv[1] if len(sys.argv) > 1 else "S"
 form = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+PF = int(sys.argv[4]) if len(sys.argv) > 4 else -1            # third form: 7 = never gather ahead
 V, C, H, W, dims, stride = synth.SHAPES[wl]
 sc = synth.make_scene(wl, seed=0, boxes=3, device=dev)
 feat, proj, tsdf = sc["features"][:, 0].to(dev), sc["projection"][:, 0], sc["tsdf"][0, 0].to(dev)
@@ -60,7 +61,7 @@ for c in calls:
     b.record()
     torch.cuda.synchronize()
     t_plain = a.elapsed_time(b) / 10 * 1e3
-    S.conv_tuning(go=form, nb=nb, ablate=64)
+    S.conv_tuning(go=form, nb=nb, ablate=64, pf=PF)
     print("  diagnostic build", flush=True)
     run()
     torch.cuda.synchronize()

@@ -27,6 +27,25 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters, unsigned long
   out[blockIdx.x * 256 + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
+// dependent-issue latency: ONE wave per SIMD with 1 / 2 / 4 independent accumulator chains of v_mfma_f32_32x32x16_f16
+template <int CH>
+__global__ __launch_bounds__(64) void chains(float* out, int iters, unsigned long long* cyc) {
+  f32x16 a0 = {}, a1 = {}, a2 = {}, a3 = {};
+  f16x8 h = {(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int r = 0; r < 12 / CH; ++r) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a0, 0, 0, 0);
+      if (CH >= 2) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a1, 0, 0, 0);
+      if (CH >= 4) { a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(h, h, a3, 0, 0, 0); }
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  out[blockIdx.x * 64 + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
 int main() {
   float* out; unsigned long long* cyc;
   hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&cyc, 8);
@@ -46,5 +65,17 @@ int main() {
                mode == 0 ? "f16 32x32x16" : "f32 32x32x2 ", blocks, ms, flop / ms / 1e9, c, c / ms / 1e6,
                (double)c / ((double)iters * 4 * (blocks >= 1024 ? 4 : 1)));
       }
+  // one wave per SIMD (1024 single-wave blocks), 12 MFMAs per iteration spread over CH accumulator chains
+  for (int ch : {1, 2, 4}) {
+    const int iters = 100000;
+    hipEventRecord(e0);
+    if (ch == 1) hipLaunchKernelGGL(chains<1>, dim3(1024), dim3(64), 0, 0, out, iters, cyc);
+    else if (ch == 2) hipLaunchKernelGGL(chains<2>, dim3(1024), dim3(64), 0, 0, out, iters, cyc);
+    else hipLaunchKernelGGL(chains<4>, dim3(1024), dim3(64), 0, 0, out, iters, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("one wave per SIMD, %d accumulator chain(s): %.1f ns per MFMA = %.1f cycles at 2.4 GHz (an independent MFMA: 32)\n", ch,
+           ms * 1e6 / (iters * 12.0), ms * 1e6 / (iters * 12.0) * 2.4);
+  }
   return 0;
 }
