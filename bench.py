@@ -839,7 +839,7 @@ def compact_line(result):
                          conv_ms_per_scene=(s.get("conv") or {}).get("ms_per_scene"),
                          conv_mfma_busy=(s.get("conv") or {}).get("mfma_busy_gather_once"),
                          roofline=_roof(s.get("roofline")), cpu_baseline=_cpu(s.get("cpu_baseline"), sample=False))
-    for k in ("through_plugin", "nchw_input", "f32_conv", "train_S"):
+    for k in ("through_plugin", "nchw_input", "f32_conv", "St", "train_S"):
         if result.get(k):
             line[k] = {kk: result[k][kk] for kk in ("value", "ms_per_step") if kk in result[k]}
     if result.get("dist"):
@@ -849,7 +849,7 @@ def compact_line(result):
     line = _r(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     if len(text) >= LINE_LIMIT:                                          # never print a line the driver cannot parse
-        for k in ("train_S", "f32_conv", "nchw_input", "through_plugin", "dist"):
+        for k in ("train_S", "St", "f32_conv", "nchw_input", "through_plugin", "dist"):
             line.pop(k, None)
         line["config"] = {k: v for k, v in line["config"].items() if k in ("workload", "scenes_per_step")}
         line["config"]["workload"] = line["config"].get("workload", "")[:200]
@@ -1008,6 +1008,14 @@ def main():
             result["S"] = bs
             del wls
             torch.cuda.empty_cache()
+    if not args.no_secondary and not args.through_plugin and args.workload != "St":
+        # ---- ScanNet TEST shape (ray_marching_scannet.py:16,19: 50 views, grid 256 x 256 x 96): numbers only
+        wlt, bt = measure("St", device, rank, world, args, barrier)
+        result["St"] = {k: bt[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step", "windows_scenes_per_s",
+                                            "plan_violations", "graph_nodes_per_scene", "M_rows", "M_selected", "M_unique", "level_rows", "head_rows")}
+        result["St"]["workload"] = "St: ScanNet test shape, V=50, C=32, 120x160 maps (stride 4), grid 256x256x96 (ray_marching_scannet.py:16,19)"
+        del wlt
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_secondary and not args.through_plugin:
         log("training step at the ScanNet shape (bf16 autocast)")
         try:
