@@ -2440,7 +2440,8 @@ __device__ __forceinline__ void go_load_frag(u32x4_t (&b)[2][2], const uint16_t*
 }
 
 constexpr int GO2_US = (GO_UMAX + 2) * LDK;              // 16-bit elements of one plane of the image
-constexpr int GO2_LDS = 2 * GO2_US * 2 + GO_BM * 27 * 2 + GO_UMAX * 4;     // bytes: two planes, local indices, row numbers
+constexpr int GO2_RS = 288;                             // row numbers parked per tile (>= GO_UMAX; two loads per thread)
+constexpr int GO2_LDS = 2 * GO2_US * 2 + GO_BM * 27 * 2 + GO2_RS * 4;      // bytes: two planes, local indices, row numbers
 
 template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false>
 __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_go2_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag,
@@ -2481,9 +2482,7 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
   const int4 h0 = *reinterpret_cast<const int4*>(th);
   uint4 lv = make_uint4(0x00010000u, 0x00030002u, 0x00050004u, 0x00070006u);
   if (tid < GO_BM * 27 / 8) lv = reinterpret_cast<const uint4*>(g.lidx + tile * (GO_BM * 27))[tid];
-  int32_t pre[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pre[i] = tr[(tid >> 3) + 32 * i];
+  const int32_t rn0 = tr[tid], rn1 = tr[256 + (tid & 31)];     // all row numbers a union of group 0 can have (GO2_RS >= GO_UMAX)
   const int col = cout0 + wc * 32 + (lane & 31);
   const bool col_ok = col < Cout;
   const int colc = col_ok ? col : 0;
@@ -2493,6 +2492,8 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
   const float a_scale = f16_scale_for(read_amax(p.in_amax));
   const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
   if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls)[tid] = lv;
+  Rs[tid] = rn0;
+  if (tid < GO2_RS - 256) Rs[256 + tid] = rn1;
   if (tid < 16) {                                            // the zero row of both planes (64 bytes each)
     reinterpret_cast<uint32_t*>(Us + GO_UMAX * LDK)[tid] = 0u;
     reinterpret_cast<uint32_t*>(Us + GO2_US + GO_UMAX * LDK)[tid] = 0u;
@@ -2575,8 +2576,10 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
       // ---- the union rows of the group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight.  Row numbers:
       // group 0 in its first slice from memory (the first batch was requested at the top of the kernel) and kept in LDS for
       // the later slices; other groups (tiles without locality) from memory every time
-      const bool cached = grpi == 0 && slice != s_lo, keep = grpi == 0 && slice == s_lo && s_hi - s_lo > 1;
+      // Row numbers: group 0 from LDS (all of them were requested at the top of the kernel: every gather batch of every slice
+      // is ONE round trip), other groups (tiles without locality) from memory
       const int tasks = un * 8;
+      const int32_t* rows_g = tr + ub;
       for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
         float4 v[4];
         int32_t src[4];
@@ -2584,21 +2587,15 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
         for (int i = 0; i < 4; ++i) {
           const int tk = t0 + i * 256 + tid;
           const int r = tk < tasks ? (tk >> 3) : 0;
-          if (cached) src[i] = Rs[r];
-          else if (grpi == 0 && t0 == 0) src[i] = tk < tasks ? pre[i] : tr[0];
-          else src[i] = tr[ub + r];
-          if (keep && (tk & 7) == 0 && tk < tasks) Rs[r] = src[i];
+          src[i] = grpi == 0 ? Rs[r] : rows_g[r];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int tk = t0 + i * 256 + tid;
-          v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (tk & 7) * 4);
-        }
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (tid & 7) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           // every loaded value is consumed on every path (tasks behind the union go to the dump row), see the first form
           const int tk = t0 + i * 256 + tid;
-          const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tk & 7;
+          const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tid & 7;
           uint2 h, m;
           split2(v[i], a_scale, h, m);
           __bf16* d = Us + lds_slot(u, kc >> 1) + (kc & 1) * 4;
