@@ -87,12 +87,14 @@ SIGNATURES = {
     "cnrma_sparse_conv_pairs_f16x3": (c_int, [P, P, I, P, I, P, I, P, P, P, I, P, P, L, P, L, P, c_size_t, P]),
     "cnrma_sparse_conv_bf16_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights_bf16": (c_int, [P, I, I, I, P, P]),
+    "cnrma_sparse_conv_prepare_weights_bf16_t": (c_int, [P, I, I, I, I, P, P]),
     "cnrma_sparse_conv_bf16": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_convtr_gen_f16x3": (c_int, [P, P, P, L, P, I, I, P, I, P, P, I, P, P, P, P]),
     "cnrma_sparse_kernel_map_transpose": (c_int, [P, L, P, I, L, P, P]),
     "cnrma_sparse_conv_wgrad_chunks": (c_int, [L, I]),
     "cnrma_sparse_conv_wgrad_f32": (c_int, [P, I, P, I, P, I, L, P, I, P, P]),
     "cnrma_sparse_conv_wgrad_bf16": (c_int, [P, I, P, I, P, I, L, P, I, P, P]),
+    "cnrma_sparse_conv_wgrad_go_bf16": (c_int, [P, I, P, P, I, L, P, I, P, P]),
     "cnrma_sparse_convtr_gen_f32": (c_int, [P, P, L, P, I, I, P, I, P, P, I, P, P, P]),
     "cnrma_sparse_maxpool_f32": (c_int, [P, I, P, I, P, L, P, P]),
     "cnrma_instnorm_workspace_bytes": (c_size_t, [I]),
@@ -114,7 +116,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class CnrmaError(RuntimeError):

@@ -9,6 +9,7 @@
 // convolution is a gather-GEMM with no atomics -- deterministic, and the BatchNorm / bias / residual /
 // activation epilogue is fused into the store.
 #include <cstdio>
+#include <type_traits>
 #include "common.h"
 
 #include <hipcub/hipcub.hpp>
@@ -896,6 +897,20 @@ __global__ __launch_bounds__(256) void prep_weights_bf16_kernel(const float* __r
     int cin, co, k;
     weight_image_coords(t, Cin, Cp, &k, &co, &cin);
     wt[t] = (__bf16)(co < Cout ? w[((int64_t)k * Cin + cin) * Cout + co] : 0.0f);
+  }
+}
+
+// the image of the TRANSPOSED weights for dgrad, straight from W: Wd[k] = W[flip ? K - 1 - k : k]^T ([Cout] -> [Cin]), bf16
+// [K][Cout/32][Cin_p][32] -- flip: a symmetric (same coordinates, odd kernel) map transposes by mirroring its offsets
+__global__ __launch_bounds__(256) void prep_weights_bf16_t_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
+                                                                  int Cin, int Cout, int flip) {
+  const int Cp = conv_cout_padded(Cin);
+  const int64_t total = (int64_t)K * Cout * Cp;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int cin, co, k;
+    weight_image_coords(t, Cout, Cp, &k, &co, &cin);              // co: a channel of grad_in (W's Cin), cin: of grad_out
+    const int ks = flip ? K - 1 - k : k;
+    wt[t] = (__bf16)(co < Cin ? w[((int64_t)ks * Cin + co) * Cout + cin] : 0.0f);
   }
 }
 
@@ -3811,78 +3826,41 @@ __global__ __launch_bounds__(256) void kernel_map_transpose_kernel(const int32_t
   if (i >= 0 && i < n_in) nbr_t[(int64_t)i * K + (t % K)] = (int32_t)(t / K);
 }
 
-// one wave per block: a 64 x 64 (Cin x Cout) tile of gradW[k] over one chunk of output rows.  A step covers 32 rows: the
-// 32 neighbour indices are fetched by one load, then the 64 operand loads of the step (16 row pairs x 2 x 2 tiles) are all
-// issued before its 64 MFMAs -- the former two-rows-per-iteration loop paid two dependent memory latencies per 4 MFMAs.
-__global__ __launch_bounds__(64) void conv_wgrad_kernel(const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr,
-                                                        int K, const float* __restrict__ gout, int Cout, int64_t no_cap,
-                                                        const int32_t* __restrict__ no_dev, int rows_per_chunk,
-                                                        float* __restrict__ slab) {
-  const int64_t n_live = live_rows(no_cap, no_dev);
-  const int chunk = blockIdx.x, k = blockIdx.y;
-  const int tiles_co = (Cout + 63) / 64;
-  const int ci0 = (blockIdx.z / tiles_co) * 64, co0 = (blockIdx.z % tiles_co) * 64;
-  const int lane = threadIdx.x, m = lane & 31, kk = lane >> 5;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
-  const int64_t r1 = min(n_live, r0 + rows_per_chunk);
-  const bool ci_ok0 = ci0 + m < Cin, ci_ok1 = ci0 + 32 + m < Cin, co_ok0 = co0 + m < Cout, co_ok1 = co0 + 32 + m < Cout;
-  for (int64_t o0 = r0; o0 < r1; o0 += 32) {
-    int32_t src_l = -1;                                   // lane l < 32: input row of output row o0 + l at this offset
-    if (m + (kk << 5) < 32 && o0 + m < r1) src_l = nbr ? nbr[(o0 + m) * K + k] : (int32_t)(o0 + m);
-    float a0[16], a1[16], b0[16], b1[16];
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-      const int row = 2 * s2 + kk;
-      const int32_t src = __shfl(src_l, row, 64);
-      const bool live = o0 + row < r1;
-      const float* ap = in + (int64_t)(src < 0 ? 0 : src) * Cin + ci0 + m;
-      const float* gp = gout + (live ? o0 + row : r0) * Cout + co0 + m;
-      const float va0 = ci_ok0 ? ap[0] : 0.0f, va1 = ci_ok1 ? ap[32] : 0.0f;
-      const float vb0 = co_ok0 ? gp[0] : 0.0f, vb1 = co_ok1 ? gp[32] : 0.0f;
-      a0[s2] = src >= 0 ? va0 : 0.0f; a1[s2] = src >= 0 ? va1 : 0.0f;
-      b0[s2] = live ? vb0 : 0.0f; b1[s2] = live ? vb1 : 0.0f;
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s2], b0[s2], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s2], b1[s2], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s2], b0[s2], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s2], b1[s2], acc[1][1], 0, 0, 0);
-    }
+// one block of 8 waves per (row chunk, offset, 64 x 64 tile of gradW[k]): the chunk's 32-row steps go round-robin to the waves,
+// whose eight accumulator tiles are added through LDS in a fixed tree ((0+4)+(2+6))+((1+5)+(3+7)) -- deterministic, and one
+// slab per BLOCK (the one-wave-per-block kernel of rounds 2-4 wrote one per wave: 125 MB of slabs per layer at any size,
+// zeroed, written and read back = 19 GB of the step's traffic).
+// The 1-D grid is decoded XCD-first (block b runs on XCD b % 8): all K offsets and all tiles of a chunk land on ONE XCD back
+// to back, so the chunk's grad_out rows and the input rows around it come over the fabric once and are served from that
+// XCD's L2 to the other K * tiles - 1 blocks (chunk-major order spread them over 8 L2s and over time: ~1 GB of fabric reads
+// for a 73 k-row 64 -> 64 layer).
+// Lane (m, kh): channels ci0 + 2m, ci0 + 2m + 1 of the tile's rows and co0 + 2m, co0 + 2m + 1 of its columns, one 8-byte
+// load each per row (V2: both channel counts even) -- the MFMA does not care which channel sits in which matrix row as long
+// as the store agrees: acc[x][y] holds (ci0 + 2 row + x, co0 + 2 col + y).
+// BF16: operands rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16 (lane (m, kh) holds rows 8 kh .. 8 kh + 7 of
+// a 16-row half step); else exact products on v_mfma_f32_32x32x2_f32 (lane (m, kh) holds row 2 s + kh of pair s).
+constexpr int WG_WAVES = 8;
+struct WgradMap { int chunks, per, tiles, tiles_co, by_chunk; };
+template <bool BF16, bool V2>
+__global__ __launch_bounds__(64 * WG_WAVES, 2) void conv_wgrad_block_kernel(
+    const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr, int K, const float* __restrict__ gout, int Cout,
+    int64_t no_cap, const int32_t* __restrict__ no_dev, int rows_per_chunk, float* __restrict__ slab, WgradMap map) {
+  __shared__ float red[4 * 4096];
+  const unsigned bid = blockIdx.x, xcd = bid & 7u, j = bid >> 3;
+  int chunk, k, tile;
+  if (map.by_chunk) {                                                // many chunks: a chunk's K * tiles blocks on one XCD
+    chunk = (int)(j / (unsigned)map.per) * 8 + (int)xcd;
+    const int rem = (int)(j % (unsigned)map.per);
+    k = rem / map.tiles; tile = rem % map.tiles;
+  } else {                                                           // few chunks: a (chunk, offset)'s tiles on one XCD
+    const int unit = (int)(j / (unsigned)map.tiles) * 8 + (int)xcd;
+    chunk = unit / K; k = unit % K; tile = (int)(j % (unsigned)map.tiles);
   }
-  float* dst = slab + ((int64_t)chunk * K + k) * Cin * Cout;
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int co = co0 + y * 32 + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-        if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[x][y][i];
-      }
-    }
-}
-
-// the same tile in bf16 (autocast training): operands rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16 --
-// 16 rows per MFMA instead of 2, so the matrix pipe is no longer the limiter (the gathers are).  Lane (m, kh) holds rows
-// 8 kh .. 8 kh + 7 of a 16-row step for channel m: A[m][k] = in[src(row k)][ci0 + m], B[k][n] = gout[row k][co0 + n].
-__global__ __launch_bounds__(64) void conv_wgrad_bf16_kernel(const float* __restrict__ in, int Cin, const int32_t* __restrict__ nbr,
-                                                             int K, const float* __restrict__ gout, int Cout, int64_t no_cap,
-                                                             const int32_t* __restrict__ no_dev, int rows_per_chunk,
-                                                             float* __restrict__ slab) {
+  if (chunk >= map.chunks) return;                                   // block-uniform, before any barrier
+  const int ci0 = (tile / map.tiles_co) * 64, co0 = (tile % map.tiles_co) * 64;
   const int64_t n_live = live_rows(no_cap, no_dev);
-  const int chunk = blockIdx.x, k = blockIdx.y;
-  const int tiles_co = (Cout + 63) / 64;
-  const int ci0 = (blockIdx.z / tiles_co) * 64, co0 = (blockIdx.z % tiles_co) * 64;
-  const int lane = threadIdx.x, m = lane & 31, kh = lane >> 5;
+  const int lane = threadIdx.x & 63, m = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -3894,50 +3872,297 @@ __global__ __launch_bounds__(64) void conv_wgrad_bf16_kernel(const float* __rest
   const int64_t r1 = min(n_live, r0 + rows_per_chunk);
   // out-of-range channels / missing rows load from a clamped (valid) address and are zeroed AFTER all loads of the step
   // are in flight: a select right behind each load makes the compiler wait for every load in turn
-  const bool ci_ok0 = ci0 + m < Cin, ci_ok1 = ci0 + 32 + m < Cin, co_ok0 = co0 + m < Cout, co_ok1 = co0 + 32 + m < Cout;
-  const int ca0 = ci_ok0 ? ci0 + m : 0, ca1 = ci_ok1 ? ci0 + 32 + m : 0, cb0 = co_ok0 ? co0 + m : 0, cb1 = co_ok1 ? co0 + 32 + m : 0;
-  for (int64_t o0 = r0; o0 < r1; o0 += 32) {
-    int32_t src_l = -1;                                   // lane l < 32: input row of output row o0 + l at this offset
-    if (lane < 32 && o0 + lane < r1) src_l = nbr ? nbr[(o0 + lane) * K + k] : (int32_t)(o0 + lane);
-    float a0[16], a1[16], b0[16], b1[16];                 // [q]: row 16 (q >> 3) + 8 kh + (q & 7)
+  const bool ci_ok0 = ci0 + 2 * m < Cin, ci_ok1 = ci0 + 2 * m + 1 < Cin, co_ok0 = co0 + 2 * m < Cout, co_ok1 = co0 + 2 * m + 1 < Cout;
+  const int ca0 = ci_ok0 ? ci0 + 2 * m : 0, ca1 = ci_ok1 ? ci0 + 2 * m + 1 : 0;
+  const int cb0 = co_ok0 ? co0 + 2 * m : 0, cb1 = co_ok1 ? co0 + 2 * m + 1 : 0;
+  auto src_of = [&](int64_t o0) -> int32_t {              // lane l < 32: input row of output row o0 + l at this offset
+    int32_t v = -1;
+    if (lane < 32 && o0 + lane < r1) v = nbr ? nbr[(o0 + lane) * K + k] : (int32_t)(o0 + lane);
+    return v;
+  };
+  int64_t o0 = r0 + 32 * wave;
+  int32_t src_l = o0 < r1 ? src_of(o0) : -1;
+  for (; o0 < r1; o0 += 32 * WG_WAVES) {
+    float a0[16], a1[16], b0[16], b1[16];
     unsigned ok_a = 0, ok_b = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int row = 16 * (q >> 3) + 8 * kh + (q & 7);
+      const int row = BF16 ? 16 * (q >> 3) + 8 * kh + (q & 7) : 2 * q + kh;
       const int32_t src = __shfl(src_l, row, 64);
       const bool live = o0 + row < r1;
       const float* ap = in + (int64_t)(src < 0 ? 0 : src) * Cin;
       const float* gp = gout + (live ? o0 + row : r0) * Cout;
-      a0[q] = ap[ca0]; a1[q] = ap[ca1];
-      b0[q] = gp[cb0]; b1[q] = gp[cb1];
+      if (V2) {
+        const float2 ta = *reinterpret_cast<const float2*>(ap + ca0), tb = *reinterpret_cast<const float2*>(gp + cb0);
+        a0[q] = ta.x; a1[q] = ta.y; b0[q] = tb.x; b1[q] = tb.y;
+      } else {
+        a0[q] = ap[ca0]; a1[q] = ap[ca1];
+        b0[q] = gp[cb0]; b1[q] = gp[cb1];
+      }
       ok_a |= (src >= 0 ? 1u : 0u) << q;
       ok_b |= (live ? 1u : 0u) << q;
     }
+    const int64_t on = o0 + 32 * WG_WAVES;                // the next step's row numbers ride behind this step's operands
+    src_l = on < r1 ? src_of(on) : -1;
+    if (BF16) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      bf16x8_t fa0, fa1, fb0, fb1;
+      for (int t = 0; t < 2; ++t) {
+        bf16x8_t fa0, fa1, fb0, fb1;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int q = 8 * t + j;
-        const bool oa = (ok_a >> q) & 1u, ob = (ok_b >> q) & 1u;
-        fa0[j] = (__bf16)(oa && ci_ok0 ? a0[q] : 0.0f); fa1[j] = (__bf16)(oa && ci_ok1 ? a1[q] : 0.0f);
-        fb0[j] = (__bf16)(ob && co_ok0 ? b0[q] : 0.0f); fb1[j] = (__bf16)(ob && co_ok1 ? b1[q] : 0.0f);
+        for (int jj = 0; jj < 8; ++jj) {
+          const int q = 8 * t + jj;
+          const bool oa = (ok_a >> q) & 1u, ob = (ok_b >> q) & 1u;
+          fa0[jj] = (__bf16)(oa && ci_ok0 ? a0[q] : 0.0f); fa1[jj] = (__bf16)(oa && ci_ok1 ? a1[q] : 0.0f);
+          fb0[jj] = (__bf16)(ob && co_ok0 ? b0[q] : 0.0f); fb1[jj] = (__bf16)(ob && co_ok1 ? b1[q] : 0.0f);
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
       }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const bool oa = (ok_a >> q) & 1u, ob = (ok_b >> q) & 1u;
+        const float va0 = oa && ci_ok0 ? a0[q] : 0.0f, va1 = oa && ci_ok1 ? a1[q] : 0.0f;
+        const float vb0 = ob && co_ok0 ? b0[q] : 0.0f, vb1 = ob && co_ok1 ? b1[q] : 0.0f;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb1, acc[1][1], 0, 0, 0);
+      }
     }
   }
+  // the eight waves' tiles: a fixed tree through LDS (element e of lane l at [e][l]: conflict-free)
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[slot * 4096 + ((x * 2 + y) * 16 + i) * 64 + lane] = acc[x][y][i];
+  };
+  auto add = [&](int slot) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[x][y][i] += red[slot * 4096 + ((x * 2 + y) * 16 + i) * 64 + lane];
+  };
+  if (wave >= 4) put(wave - 4);
+  __syncthreads();
+  if (wave < 4) add(wave);
+  __syncthreads();
+  if (wave == 2 || wave == 3) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave != 0) return;
+  add(0);
   float* dst = slab + ((int64_t)chunk * K + k) * Cin * Cout;
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ci = ci0 + 2 * (8 * (i >> 2) + 4 * kh + (i & 3)) + x;
+      const int co = co0 + 2 * m;
+      if (ci >= Cin) continue;
+      if (V2) {
+        if (co < Cout) *reinterpret_cast<float2*>(dst + (int64_t)ci * Cout + co) = make_float2(acc[x][0][i], acc[x][1][i]);
+      } else {
+        if (co < Cout) dst[(int64_t)ci * Cout + co] = acc[x][0][i];
+        if (co + 1 < Cout) dst[(int64_t)ci * Cout + co + 1] = acc[x][1][i];
+      }
+    }
+}
+
+template <bool BF16>
+static int launch_wgrad(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out, int Cout,
+                        int64_t no_cap, const int32_t* no_dev, int rows_per_chunk, float* slabs, void* stream) {
+  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0 || rows_per_chunk <= 0 || (rows_per_chunk & 1) || slabs == nullptr)
+    return CNRMA_EINVAL;
+  WgradMap map;
+  map.chunks = (int)ceil_div(no_cap, rows_per_chunk);
+  map.tiles_co = (int)ceil_div(Cout, 64);
+  map.tiles = (int)ceil_div(Cin, 64) * map.tiles_co;
+  map.per = K * map.tiles;
+  map.by_chunk = map.chunks >= 32;
+  const int64_t blocks = map.by_chunk ? ceil_div(map.chunks, 8) * (int64_t)map.per * 8
+                                      : ceil_div((int64_t)map.chunks * K, 8) * map.tiles * 8;
+  if (blocks > 0x7fffffffLL) return CNRMA_EINVAL;
+  const bool v2 = !(Cin & 1) && !(Cout & 1);
+  auto kern = v2 ? conv_wgrad_block_kernel<BF16, true> : conv_wgrad_block_kernel<BF16, false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WG_WAVES), 0, as_stream(stream), in_feats, Cin, nbr, K, grad_out,
+                     Cout, no_cap, no_dev, rows_per_chunk, slabs, map);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- weight gradient on the gather-once structure (bf16 operands, same-coordinates 3x3x3 convolutions) -------------------------
+// The block kernel above reads an input row once per (output row, offset) pair it takes part in -- ~9 times on a surface --
+// and grad_out once per offset: 1 GB through the vector memory path for a 73 k-row 64 -> 64 layer, which is what bounds it.
+// The tile unions of the forward convolution (tile_union_kernel: per 64-row output tile the DISTINCT input rows of its 27
+// offsets + local indices) remove both: a block stages the tile's union rows (one 64-channel slice, bf16) and its 64
+// grad_out rows ONCE in LDS, transposed ([channel][row]: the MFMA's reduction dimension is the row, so a lane's 8 values of
+// a fragment are 8 rows of ONE channel -- contiguous for grad_out, an indexed 2-byte read per row for the input), and
+// seven waves run one offset each over the image: A[ci][row r] = image[ci][lidx[r][k]], a missing neighbour indexes a zero
+// column.  A block owns (part = a range of tiles, 7 of the 27 offsets, 64 x 64 tile of the matrix) and keeps its accumulators over
+// all tiles of the part: one slab per part, every element written by exactly one wave, no reduction inside the block.
+constexpr int WGO_PITCH = 290;      // u16 per channel of the input image: 280 union rows + the zero column (280) -> 145 dwords: odd,
+                                    // consecutive channels (the lanes of a fragment read) fall into distinct banks
+constexpr int WGO_BP = 72;          // u16 per channel of the grad_out image: 64 rows + 8 (144 B: 16-byte aligned fragment reads)
+constexpr int WGO_KPB = 7;          // offsets per block (one per wave; the eighth wave only stages)
+constexpr int WGO_KG = 4;           // offset groups: 4 x 7 >= 27
+struct WgoMap { int parts, tiles_per_part, n_ci, n_co, by_part; };
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__global__ __launch_bounds__(512, 4) void conv_wgrad_go_kernel(const float* __restrict__ in, int Cin, const float* __restrict__ gout,
+                                                               int Cout, int64_t no_cap, const int32_t* __restrict__ no_dev,
+                                                               const int32_t* __restrict__ hdr, const int32_t* __restrict__ urows,
+                                                               const uint16_t* __restrict__ lidx, float* __restrict__ slab,
+                                                               WgoMap map) {
+  __shared__ __attribute__((aligned(16))) uint16_t At[64 * WGO_PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t Bt[64 * WGO_BP];
+  __shared__ __attribute__((aligned(16))) uint16_t Ls[8 * 64];
+  const int per = WGO_KG * map.n_ci * map.n_co;
+  const unsigned bid = blockIdx.x;
+  int part, rem;
+  if (map.by_part) {                                                 // a part's blocks on one XCD: they stage the same rows
+    const unsigned xcd = bid & 7u, j = bid >> 3;
+    part = (int)(j / (unsigned)per) * 8 + (int)xcd; rem = (int)(j % (unsigned)per);
+  } else {
+    part = (int)(bid / (unsigned)per); rem = (int)(bid % (unsigned)per);
+  }
+  if (part >= map.parts) return;
+  const int g = rem / (map.n_ci * map.n_co), t2 = rem % (map.n_ci * map.n_co);
+  const int ci0 = (t2 / map.n_co) * 64, co0 = (t2 % map.n_co) * 64;
+  const int64_t n_live = live_rows(no_cap, no_dev);
+  const int64_t n_tiles = (n_live + GO_BM - 1) / GO_BM;
+  const int64_t t_begin = (int64_t)part * map.tiles_per_part;
+  const int64_t t_end = min(n_tiles, t_begin + map.tiles_per_part);
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, kh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = g * WGO_KPB + wave;
+  const bool has_k = wave < WGO_KPB && k < 27;
+  const unsigned kmask_block = (((1u << WGO_KPB) - 1u) << (g * WGO_KPB)) & ((1u << 27) - 1u);
+  const bool two_ci = Cin - ci0 > 32;                                // a 32-channel layer: the second half tile stays out
+  for (int i = tid; i < 64 * (WGO_PITCH - GO_UMAX); i += 512)        // the zero column (and the padding behind it)
+    At[(i / (WGO_PITCH - GO_UMAX)) * WGO_PITCH + GO_UMAX + i % (WGO_PITCH - GO_UMAX)] = 0;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+  for (int64_t tile = t_begin; tile < t_end; ++tile) {
+    const int64_t tile0 = tile * GO_BM;
+    const int rows_here = (int)min((int64_t)GO_BM, n_live - tile0);
+    const int32_t* th = hdr + tile * GO_HDR;
+    const int ng = th[0];
+    bool first_stage = true;
+    for (int gi = 0; gi < ng; ++gi) {
+      const unsigned mask = (unsigned)th[1 + 3 * gi];
+      if ((mask & kmask_block) == 0u) continue;                      // block-uniform
+      const int first = th[2 + 3 * gi], cnt = th[3 + 3 * gi];
+      // the global loads of a stage are issued together, ahead of the LDS stores: union row numbers, then (one round trip
+      // later) the rows -- <= 5 (row pair, 4 channels) tasks per thread, in two batches of 3 + 2 (registers) -- and, for a
+      // new tile, the grad_out tile + the local indices with the first batch
+      const int32_t* tr = urows + tile * GO_ROWS + first;
+      const int tasks = ((cnt + 1) >> 1) * 16;
+      const bool stage_b = first_stage;
+      first_stage = false;
+      const int aq = tid & 15, ac = ci0 + 4 * aq;
+      const bool okc = ac < Cin;
+      unsigned* a32 = reinterpret_cast<unsigned*>(At);
+      auto batch = [&](auto nconst, int it0, bool with_b) {
+        constexpr int N = decltype(nconst)::value;
+        int32_t r0[N], r1[N];
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+          const int task = tid + (it0 + it) * 512, u = 2 * (task >> 4);
+          r0[it] = task < tasks ? tr[u] : -1;
+          r1[it] = task < tasks && u + 1 < cnt ? tr[u + 1] : -1;
+        }
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        uint16_t lsv = (uint16_t)GO_UMAX;
+        const int brp = tid >> 4, bq = tid & 15, br = 2 * brp, bc = co0 + 4 * bq;
+        if (with_b) {                                                // grad_out tile: thread = (row pair, 4 columns)
+          if (bc < Cout && br < rows_here) g0 = *reinterpret_cast<const float4*>(gout + (tile0 + br) * Cout + bc);
+          if (bc < Cout && br + 1 < rows_here) g1 = *reinterpret_cast<const float4*>(gout + (tile0 + br + 1) * Cout + bc);
+          const int kk = tid >> 6, r = tid & 63, kg = g * WGO_KPB + kk;  // the block's 7 columns of the local indices
+          if (kk < WGO_KPB && kg < 27 && r < rows_here) lsv = lidx[tile * (GO_BM * 27) + r * 27 + kg];
+        }
+        float4 f0[N], f1[N];
+#pragma unroll
+        for (int it = 0; it < N; ++it) {                             // clamped (valid) addresses, zeroed below
+          f0[it] = *reinterpret_cast<const float4*>(in + (int64_t)(r0[it] >= 0 ? r0[it] : 0) * Cin + (okc ? ac : 0));
+          f1[it] = *reinterpret_cast<const float4*>(in + (int64_t)(r1[it] >= 0 ? r1[it] : 0) * Cin + (okc ? ac : 0));
+        }
+        if (it0 == 0) __syncthreads();                               // the readers of the previous image are done
+        if (with_b) {
+          unsigned* b32 = reinterpret_cast<unsigned*>(Bt);
+          b32[((4 * bq + 0) * WGO_BP + br) >> 1] = pack_bf16x2(g0.x, g1.x);
+          b32[((4 * bq + 1) * WGO_BP + br) >> 1] = pack_bf16x2(g0.y, g1.y);
+          b32[((4 * bq + 2) * WGO_BP + br) >> 1] = pack_bf16x2(g0.z, g1.z);
+          b32[((4 * bq + 3) * WGO_BP + br) >> 1] = pack_bf16x2(g0.w, g1.w);
+          if (tid < WGO_KPB * 64) Ls[tid] = lsv;                     // [offset][row]
+        }
+#pragma unroll
+        for (int it = 0; it < N; ++it) {
+          const int task = tid + (it0 + it) * 512, u = 2 * (task >> 4);
+          if (task < tasks) {
+            const bool k0 = okc, k1 = okc && r1[it] >= 0;
+            a32[((4 * aq + 0) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].x : 0.f, k1 ? f1[it].x : 0.f);
+            a32[((4 * aq + 1) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].y : 0.f, k1 ? f1[it].y : 0.f);
+            a32[((4 * aq + 2) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].z : 0.f, k1 ? f1[it].z : 0.f);
+            a32[((4 * aq + 3) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].w : 0.f, k1 ? f1[it].w : 0.f);
+          }
+        }
+      };
+      static_assert(GO_UMAX / 2 * 16 <= 5 * 512, "five tasks per thread cover the largest union");
+      batch(std::integral_constant<int, 3>{}, 0, stage_b);
+      if (tasks > 3 * 512) batch(std::integral_constant<int, 2>{}, 3, false);
+      __syncthreads();
+      if (has_k && ((mask >> k) & 1u)) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const u16x8_t lv = *reinterpret_cast<const u16x8_t*>(&Ls[wave * 64 + 16 * t4 + 8 * kh]);
+          const bf16x8_t fb0 = *reinterpret_cast<const bf16x8_t*>(&Bt[m * WGO_BP + 16 * t4 + 8 * kh]);
+          const bf16x8_t fb1 = *reinterpret_cast<const bf16x8_t*>(&Bt[(32 + m) * WGO_BP + 16 * t4 + 8 * kh]);
+          u16x8_t ra0, ra1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ra0[j] = At[m * WGO_PITCH + lv[j]];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra0), fb0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra0), fb1, acc[0][1], 0, 0, 0);
+          if (two_ci) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra1[j] = At[(32 + m) * WGO_PITCH + lv[j]];
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra1), fb0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra1), fb1, acc[1][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (!has_k) return;
+  float* dst = slab + ((int64_t)part * 27 + k) * Cin * Cout;
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
     for (int y = 0; y < 2; ++y) {
-      const int co = co0 + y * 32 + (lane & 31);
+      const int co = co0 + y * 32 + m;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
         if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[x][y][i];
       }
     }
@@ -3962,27 +4187,13 @@ extern "C" int cnrma_sparse_conv_wgrad_chunks(int64_t no_cap, int rows_per_chunk
 extern "C" int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out,
                                            int Cout, int64_t no_cap, const int32_t* no_dev, int rows_per_chunk,
                                            float* slabs, void* stream) {
-  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0 || rows_per_chunk <= 0 || (rows_per_chunk & 1) || slabs == nullptr)
-    return CNRMA_EINVAL;
-  const unsigned chunks = (unsigned)ceil_div(no_cap, rows_per_chunk);
-  const unsigned tiles = (unsigned)(ceil_div(Cin, 64) * ceil_div(Cout, 64));
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(chunks, (unsigned)K, tiles), dim3(64), 0, as_stream(stream), in_feats, Cin, nbr,
-                     K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs);
-  CNRMA_LAUNCH_CHECK();
-  return 0;
+  return launch_wgrad<false>(in_feats, Cin, nbr, K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs, stream);
 }
 
 extern "C" int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out,
                                             int Cout, int64_t no_cap, const int32_t* no_dev, int rows_per_chunk,
                                             float* slabs, void* stream) {
-  if (Cin <= 0 || Cout <= 0 || K <= 0 || no_cap <= 0 || rows_per_chunk <= 0 || (rows_per_chunk & 1) || slabs == nullptr)
-    return CNRMA_EINVAL;
-  const unsigned chunks = (unsigned)ceil_div(no_cap, rows_per_chunk);
-  const unsigned tiles = (unsigned)(ceil_div(Cin, 64) * ceil_div(Cout, 64));
-  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(chunks, (unsigned)K, tiles), dim3(64), 0, as_stream(stream), in_feats, Cin,
-                     nbr, K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs);
-  CNRMA_LAUNCH_CHECK();
-  return 0;
+  return launch_wgrad<true>(in_feats, Cin, nbr, K, grad_out, Cout, no_cap, no_dev, rows_per_chunk, slabs, stream);
 }
 
 extern "C" size_t cnrma_voxelize_workspace_bytes(int64_t M) {
@@ -4739,6 +4950,32 @@ extern "C" int cnrma_sparse_tile_union_build(const int32_t* nbr, int64_t no_cap,
   return 0;
 }
 
+extern "C" int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, const void* tile_union, const float* grad_out,
+                                               int Cout, int64_t no_cap, const int32_t* no_dev, int parts, float* slabs,
+                                               void* stream) {
+  if (in_feats == nullptr || tile_union == nullptr || grad_out == nullptr || slabs == nullptr || Cin <= 0 || Cout <= 0 ||
+      (Cin & 3) || (Cout & 3) || no_cap <= 0 || parts <= 0)
+    return CNRMA_EINVAL;
+  const size_t tiles = (size_t)ceil_div(no_cap, GO_BM);
+  const char* w = reinterpret_cast<const char*>(tile_union);
+  const int32_t* hdr = reinterpret_cast<const int32_t*>(w);      w += go_align(tiles * GO_HDR * 4);
+  const int32_t* rows = reinterpret_cast<const int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
+  const uint16_t* lidx = reinterpret_cast<const uint16_t*>(w);
+  WgoMap map;
+  map.parts = parts;
+  map.tiles_per_part = (int)ceil_div((int64_t)tiles, parts);
+  map.n_ci = (int)ceil_div(Cin, 64);
+  map.n_co = (int)ceil_div(Cout, 64);
+  map.by_part = parts >= 16;
+  const int64_t per = (int64_t)WGO_KG * map.n_ci * map.n_co;
+  const int64_t blocks = (map.by_part ? ceil_div(parts, 8) * 8 : (int64_t)parts) * per;
+  if (blocks > 0x7fffffffLL) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(conv_wgrad_go_kernel, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), in_feats, Cin, grad_out, Cout,
+                     no_cap, no_dev, hdr, rows, lidx, slabs, map);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int cnrma_sparse_conv_prepare_weights_f16_frag(const float* weight, int K, int Cin, int Cout, void* weight_frag,
                                                           void* stream) {
   if (K <= 0 || Cin <= 0 || Cin % BK != 0 || Cout <= 0 || weight_frag == nullptr) return CNRMA_EINVAL;
@@ -4852,6 +5089,17 @@ extern "C" int cnrma_sparse_conv_prepare_weights_bf16(const float* weight, int K
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(prep_weights_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
                      reinterpret_cast<__bf16*>(weight_bf16), K, Cin, Cout);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_bf16_t(const float* weight, int K, int Cin, int Cout, int flip,
+                                                        void* weight_bf16, void* stream) {
+  if (K <= 0 || Cin <= 0 || Cout <= 0 || Cout % 32 != 0 || weight == nullptr || weight_bf16 == nullptr) return CNRMA_EINVAL;
+  int64_t blocks = ceil_div((int64_t)K * Cout * conv_cout_padded(Cin), 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_bf16_t_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
+                     reinterpret_cast<__bf16*>(weight_bf16), K, Cin, Cout, flip ? 1 : 0);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

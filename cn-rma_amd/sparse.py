@@ -846,9 +846,33 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
     return SparseTensor(out, out_cs, out_split)
 
 
+def _dgrad_weights(w3, flip, precision):
+    """the weights of the data gradient, W'[k] = W[K - 1 - k if flip else k]^T: under bf16 the prepared image straight
+    from W (one kernel; the image cannot be cached -- the optimiser changes W every step), else the fp32 tensor"""
+    K, Cin, Cout = w3.shape
+    if precision == "bf16" and Cout % 32 == 0:
+        img = torch.empty(_lib.load().cnrma_sparse_conv_bf16_weight_bytes(K, Cout, Cin), dtype=torch.uint8, device=w3.device)
+        call("cnrma_sparse_conv_prepare_weights_bf16_t", ptr(w3.contiguous()), K, Cin, Cout, 1 if flip else 0, ptr(img), stream())
+        return (K, Cout, Cin), img
+    wt = (w3.flip(0) if flip else w3).transpose(1, 2).contiguous()
+    return (K, Cout, Cin), wt
+
+
 @torch.no_grad()
-def _conv_on_table(feats, n_out, nbr, weight, precision=None):
-    """out [n_out, Cout] = sum_k feats[nbr[:, k]] @ weight[k] for an explicit neighbour table (None = identity, K == 1)"""
+def _conv_on_table(feats, n_out, nbr, weight, precision=None, bf16_image=None):
+    """out [n_out, Cout] = sum_k feats[nbr[:, k]] @ weight[k] for an explicit neighbour table (None = identity, K == 1);
+    bf16_image: ((K, Cin, Cout), prepared image) instead of `weight` (precision "bf16")"""
+    if bf16_image is not None:
+        (K, Cin, Cout), image = bf16_image
+        assert _precision(precision) == "bf16" and Cin % 32 == 0
+        out = torch.empty((n_out, Cout), dtype=torch.float32, device=feats.device)
+        if n_out == 0:
+            return out
+        ws_bytes = _lib.load().cnrma_sparse_conv_workspace_bytes(n_out, Cout, K)
+        ws = _workspace(ws_bytes, feats.device) if ws_bytes else None
+        call("cnrma_sparse_conv_bf16", ptr(feats.contiguous().float()), Cin, ptr(nbr), K, ptr(image), Cout,
+             None, None, None, 0, ptr(out), n_out, None, ptr(ws), ws_bytes, stream())
+        return out
     w = weight.detach().contiguous().float()
     if w.dim() == 2:
         w = w.unsqueeze(0)
@@ -874,15 +898,22 @@ def _conv_on_table(feats, n_out, nbr, weight, precision=None):
     return out
 
 
+WGRAD_BLOCKS = 1024     # blocks (of 8 waves) the weight-gradient launch aims for
+WGRAD_GO = "auto"       # bf16 weight gradient on the tile unions (cnrma_sparse_conv_wgrad_go_bf16): "auto" / True / False
+WGRAD_GO_BLOCKS = 512   # blocks that launch aims for (two per CU)
+WGRAD_GO_MIN_ROWS = 256
+DGRAD_MIRROR = True     # data gradient of a same-coordinates convolution on the forward table (mirrored offsets)
+
+
 class _ConvFn(torch.autograd.Function):
     """sum_k F[nbr[:, k]] @ W[k] with gradients: dgrad = the same convolution of grad_out over the transposed table with
     W[k]^T, wgrad = cnrma_sparse_conv_wgrad_f32."""
 
     @staticmethod
-    def forward(ctx, F, weight, nbr, n_out, precision):
+    def forward(ctx, F, weight, nbr, n_out, precision, symmetric=False, sets=None):
         ctx.save_for_backward(F, weight)
         precision = _precision(precision)          # resolved here: the backward runs outside the autocast region
-        ctx.nbr, ctx.n_out, ctx.precision = nbr, n_out, precision
+        ctx.nbr, ctx.n_out, ctx.precision, ctx.symmetric, ctx.sets = nbr, n_out, precision, symmetric, sets
         # the Parameter object itself goes down (its prepared image is cached on it until the optimiser changes it)
         return _conv_on_table(F.detach().float(), n_out, nbr, weight, precision)
 
@@ -897,29 +928,57 @@ class _ConvFn(torch.autograd.Function):
         n_in = F.shape[0]
         grad_F = grad_W = None
         if ctx.needs_input_grad[0]:
-            if nbr is None:
-                grad_F = _conv_on_table(g, n_in, None, w3.transpose(1, 2).contiguous(), ctx.precision)
+            # same coordinates on both sides (odd kernel, stride 1): nbr_t[i][k] = nbr[i][K - 1 - k] -- the forward table
+            # with the offsets of the weights mirrored; else the table is transposed by a kernel
+            flip = bool(ctx.symmetric and nbr is not None and n_in == n_out and DGRAD_MIRROR)
+            if nbr is None or flip:
+                nbr_t = nbr
             else:
                 nbr_t = torch.empty((n_in, K), dtype=torch.int32, device=g.device)
                 if n_in and n_out:
                     call("cnrma_sparse_kernel_map_transpose", ptr(nbr), n_out, None, K, n_in, ptr(nbr_t), stream())
                 else:
                     nbr_t.fill_(-1)
-                grad_F = _conv_on_table(g, n_in, nbr_t, w3.transpose(1, 2).contiguous(), ctx.precision)
-        if ctx.needs_input_grad[1]:
-            # one wave per (row chunk, offset, 64x64 weight tile): size the chunks for ~8 waves per SIMD (latency hiding)
+            shape_t, wt = _dgrad_weights(w3, flip, ctx.precision)
+            if wt.dtype == torch.uint8:
+                grad_F = _conv_on_table(g, n_in, nbr_t, None, ctx.precision, bf16_image=(shape_t, wt))
+            else:
+                grad_F = _conv_on_table(g, n_in, nbr_t, wt, ctx.precision)
+        if ctx.needs_input_grad[1] and _wgrad_go(ctx, K, Cin, Cout):
+            # bf16, 27 offsets, compact rows: on the tile unions of the forward's gather-once structure (cached on the
+            # coordinate set: the convolutions of a residual stage share them)
+            in_cs, out_cs, ksize = ctx.sets
+            tu = tile_union(in_cs, out_cs, ksize, in_cs.stride)
+            per = 4 * ((Cin + 63) // 64) * ((Cout + 63) // 64)
+            parts = max(1, min((n_out + 63) // 64, WGRAD_GO_BLOCKS // per))
+            slabs = torch.empty((parts, K, Cin, Cout), dtype=torch.float32, device=g.device)
+            call("cnrma_sparse_conv_wgrad_go_bf16", ptr(F.detach().contiguous().float()), Cin, ptr(tu), ptr(g), Cout, n_out, None,
+                 parts, ptr(slabs), stream())
+            grad_W = (slabs[0] if parts == 1 else slabs.sum(dim=0)).view(weight.shape)
+        elif ctx.needs_input_grad[1]:
+            # one block of 8 waves per (row chunk, offset, 64x64 weight tile), one slab per block: chunks sized for ~1024
+            # blocks (8 waves per SIMD over the launch), at least 8 steps of 32 rows each
             tiles = ((Cin + 63) // 64) * ((Cout + 63) // 64)
-            want = max(1, 8192 // (K * tiles))
-            rows = max(64, -(-max(n_out, 1) // want))
-            rows += rows & 1
+            want = max(1, WGRAD_BLOCKS // (K * tiles))
+            rows = max(256, -(-max(n_out, 1) // want))
+            rows = (rows + 31) // 32 * 32
             chunks = _lib.load().cnrma_sparse_conv_wgrad_chunks(max(n_out, 1), rows)
-            slabs = torch.zeros((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
+            # the kernel writes every element of every slab
+            slabs = (torch.empty if n_out else torch.zeros)((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
             if n_out:
                 # under autocast(bf16) the weight gradient is a bf16 x bf16 -> fp32 reduction too (what AMP computes)
                 call("cnrma_sparse_conv_wgrad_bf16" if ctx.precision == "bf16" else "cnrma_sparse_conv_wgrad_f32",
                      ptr(F.detach().contiguous().float()), Cin, ptr(nbr), K, ptr(g), Cout, n_out, None, rows, ptr(slabs), stream())
-            grad_W = slabs.sum(dim=0).view(weight.shape)
-        return grad_F, grad_W, None, None, None
+            grad_W = (slabs[0] if chunks == 1 else slabs.sum(dim=0)).view(weight.shape)
+        return grad_F, grad_W, None, None, None, None, None
+
+
+def _wgrad_go(ctx, K, Cin, Cout):
+    """weight gradient on the gather-once structure: bf16 mode, a 27-offset table between known coordinate sets whose rows
+    are compact (WGRAD_GO "auto") -- a tile's offsets then share most of their input rows; True / False force the choice"""
+    if ctx.precision != "bf16" or ctx.sets is None or K != 27 or ctx.n_out == 0 or Cin % 4 or Cout % 4 or WGRAD_GO is False:
+        return False
+    return True if WGRAD_GO is True else bool(ctx.sets[0].compact and ctx.n_out >= WGRAD_GO_MIN_ROWS)
 
 
 def conv_autograd(x, weight, kernel_size=3, stride=1, precision=None):
@@ -930,7 +989,8 @@ def conv_autograd(x, weight, kernel_size=3, stride=1, precision=None):
     out_cs = in_cs if stride == 1 else in_cs.strided(stride)
     nbr = None if (kernel_size == 1 and stride == 1) else in_cs.neighbours(out_cs, kernel_size, in_cs.stride)
     assert (weight.shape[0] if weight.dim() == 3 else 1) == K
-    out = _ConvFn.apply(x.F, weight, nbr, out_cs.n, precision)
+    out = _ConvFn.apply(x.F, weight, nbr, out_cs.n, precision, out_cs is in_cs and kernel_size % 2 == 1,
+                        (in_cs, out_cs, kernel_size) if K == 27 else None)
     return SparseTensor(out, out_cs)
 
 

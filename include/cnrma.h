@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 4   /* 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
+#define CNRMA_ABI_VERSION 5   /* 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16; 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
 
 int cnrma_abi_version(void);
 
@@ -491,6 +491,12 @@ int cnrma_sparse_convtr_gen_f16x3(const int32_t* in_coords, const float* in_feat
  * fp32 [K][Cin][Cout] -> bf16 [K][Cin/32][Cout_p][32].  Same arguments / epilogue as cnrma_sparse_conv_f32 otherwise. */
 size_t cnrma_sparse_conv_bf16_weight_bytes(int K, int Cin, int Cout);
 int cnrma_sparse_conv_prepare_weights_bf16(const float* weight, int K, int Cin, int Cout, void* weight_bf16, void* stream);
+/* the image of the data gradient's weights straight from W: Wd[k] = W[flip ? K - 1 - k : k]^T ([Cout] -> [Cin]; needs
+ * Cout % 32 == 0; cnrma_sparse_conv_bf16_weight_bytes(K, Cout, Cin) bytes).  flip = 1: for a convolution whose output
+ * coordinates ARE its input coordinates (odd kernel, stride 1) the transposed neighbour table is the table with its
+ * offsets mirrored, nbr_t[i][k] = nbr[i][K - 1 - k] -- the data gradient runs on the forward table with these weights */
+int cnrma_sparse_conv_prepare_weights_bf16_t(const float* weight, int K, int Cin, int Cout, int flip, void* weight_bf16,
+                                             void* stream);
 int cnrma_sparse_conv_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const void* weight_bf16, int Cout,
                            const float* scale, const float* shift, const float* residual, int act, float* out_feats,
                            int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
@@ -500,7 +506,10 @@ int cnrma_sparse_conv_bf16(const float* in_feats, int Cin, const int32_t* nbr, i
  *   gradient is then the forward convolution of grad_out over nbr_t with the per-offset transposed weights.
  * cnrma_sparse_conv_wgrad_f32: slabs[chunk][K][Cin][Cout] = sum over the chunk's output rows o of
  *   in_feats[nbr[o][k]]^T (x) grad_out[o] (fp32 MFMA); the weight gradient is the sum of the
- *   cnrma_sparse_conv_wgrad_chunks(no_cap, rows_per_chunk) slabs.  nbr == NULL: identity map (K == 1). */
+ *   cnrma_sparse_conv_wgrad_chunks(no_cap, rows_per_chunk) slabs.  nbr == NULL: identity map (K == 1).
+ *   One block of 8 waves per (chunk, offset, 64 x 64 tile), the waves' partial tiles added in a fixed order: every
+ *   element of every slab is written (no clearing needed), the result does not depend on scheduling; rows_per_chunk even,
+ *   >= 256 keeps all waves busy. */
 int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K, int64_t n_in,
                                       int32_t* nbr_t, void* stream);
 int cnrma_sparse_conv_wgrad_chunks(int64_t no_cap, int rows_per_chunk);
@@ -510,6 +519,15 @@ int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const int32_t* n
  * gradient of a torch.autocast(bfloat16) training step, as AMP computes it */
 int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out, int Cout,
                                  int64_t no_cap, const int32_t* no_dev, int rows_per_chunk, float* slabs, void* stream);
+
+/* the bf16 weight gradient of a 27-offset convolution on the gather-once structure of its forward
+ * (cnrma_sparse_tile_union_build over the same neighbour table): slabs[part][27][Cin][Cout], part = a range of
+ * ceil(tiles / parts) 64-row tiles; the weight gradient is the sum of the `parts` slabs, every element of which is written.
+ * A block stages a tile's distinct input rows and its grad_out rows once in LDS (bf16, transposed) and runs 7 offsets over
+ * them, one per wave; the accumulators live across the part's tiles.  Cin % 4 == Cout % 4 == 0.  Operands rounded to bf16,
+ * fp32 accumulation: same products as cnrma_sparse_conv_wgrad_bf16, summed in another (fixed) order. */
+int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, const void* tile_union, const float* grad_out, int Cout,
+                                    int64_t no_cap, const int32_t* no_dev, int parts, float* slabs, void* stream);
 
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */

@@ -68,6 +68,43 @@ def test_bf16_weight_gradient_equals_fp32_accumulation_of_bf16_operands(device, 
     np.testing.assert_allclose(got, gW, rtol=2e-5, atol=2e-5 * np.abs(gW).max())
     err = np.abs(got - gW_exact).max() / np.abs(gW_exact).max()
     assert 1e-5 < err < 2e-2                                   # bf16 operands: visible, bounded
+    # the data gradient: grad_out and W rounded to bf16, fp32 accumulation -- at stride 1 on the forward table with the
+    # offsets of the weight image mirrored (cnrma_sparse_conv_prepare_weights_bf16_t), else on the transposed table
+    if cout % 32 == 0:
+        assert "cnrma_sparse_conv_prepare_weights_bf16_t" in calls
+        assert ("cnrma_sparse_kernel_map_transpose" in calls) == (stride != 1)
+    gF, _ = SO.conv_backward(c, f, _bf16_round(W), _bf16_round(g), 3, stride, 2, out_coords=oc)
+    gF_exact, _ = SO.conv_backward(c, f, W, g, 3, stride, 2, out_coords=oc)
+    got_f = x.F.grad.cpu().numpy()
+    if cout % 32 == 0:
+        np.testing.assert_allclose(got_f, gF, rtol=2e-5, atol=2e-5 * np.abs(gF).max())
+    assert np.abs(got_f - gF_exact).max() / np.abs(gF_exact).max() < 2e-2
+
+
+def test_mirrored_data_gradient_equals_the_transposed_table(device):
+    """stride-1 convolution: the data gradient on the forward table with mirrored weight offsets is the one over the
+    transposed table, bit for bit (same products, same order over k reversed -> compared at 1e-6), in fp32 and bf16"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(77)
+    c = np.unique(np.concatenate((rng.randint(0, 2, size=(6000, 1)), rng.randint(-12, 12, size=(6000, 3))), axis=1), axis=0)
+    f = rng.randn(len(c), 64).astype(np.float32)
+    W = (rng.randn(27, 64, 64) / 20).astype(np.float32)
+    g = rng.randn(len(c), 64).astype(np.float32)
+    grads = {}
+    for prec in ("f32", "bf16"):
+        for mirror in (True, False):
+            S.DGRAD_MIRROR = mirror
+            try:
+                x = S.SparseTensor(torch.from_numpy(f).to(device).requires_grad_(True),
+                                   S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 1))
+                Wd = torch.from_numpy(W).to(device).requires_grad_(True)
+                y = S.conv_autograd(x, Wd, 3, 1, precision=prec)
+                y.F.backward(torch.from_numpy(g).to(device))
+                grads[prec, mirror] = x.F.grad.cpu().numpy()
+            finally:
+                S.DGRAD_MIRROR = True
+        a, b = grads[prec, True], grads[prec, False]
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), prec
 
 
 def test_train_step_under_bf16_autocast_tracks_the_fp32_step(device, tmp_path):
@@ -235,3 +272,50 @@ def test_batch_norm_train_kernels_match_torch(device, n, C):
     np.testing.assert_allclose(got.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(got.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), rtol=1e-4, atol=1e-6)
     assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,cout,stride,morton", [(64, 64, 1, True), (64, 64, 1, False), (32, 64, 2, True), (128, 96, 1, True),
+                                                    (256, 128, 1, False), (36, 20, 1, True)])
+def test_gather_once_weight_gradient_equals_the_block_kernel(device, cin, cout, stride, morton):
+    """cnrma_sparse_conv_wgrad_go_bf16 (tile unions: compact Morton rows = one group per tile, shuffled rows = several) against
+    the block kernel on the same operands -- same bf16 products, another summation order -- and against the fp64 oracle"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + cout + stride)
+    c = np.unique(np.concatenate((rng.randint(0, 2, size=(9000, 1)), rng.randint(-14, 14, size=(9000, 3)) * 2), axis=1), axis=0)
+    if morton:
+        key = (c[:, 0].astype(np.int64) << 60)
+        cc = ((c[:, 1:] + 64) // 2).astype(np.int64)
+        for b in range(8):
+            for a in range(3):
+                key |= ((cc[:, a] >> b) & 1) << (3 * b + 2 - a)
+        c = c[np.argsort(key, kind="stable")]
+    else:
+        c = c[rng.permutation(len(c))]
+    f = rng.randn(len(c), cin).astype(np.float32)
+    W = (rng.randn(27, cin, cout) / 20).astype(np.float32)
+    got = {}
+    g = None
+    for go in (True, False):
+        S.WGRAD_GO = go
+        try:
+            x = S.SparseTensor(torch.from_numpy(f).to(device).requires_grad_(True), S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 2))
+            Wd = torch.from_numpy(W).to(device).requires_grad_(True)
+            y = S.conv_autograd(x, Wd, 3, stride, precision="bf16")
+            if g is None:
+                g = rng.randn(*y.F.shape).astype(np.float32)
+            calls = []
+            orig = S.call
+            S.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+            try:
+                y.F.backward(torch.from_numpy(g).to(device))
+            finally:
+                S.call = orig
+            assert ("cnrma_sparse_conv_wgrad_go_bf16" in calls) == go and ("cnrma_sparse_conv_wgrad_bf16" in calls) == (not go)
+            got[go] = Wd.grad.cpu().numpy()
+            oc = y.C.cpu().numpy().astype(np.int64)
+        finally:
+            S.WGRAD_GO = "auto"
+    scale = np.abs(got[False]).max()
+    assert np.abs(got[True] - got[False]).max() <= 2e-5 * scale
+    _, gW = SO.conv_backward(c, _bf16_round(f), W, _bf16_round(g), 3, stride, 2, out_coords=oc)
+    np.testing.assert_allclose(got[True], gW, rtol=2e-5, atol=2e-5 * np.abs(gW).max())
