@@ -4008,15 +4008,21 @@ static int launch_wgrad(const float* in_feats, int Cin, const int32_t* nbr, int 
 // offsets + local indices) remove both: a block stages the tile's union rows (one 64-channel slice, bf16) and its 64
 // grad_out rows ONCE in LDS, transposed ([channel][row]: the MFMA's reduction dimension is the row, so a lane's 8 values of
 // a fragment are 8 rows of ONE channel -- contiguous for grad_out, an indexed 2-byte read per row for the input), and
-// seven waves run one offset each over the image: A[ci][row r] = image[ci][lidx[r][k]], a missing neighbour indexes a zero
-// column.  A block owns (part = a range of tiles, 7 of the 27 offsets, 64 x 64 tile of the matrix) and keeps its accumulators over
+// seven waves run two offsets each over the image: A[ci][row r] = image[ci][lidx[r][k]], a missing neighbour indexes a zero
+// column.  A block owns (part = a range of tiles, 14 of the 27 offsets, 64 x 64 tile of the matrix) and keeps its accumulators over
 // all tiles of the part: one slab per part, every element written by exactly one wave, no reduction inside the block.
 constexpr int WGO_PITCH = 290;      // u16 per channel of the input image: 280 union rows + the zero column (280) -> 145 dwords: odd,
                                     // consecutive channels (the lanes of a fragment read) fall into distinct banks
 constexpr int WGO_BP = 72;          // u16 per channel of the grad_out image: 64 rows + 8 (144 B: 16-byte aligned fragment reads)
-constexpr int WGO_KPB = 7;          // offsets per block (one per wave; the eighth wave only stages)
-constexpr int WGO_KG = 4;           // offset groups: 4 x 7 >= 27
-struct WgoMap { int parts, tiles_per_part, n_ci, n_co, by_part; };
+constexpr int WGO_KPW = 2;          // offsets per consumer wave (two accumulator sets: 128 registers)
+constexpr int WGO_CW = 7;           // consumer waves: 14 offsets per block
+constexpr int WGO_PW = 5;           // producer waves: 320 threads stage the next tile while the consumers run this one
+constexpr int WGO_KPB = WGO_KPW * WGO_CW;
+constexpr int WGO_KG = 2;           // offset groups: 2 x 14 >= 27
+constexpr int WGO_PT = 64 * WGO_PW;
+constexpr int WGO_IT = (GO_UMAX / 2 * 16 + WGO_PT - 1) / WGO_PT;   // (row pair, 4 channels) tasks per producer thread: 7
+static_assert(WGO_PT % 16 == 0, "a producer thread keeps its channel quad over its tasks");
+struct WgoMap { int parts, tiles_per_part, n_ci, n_co, by_part, ablate; };
 typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
@@ -4024,14 +4030,23 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-__global__ __launch_bounds__(512, 4) void conv_wgrad_go_kernel(const float* __restrict__ in, int Cin, const float* __restrict__ gout,
-                                                               int Cout, int64_t no_cap, const int32_t* __restrict__ no_dev,
-                                                               const int32_t* __restrict__ hdr, const int32_t* __restrict__ urows,
-                                                               const uint16_t* __restrict__ lidx, float* __restrict__ slab,
-                                                               WgoMap map) {
-  __shared__ __attribute__((aligned(16))) uint16_t At[64 * WGO_PITCH];
-  __shared__ __attribute__((aligned(16))) uint16_t Bt[64 * WGO_BP];
-  __shared__ __attribute__((aligned(16))) uint16_t Ls[8 * 64];
+// Roles: the dependent chain header -> union row numbers -> rows -> LDS costs three round trips per tile; done in place by
+// the waves that also hold the accumulators it took 6-8 us per tile and block against 2 us of LDS reads + MFMAs (measured with
+// the phases switched off one at a time, scripts/wgrad_go_ablate.py; a register pipeline in the same waves spilled and its
+// scratch reloads wait for vmcnt(0), i.e. for the very loads they were meant to overlap).  So the block is split:
+//   5 producer waves stage tile t + 1 into the other half of a double-buffered image (their registers hold nothing else);
+//   7 consumer waves run their 2 offsets each over tile t;
+// one barrier per stage: after barrier s the consumers read buffer s & 1 while the producers fill buffer (s + 1) & 1.
+// A stage = (tile, offset group); compact tiles have one group.  The producers publish {live, offset mask} per stage; a zero
+// `live` ends the consumers' loop (both sides pass the same number of barriers).
+__global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kernel(
+    const float* __restrict__ in, int Cin, const float* __restrict__ gout, int Cout, int64_t no_cap,
+    const int32_t* __restrict__ no_dev, const int32_t* __restrict__ hdr, const int32_t* __restrict__ urows,
+    const uint16_t* __restrict__ lidx, float* __restrict__ slab, WgoMap map) {
+  __shared__ __attribute__((aligned(16))) uint16_t At[2][64 * WGO_PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t Bt[2][64 * WGO_BP];
+  __shared__ __attribute__((aligned(16))) uint16_t Ls[2][WGO_KPB * 64];
+  __shared__ int meta[2][2];
   const int per = WGO_KG * map.n_ci * map.n_co;
   const unsigned bid = blockIdx.x;
   int part, rem;
@@ -4048,124 +4063,233 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_go_kernel(const float* __re
   const int64_t n_tiles = (n_live + GO_BM - 1) / GO_BM;
   const int64_t t_begin = (int64_t)part * map.tiles_per_part;
   const int64_t t_end = min(n_tiles, t_begin + map.tiles_per_part);
-  const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, kh = lane >> 5;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int k = g * WGO_KPB + wave;
-  const bool has_k = wave < WGO_KPB && k < 27;
   const unsigned kmask_block = (((1u << WGO_KPB) - 1u) << (g * WGO_KPB)) & ((1u << 27) - 1u);
+  for (int i = tid; i < 2 * 64 * (WGO_PITCH - GO_UMAX); i += 64 * (WGO_CW + WGO_PW)) {   // the zero columns (+ padding) of both images
+    const int bufi = i / (64 * (WGO_PITCH - GO_UMAX)), e = i % (64 * (WGO_PITCH - GO_UMAX));
+    At[bufi][(e / (WGO_PITCH - GO_UMAX)) * WGO_PITCH + GO_UMAX + e % (WGO_PITCH - GO_UMAX)] = 0;
+  }
+  __syncthreads();
+
+  if (wave >= WGO_CW) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    // The producers run their own pipeline, one stage deep on each level of the dependent chain: while image t is being
+    // written, the rows of tile t + 1 are already requested (right after the last LDS store of tile t, before the barrier:
+    // their flight overlaps the wait for the consumers), and header + union row numbers of tile t + 2 behind them.
+    // Only a tile's first offset group rides the pipeline; further groups (a tile without locality) are staged in place.
+    const int ptid = tid - 64 * WGO_CW;
+    const int aq = ptid & 15, ac = ci0 + 4 * aq, bc = co0 + 4 * aq;  // this thread's 4 channels / 4 columns
+    const bool okc = ac < Cin, okb = bc < Cout;
+    const int acs = okc ? ac : 0;
+    int stage = 0;
+    int4 h_i = make_int4(0, 0, 0, 0);      // header {groups, mask, first (0), rows} of the tile whose row numbers are in id0 / id1
+    int32_t id0[WGO_IT], id1[WGO_IT];
+    int4 h_r = make_int4(0, 0, 0, 0);      // header of the tile whose rows are in f0 / f1 / gb0 / gb1 / lsv
+    float4 f0[WGO_IT], f1[WGO_IT], gb0[2], gb1[2];
+    uint16_t lsv[3];
+    auto load_ids = [&](int64_t tile) {    // header + first group's row numbers (entry 0 on: no dependency on the header)
+      if (tile >= t_end) { h_i = make_int4(0, 0, 0, 0); return; }
+      h_i = *reinterpret_cast<const int4*>(hdr + tile * GO_HDR);
+      const int32_t* tr = urows + tile * GO_ROWS;
+#pragma unroll
+      for (int it = 0; it < WGO_IT; ++it) {
+        const int u = 2 * ((ptid + it * WGO_PT) >> 4);               // < 280: inside the tile's GO_ROWS entries whatever its count
+        id0[it] = tr[u]; id1[it] = tr[u + 1];
+      }
+    };
+    auto load_tile_rows = [&](int64_t tile, int rows_here) {         // grad_out tile + the block's 14 columns of local indices
+      const int64_t tile0 = tile * GO_BM;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {                                  // task = (row pair, 4 columns), 512 tasks
+        const int bt = ptid + e * WGO_PT, br = 2 * (bt >> 4);
+        gb0[e] = make_float4(0.f, 0.f, 0.f, 0.f); gb1[e] = gb0[e];
+        if (bt < 512 && okb && br < rows_here) gb0[e] = *reinterpret_cast<const float4*>(gout + (tile0 + br) * Cout + bc);
+        if (bt < 512 && okb && br + 1 < rows_here) gb1[e] = *reinterpret_cast<const float4*>(gout + (tile0 + br + 1) * Cout + bc);
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int idx = ptid + e * WGO_PT, kk = idx >> 6, r = idx & 63, kg = g * WGO_KPB + kk;
+        lsv[e] = (uint16_t)GO_UMAX;
+        if (kk < WGO_KPB && kg < 27 && r < rows_here) lsv[e] = lidx[tile * (GO_BM * 27) + r * 27 + kg];
+      }
+    };
+    auto load_rows = [&](int64_t tile) {   // the rows of `tile` by the numbers in id0 / id1 (h_i -> h_r)
+      h_r = h_i;
+      if (tile >= t_end) return;
+      const int cnt = h_i.w;
+      if (!(map.ablate & 1024)) {
+#pragma unroll
+        for (int it = 0; it < WGO_IT; ++it) {                        // entries beyond the list: row 0 (a valid address), zeroed at the store
+          const int u = 2 * ((ptid + it * WGO_PT) >> 4);
+          const int32_t ra = u < cnt ? id0[it] : 0, rb = u + 1 < cnt ? id1[it] : 0;
+          f0[it] = *reinterpret_cast<const float4*>(in + (int64_t)ra * Cin + acs);
+          f1[it] = *reinterpret_cast<const float4*>(in + (int64_t)rb * Cin + acs);
+        }
+      }
+      load_tile_rows(tile, (int)min((int64_t)GO_BM, n_live - tile * GO_BM));
+    };
+    // LDS stores off ONE base per image and constant offsets (a thread's tasks are 20 row pairs apart, its 4 channels one
+    // channel pitch): the compiler otherwise keeps 39 precomputed addresses in registers -- and spills
+    static_assert(WGO_PT / 16 == 20 && WGO_PITCH % 2 == 0 && WGO_BP % 2 == 0, "store offsets");
+    auto store_tile_rows = [&](int buf) {
+      unsigned* bb = reinterpret_cast<unsigned*>(Bt[buf]) + (4 * aq) * (WGO_BP / 2) + (ptid >> 4);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (ptid + e * WGO_PT < 512) {
+          bb[0 * (WGO_BP / 2) + 20 * e] = pack_bf16x2(gb0[e].x, gb1[e].x);
+          bb[1 * (WGO_BP / 2) + 20 * e] = pack_bf16x2(gb0[e].y, gb1[e].y);
+          bb[2 * (WGO_BP / 2) + 20 * e] = pack_bf16x2(gb0[e].z, gb1[e].z);
+          bb[3 * (WGO_BP / 2) + 20 * e] = pack_bf16x2(gb0[e].w, gb1[e].w);
+        }
+      }
+      uint16_t* lb = Ls[buf] + ptid;
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        if (ptid + e * WGO_PT < WGO_KPB * 64) lb[e * WGO_PT] = lsv[e];                       // [offset][row]
+    };
+    auto store_rows = [&](int buf) {
+      const int cnt = h_r.w;
+      store_tile_rows(buf);
+      unsigned* ab = reinterpret_cast<unsigned*>(At[buf]) + (4 * aq) * (WGO_PITCH / 2) + (ptid >> 4);
+      const int u_base = 2 * (ptid >> 4);
+#pragma unroll
+      for (int it = 0; it < WGO_IT; ++it) {
+        const int u = u_base + 40 * it;
+        if (u < cnt) {
+          const bool k1 = okc && u + 1 < cnt;
+          ab[0 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].x : 0.f, k1 ? f1[it].x : 0.f);
+          ab[1 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].y : 0.f, k1 ? f1[it].y : 0.f);
+          ab[2 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].z : 0.f, k1 ? f1[it].z : 0.f);
+          ab[3 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].w : 0.f, k1 ? f1[it].w : 0.f);
+        }
+      }
+    };
+    load_ids(t_begin);
+    load_rows(t_begin);
+    load_ids(t_begin + 1);
+    for (int64_t tile = t_begin; tile < t_end; ++tile) {
+      const int ng = h_r.x;
+      const unsigned mask0 = (unsigned)h_r.y;
+      const bool live0 = ng > 0 && (mask0 & kmask_block) != 0u;
+      if (live0 && !(map.ablate & 512)) store_rows(stage & 1);
+      load_rows(tile + 1);                                           // requested before the barrier: in flight while we wait
+      load_ids(tile + 2);
+      if (live0) {
+        if (ptid == 0) { meta[stage & 1][0] = 1; meta[stage & 1][1] = (int)mask0; }
+        __syncthreads();                                             // barrier `stage`: this image is complete
+        ++stage;
+      }
+      if (ng > 1) {                                                  // the other groups of a tile without locality: in place
+        const int64_t tile0 = tile * GO_BM;
+        const int rows_here = (int)min((int64_t)GO_BM, n_live - tile0);
+        const int32_t* th = hdr + tile * GO_HDR;
+        for (int gi = 1; gi < ng; ++gi) {
+          const unsigned mask = (unsigned)th[1 + 3 * gi];
+          if ((mask & kmask_block) == 0u) continue;                  // block-uniform
+          const int first = th[2 + 3 * gi], cnt = th[3 + 3 * gi];
+          const int32_t* tr = urows + tile * GO_ROWS + first;
+          const int buf = stage & 1;
+          unsigned* b32 = reinterpret_cast<unsigned*>(Bt[buf]);
+          for (int bt = ptid; bt < 512; bt += WGO_PT) {
+            const int br = 2 * (bt >> 4);
+            float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+            if (okb && br < rows_here) x0 = *reinterpret_cast<const float4*>(gout + (tile0 + br) * Cout + bc);
+            if (okb && br + 1 < rows_here) x1 = *reinterpret_cast<const float4*>(gout + (tile0 + br + 1) * Cout + bc);
+            b32[((4 * aq + 0) * WGO_BP + br) >> 1] = pack_bf16x2(x0.x, x1.x);
+            b32[((4 * aq + 1) * WGO_BP + br) >> 1] = pack_bf16x2(x0.y, x1.y);
+            b32[((4 * aq + 2) * WGO_BP + br) >> 1] = pack_bf16x2(x0.z, x1.z);
+            b32[((4 * aq + 3) * WGO_BP + br) >> 1] = pack_bf16x2(x0.w, x1.w);
+          }
+          for (int idx = ptid; idx < WGO_KPB * 64; idx += WGO_PT) {
+            const int kk = idx >> 6, r = idx & 63, kg = g * WGO_KPB + kk;
+            Ls[buf][idx] = kg < 27 && r < rows_here ? lidx[tile * (GO_BM * 27) + r * 27 + kg] : (uint16_t)GO_UMAX;
+          }
+          unsigned* a32 = reinterpret_cast<unsigned*>(At[buf]);
+          const int tasks = ((cnt + 1) >> 1) * 16;
+          for (int task = ptid; task < tasks; task += WGO_PT) {
+            const int u = 2 * (task >> 4);
+            const int32_t r0 = tr[u], r1 = u + 1 < cnt ? tr[u + 1] : -1;
+            const float4 x0 = *reinterpret_cast<const float4*>(in + (int64_t)r0 * Cin + acs);
+            const float4 x1 = *reinterpret_cast<const float4*>(in + (int64_t)(r1 >= 0 ? r1 : r0) * Cin + acs);
+            const bool k1 = okc && r1 >= 0;
+            a32[((4 * aq + 0) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.x : 0.f, k1 ? x1.x : 0.f);
+            a32[((4 * aq + 1) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.y : 0.f, k1 ? x1.y : 0.f);
+            a32[((4 * aq + 2) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.z : 0.f, k1 ? x1.z : 0.f);
+            a32[((4 * aq + 3) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.w : 0.f, k1 ? x1.w : 0.f);
+          }
+          if (ptid == 0) { meta[buf][0] = 1; meta[buf][1] = (int)mask; }
+          __syncthreads();
+          ++stage;
+        }
+      }
+    }
+    if (ptid == 0) meta[stage & 1][0] = 0;
+    __syncthreads();
+    return;
+  }
+
+  // -------------------------------------------------- consumers --------------------------------------------------
+  const int lane = tid & 63, m = lane & 31, kh = lane >> 5;
+  const int k0 = g * WGO_KPB + WGO_KPW * wave;
+  const bool has0 = k0 < 27, has1 = k0 + 1 < 27;
   const bool two_ci = Cin - ci0 > 32;                                // a 32-channel layer: the second half tile stays out
-  for (int i = tid; i < 64 * (WGO_PITCH - GO_UMAX); i += 512)        // the zero column (and the padding behind it)
-    At[(i / (WGO_PITCH - GO_UMAX)) * WGO_PITCH + GO_UMAX + i % (WGO_PITCH - GO_UMAX)] = 0;
-  f32x16 acc[2][2];
+  f32x16 acc[WGO_KPW][2][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int e = 0; e < WGO_KPW; ++e)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-  for (int64_t tile = t_begin; tile < t_end; ++tile) {
-    const int64_t tile0 = tile * GO_BM;
-    const int rows_here = (int)min((int64_t)GO_BM, n_live - tile0);
-    const int32_t* th = hdr + tile * GO_HDR;
-    const int ng = th[0];
-    bool first_stage = true;
-    for (int gi = 0; gi < ng; ++gi) {
-      const unsigned mask = (unsigned)th[1 + 3 * gi];
-      if ((mask & kmask_block) == 0u) continue;                      // block-uniform
-      const int first = th[2 + 3 * gi], cnt = th[3 + 3 * gi];
-      // the global loads of a stage are issued together, ahead of the LDS stores: union row numbers, then (one round trip
-      // later) the rows -- <= 5 (row pair, 4 channels) tasks per thread, in two batches of 3 + 2 (registers) -- and, for a
-      // new tile, the grad_out tile + the local indices with the first batch
-      const int32_t* tr = urows + tile * GO_ROWS + first;
-      const int tasks = ((cnt + 1) >> 1) * 16;
-      const bool stage_b = first_stage;
-      first_stage = false;
-      const int aq = tid & 15, ac = ci0 + 4 * aq;
-      const bool okc = ac < Cin;
-      unsigned* a32 = reinterpret_cast<unsigned*>(At);
-      auto batch = [&](auto nconst, int it0, bool with_b) {
-        constexpr int N = decltype(nconst)::value;
-        int32_t r0[N], r1[N];
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int it = 0; it < N; ++it) {
-          const int task = tid + (it0 + it) * 512, u = 2 * (task >> 4);
-          r0[it] = task < tasks ? tr[u] : -1;
-          r1[it] = task < tasks && u + 1 < cnt ? tr[u + 1] : -1;
-        }
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-        uint16_t lsv = (uint16_t)GO_UMAX;
-        const int brp = tid >> 4, bq = tid & 15, br = 2 * brp, bc = co0 + 4 * bq;
-        if (with_b) {                                                // grad_out tile: thread = (row pair, 4 columns)
-          if (bc < Cout && br < rows_here) g0 = *reinterpret_cast<const float4*>(gout + (tile0 + br) * Cout + bc);
-          if (bc < Cout && br + 1 < rows_here) g1 = *reinterpret_cast<const float4*>(gout + (tile0 + br + 1) * Cout + bc);
-          const int kk = tid >> 6, r = tid & 63, kg = g * WGO_KPB + kk;  // the block's 7 columns of the local indices
-          if (kk < WGO_KPB && kg < 27 && r < rows_here) lsv = lidx[tile * (GO_BM * 27) + r * 27 + kg];
-        }
-        float4 f0[N], f1[N];
+        for (int i = 0; i < 16; ++i) acc[e][a][b][i] = 0.0f;
+  for (int stage = 0;; ++stage) {
+    __syncthreads();                                                 // barrier `stage`
+    const int buf = stage & 1;
+    if (meta[buf][0] == 0) break;
+    const unsigned mask = (unsigned)meta[buf][1];
+    const bool do0 = has0 && ((mask >> k0) & 1u), do1 = has1 && ((mask >> (k0 + 1)) & 1u);
+    if ((!do0 && !do1) || (map.ablate & 256)) continue;
+    const uint16_t* A = At[buf];
+    const uint16_t* B = Bt[buf];
+    const uint16_t* L = Ls[buf];
+#pragma unroll 1
+    for (int t4 = 0; t4 < 4; ++t4) {
+      const bf16x8_t fb0 = *reinterpret_cast<const bf16x8_t*>(&B[m * WGO_BP + 16 * t4 + 8 * kh]);
+      const bf16x8_t fb1 = *reinterpret_cast<const bf16x8_t*>(&B[(32 + m) * WGO_BP + 16 * t4 + 8 * kh]);
 #pragma unroll
-        for (int it = 0; it < N; ++it) {                             // clamped (valid) addresses, zeroed below
-          f0[it] = *reinterpret_cast<const float4*>(in + (int64_t)(r0[it] >= 0 ? r0[it] : 0) * Cin + (okc ? ac : 0));
-          f1[it] = *reinterpret_cast<const float4*>(in + (int64_t)(r1[it] >= 0 ? r1[it] : 0) * Cin + (okc ? ac : 0));
-        }
-        if (it0 == 0) __syncthreads();                               // the readers of the previous image are done
-        if (with_b) {
-          unsigned* b32 = reinterpret_cast<unsigned*>(Bt);
-          b32[((4 * bq + 0) * WGO_BP + br) >> 1] = pack_bf16x2(g0.x, g1.x);
-          b32[((4 * bq + 1) * WGO_BP + br) >> 1] = pack_bf16x2(g0.y, g1.y);
-          b32[((4 * bq + 2) * WGO_BP + br) >> 1] = pack_bf16x2(g0.z, g1.z);
-          b32[((4 * bq + 3) * WGO_BP + br) >> 1] = pack_bf16x2(g0.w, g1.w);
-          if (tid < WGO_KPB * 64) Ls[tid] = lsv;                     // [offset][row]
-        }
+      for (int e = 0; e < WGO_KPW; ++e) {
+        if (!(e == 0 ? do0 : do1)) continue;
+        const u16x8_t lv = *reinterpret_cast<const u16x8_t*>(&L[(WGO_KPW * wave + e) * 64 + 16 * t4 + 8 * kh]);
 #pragma unroll
-        for (int it = 0; it < N; ++it) {
-          const int task = tid + (it0 + it) * 512, u = 2 * (task >> 4);
-          if (task < tasks) {
-            const bool k0 = okc, k1 = okc && r1[it] >= 0;
-            a32[((4 * aq + 0) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].x : 0.f, k1 ? f1[it].x : 0.f);
-            a32[((4 * aq + 1) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].y : 0.f, k1 ? f1[it].y : 0.f);
-            a32[((4 * aq + 2) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].z : 0.f, k1 ? f1[it].z : 0.f);
-            a32[((4 * aq + 3) * WGO_PITCH + u) >> 1] = pack_bf16x2(k0 ? f0[it].w : 0.f, k1 ? f1[it].w : 0.f);
-          }
-        }
-      };
-      static_assert(GO_UMAX / 2 * 16 <= 5 * 512, "five tasks per thread cover the largest union");
-      batch(std::integral_constant<int, 3>{}, 0, stage_b);
-      if (tasks > 3 * 512) batch(std::integral_constant<int, 2>{}, 3, false);
-      __syncthreads();
-      if (has_k && ((mask >> k) & 1u)) {
+        for (int x = 0; x < 2; ++x) {
+          if (x == 1 && !two_ci) continue;
+          u16x8_t ra;
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          const u16x8_t lv = *reinterpret_cast<const u16x8_t*>(&Ls[wave * 64 + 16 * t4 + 8 * kh]);
-          const bf16x8_t fb0 = *reinterpret_cast<const bf16x8_t*>(&Bt[m * WGO_BP + 16 * t4 + 8 * kh]);
-          const bf16x8_t fb1 = *reinterpret_cast<const bf16x8_t*>(&Bt[(32 + m) * WGO_BP + 16 * t4 + 8 * kh]);
-          u16x8_t ra0, ra1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ra0[j] = At[m * WGO_PITCH + lv[j]];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra0), fb0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra0), fb1, acc[0][1], 0, 0, 0);
-          if (two_ci) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ra1[j] = At[(32 + m) * WGO_PITCH + lv[j]];
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra1), fb0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra1), fb1, acc[1][1], 0, 0, 0);
-          }
+          for (int j = 0; j < 8; ++j) ra[j] = A[(32 * x + m) * WGO_PITCH + lv[j]];
+          if (map.ablate & 2048) continue;                           // diagnostics: the LDS reads without the MFMAs
+          acc[e][x][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra), fb0, acc[e][x][0], 0, 0, 0);
+          acc[e][x][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra), fb1, acc[e][x][1], 0, 0, 0);
         }
       }
     }
   }
-  if (!has_k) return;
-  float* dst = slab + ((int64_t)part * 27 + k) * Cin * Cout;
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int e = 0; e < WGO_KPW; ++e) {
+    if (!(e == 0 ? has0 : has1)) continue;
+    float* dst = slab + ((int64_t)part * 27 + k0 + e) * Cin * Cout;
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int co = co0 + y * 32 + m;
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
-        if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[x][y][i];
+      for (int y = 0; y < 2; ++y) {
+        const int co = co0 + y * 32 + m;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+          if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[e][x][y][i];
+        }
       }
-    }
+  }
 }
 
 extern "C" int cnrma_sparse_kernel_map_transpose(const int32_t* nbr, int64_t no_cap, const int32_t* no_dev, int K,
@@ -4967,10 +5091,11 @@ extern "C" int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, c
   map.n_ci = (int)ceil_div(Cin, 64);
   map.n_co = (int)ceil_div(Cout, 64);
   map.by_part = parts >= 16;
+  map.ablate = g_conv_tune.ablate;
   const int64_t per = (int64_t)WGO_KG * map.n_ci * map.n_co;
   const int64_t blocks = (map.by_part ? ceil_div(parts, 8) * 8 : (int64_t)parts) * per;
   if (blocks > 0x7fffffffLL) return CNRMA_EINVAL;
-  hipLaunchKernelGGL(conv_wgrad_go_kernel, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), in_feats, Cin, grad_out, Cout,
+  hipLaunchKernelGGL(conv_wgrad_go_kernel, dim3((unsigned)blocks), dim3(64 * (WGO_CW + WGO_PW)), 0, as_stream(stream), in_feats, Cin, grad_out, Cout,
                      no_cap, no_dev, hdr, rows, lidx, slabs, map);
   CNRMA_LAUNCH_CHECK();
   return 0;

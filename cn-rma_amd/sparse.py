@@ -900,7 +900,7 @@ def _conv_on_table(feats, n_out, nbr, weight, precision=None, bf16_image=None):
 
 WGRAD_BLOCKS = 1024     # blocks (of 8 waves) the weight-gradient launch aims for
 WGRAD_GO = "auto"       # bf16 weight gradient on the tile unions (cnrma_sparse_conv_wgrad_go_bf16): "auto" / True / False
-WGRAD_GO_BLOCKS = 512   # blocks that launch aims for (two per CU)
+WGRAD_GO_BLOCKS = 256   # blocks that launch aims for (one per CU: 256 registers per lane)
 WGRAD_GO_MIN_ROWS = 256
 DGRAD_MIRROR = True     # data gradient of a same-coordinates convolution on the forward table (mirrored offsets)
 
@@ -949,7 +949,7 @@ class _ConvFn(torch.autograd.Function):
             # coordinate set: the convolutions of a residual stage share them)
             in_cs, out_cs, ksize = ctx.sets
             tu = tile_union(in_cs, out_cs, ksize, in_cs.stride)
-            per = 4 * ((Cin + 63) // 64) * ((Cout + 63) // 64)
+            per = 2 * ((Cin + 63) // 64) * ((Cout + 63) // 64)
             parts = max(1, min((n_out + 63) // 64, WGRAD_GO_BLOCKS // per))
             slabs = torch.empty((parts, K, Cin, Cout), dtype=torch.float32, device=g.device)
             call("cnrma_sparse_conv_wgrad_go_bf16", ptr(F.detach().contiguous().float()), Cin, ptr(tu), ptr(g), Cout, n_out, None,
