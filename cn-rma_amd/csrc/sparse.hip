@@ -4007,12 +4007,15 @@ static int launch_wgrad(const float* in_feats, int Cin, const int32_t* nbr, int 
 // The tile unions of the forward convolution (tile_union_kernel: per 64-row output tile the DISTINCT input rows of its 27
 // offsets + local indices) remove both: a block stages the tile's union rows (one 64-channel slice, bf16) and its 64
 // grad_out rows ONCE in LDS, transposed ([channel][row]: the MFMA's reduction dimension is the row, so a lane's 8 values of
-// a fragment are 8 rows of ONE channel -- contiguous for grad_out, an indexed 2-byte read per row for the input), and
+// a fragment are 8 rows of ONE channel -- contiguous for grad_out, an indexed read per row for the input: a dword = one channel PAIR), and
 // seven waves run two offsets each over the image: A[ci][row r] = image[ci][lidx[r][k]], a missing neighbour indexes a zero
 // column.  A block owns (part = a range of tiles, 14 of the 27 offsets, 64 x 64 tile of the matrix) and keeps its accumulators over
 // all tiles of the part: one slab per part, every element written by exactly one wave, no reduction inside the block.
-constexpr int WGO_PITCH = 290;      // u16 per channel of the input image: 280 union rows + the zero column (280) -> 145 dwords: odd,
-                                    // consecutive channels (the lanes of a fragment read) fall into distinct banks
+constexpr int WGO_PITCH = 289;      // DWORDS per channel pair of the input image: 280 union rows + the zero column (280); odd: the 32
+                                    // channel pairs a fragment read touches fall into distinct banks.  A dword holds the bf16
+                                    // values of channels 2m (low half) and 2m + 1 of one union row: the two 32-channel halves
+                                    // of the A operand come out of ONE indexed read per row (the reads bound the consumers:
+                                    // 2-byte reads, one per half, took 2.9 us per tile against 0.4 us of MFMAs)
 constexpr int WGO_BP = 72;          // u16 per channel of the grad_out image: 64 rows + 8 (144 B: 16-byte aligned fragment reads)
 constexpr int WGO_KPW = 2;          // offsets per consumer wave (two accumulator sets: 128 registers)
 constexpr int WGO_CW = 7;           // consumer waves: 14 offsets per block
@@ -4043,7 +4046,7 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
     const float* __restrict__ in, int Cin, const float* __restrict__ gout, int Cout, int64_t no_cap,
     const int32_t* __restrict__ no_dev, const int32_t* __restrict__ hdr, const int32_t* __restrict__ urows,
     const uint16_t* __restrict__ lidx, float* __restrict__ slab, WgoMap map) {
-  __shared__ __attribute__((aligned(16))) uint16_t At[2][64 * WGO_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned At[2][32 * WGO_PITCH];
   __shared__ __attribute__((aligned(16))) uint16_t Bt[2][64 * WGO_BP];
   __shared__ __attribute__((aligned(16))) uint16_t Ls[2][WGO_KPB * 64];
   __shared__ int meta[2][2];
@@ -4066,9 +4069,9 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned kmask_block = (((1u << WGO_KPB) - 1u) << (g * WGO_KPB)) & ((1u << 27) - 1u);
-  for (int i = tid; i < 2 * 64 * (WGO_PITCH - GO_UMAX); i += 64 * (WGO_CW + WGO_PW)) {   // the zero columns (+ padding) of both images
-    const int bufi = i / (64 * (WGO_PITCH - GO_UMAX)), e = i % (64 * (WGO_PITCH - GO_UMAX));
-    At[bufi][(e / (WGO_PITCH - GO_UMAX)) * WGO_PITCH + GO_UMAX + e % (WGO_PITCH - GO_UMAX)] = 0;
+  for (int i = tid; i < 2 * 32 * (WGO_PITCH - GO_UMAX); i += 64 * (WGO_CW + WGO_PW)) {   // the zero columns (+ padding) of both images
+    const int bufi = i / (32 * (WGO_PITCH - GO_UMAX)), e = i % (32 * (WGO_PITCH - GO_UMAX));
+    At[bufi][(e / (WGO_PITCH - GO_UMAX)) * WGO_PITCH + GO_UMAX + e % (WGO_PITCH - GO_UMAX)] = 0u;
   }
   __syncthreads();
 
@@ -4131,7 +4134,7 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
     };
     // LDS stores off ONE base per image and constant offsets (a thread's tasks are 20 row pairs apart, its 4 channels one
     // channel pitch): the compiler otherwise keeps 39 precomputed addresses in registers -- and spills
-    static_assert(WGO_PT / 16 == 20 && WGO_PITCH % 2 == 0 && WGO_BP % 2 == 0, "store offsets");
+    static_assert(WGO_PT / 16 == 20 && WGO_BP % 2 == 0, "store offsets");
     auto store_tile_rows = [&](int buf) {
       unsigned* bb = reinterpret_cast<unsigned*>(Bt[buf]) + (4 * aq) * (WGO_BP / 2) + (ptid >> 4);
 #pragma unroll
@@ -4151,17 +4154,17 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
     auto store_rows = [&](int buf) {
       const int cnt = h_r.w;
       store_tile_rows(buf);
-      unsigned* ab = reinterpret_cast<unsigned*>(At[buf]) + (4 * aq) * (WGO_PITCH / 2) + (ptid >> 4);
+      unsigned* ab = At[buf] + (2 * aq) * WGO_PITCH + 2 * (ptid >> 4);    // channel pairs 2 aq, 2 aq + 1; rows u, u + 1
       const int u_base = 2 * (ptid >> 4);
 #pragma unroll
       for (int it = 0; it < WGO_IT; ++it) {
         const int u = u_base + 40 * it;
         if (u < cnt) {
           const bool k1 = okc && u + 1 < cnt;
-          ab[0 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].x : 0.f, k1 ? f1[it].x : 0.f);
-          ab[1 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].y : 0.f, k1 ? f1[it].y : 0.f);
-          ab[2 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].z : 0.f, k1 ? f1[it].z : 0.f);
-          ab[3 * (WGO_PITCH / 2) + 20 * it] = pack_bf16x2(okc ? f0[it].w : 0.f, k1 ? f1[it].w : 0.f);
+          ab[40 * it] = pack_bf16x2(okc ? f0[it].x : 0.f, okc ? f0[it].y : 0.f);
+          ab[40 * it + 1] = pack_bf16x2(k1 ? f1[it].x : 0.f, k1 ? f1[it].y : 0.f);
+          ab[WGO_PITCH + 40 * it] = pack_bf16x2(okc ? f0[it].z : 0.f, okc ? f0[it].w : 0.f);
+          ab[WGO_PITCH + 40 * it + 1] = pack_bf16x2(k1 ? f1[it].z : 0.f, k1 ? f1[it].w : 0.f);
         }
       }
     };
@@ -4205,7 +4208,7 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
             const int kk = idx >> 6, r = idx & 63, kg = g * WGO_KPB + kk;
             Ls[buf][idx] = kg < 27 && r < rows_here ? lidx[tile * (GO_BM * 27) + r * 27 + kg] : (uint16_t)GO_UMAX;
           }
-          unsigned* a32 = reinterpret_cast<unsigned*>(At[buf]);
+          unsigned* a32 = At[buf];
           const int tasks = ((cnt + 1) >> 1) * 16;
           for (int task = ptid; task < tasks; task += WGO_PT) {
             const int u = 2 * (task >> 4);
@@ -4213,10 +4216,10 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
             const float4 x0 = *reinterpret_cast<const float4*>(in + (int64_t)r0 * Cin + acs);
             const float4 x1 = *reinterpret_cast<const float4*>(in + (int64_t)(r1 >= 0 ? r1 : r0) * Cin + acs);
             const bool k1 = okc && r1 >= 0;
-            a32[((4 * aq + 0) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.x : 0.f, k1 ? x1.x : 0.f);
-            a32[((4 * aq + 1) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.y : 0.f, k1 ? x1.y : 0.f);
-            a32[((4 * aq + 2) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.z : 0.f, k1 ? x1.z : 0.f);
-            a32[((4 * aq + 3) * WGO_PITCH + u) >> 1] = pack_bf16x2(okc ? x0.w : 0.f, k1 ? x1.w : 0.f);
+            a32[(2 * aq) * WGO_PITCH + u] = pack_bf16x2(okc ? x0.x : 0.f, okc ? x0.y : 0.f);
+            a32[(2 * aq) * WGO_PITCH + u + 1] = pack_bf16x2(k1 ? x1.x : 0.f, k1 ? x1.y : 0.f);
+            a32[(2 * aq + 1) * WGO_PITCH + u] = pack_bf16x2(okc ? x0.z : 0.f, okc ? x0.w : 0.f);
+            a32[(2 * aq + 1) * WGO_PITCH + u + 1] = pack_bf16x2(k1 ? x1.z : 0.f, k1 ? x1.w : 0.f);
           }
           if (ptid == 0) { meta[buf][0] = 1; meta[buf][1] = (int)mask; }
           __syncthreads();
@@ -4233,7 +4236,6 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
   const int lane = tid & 63, m = lane & 31, kh = lane >> 5;
   const int k0 = g * WGO_KPB + WGO_KPW * wave;
   const bool has0 = k0 < 27, has1 = k0 + 1 < 27;
-  const bool two_ci = Cin - ci0 > 32;                                // a 32-channel layer: the second half tile stays out
   f32x16 acc[WGO_KPW][2][2];
 #pragma unroll
   for (int e = 0; e < WGO_KPW; ++e)
@@ -4250,10 +4252,10 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
     const unsigned mask = (unsigned)meta[buf][1];
     const bool do0 = has0 && ((mask >> k0) & 1u), do1 = has1 && ((mask >> (k0 + 1)) & 1u);
     if ((!do0 && !do1) || (map.ablate & 256)) continue;
-    const uint16_t* A = At[buf];
+    const unsigned* A = At[buf] + m * WGO_PITCH;
     const uint16_t* B = Bt[buf];
     const uint16_t* L = Ls[buf];
-#pragma unroll 1
+#pragma unroll
     for (int t4 = 0; t4 < 4; ++t4) {
       const bf16x8_t fb0 = *reinterpret_cast<const bf16x8_t*>(&B[m * WGO_BP + 16 * t4 + 8 * kh]);
       const bf16x8_t fb1 = *reinterpret_cast<const bf16x8_t*>(&B[(32 + m) * WGO_BP + 16 * t4 + 8 * kh]);
@@ -4261,16 +4263,20 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
       for (int e = 0; e < WGO_KPW; ++e) {
         if (!(e == 0 ? do0 : do1)) continue;
         const u16x8_t lv = *reinterpret_cast<const u16x8_t*>(&L[(WGO_KPW * wave + e) * 64 + 16 * t4 + 8 * kh]);
+        unsigned w[8];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          if (x == 1 && !two_ci) continue;
-          u16x8_t ra;
+        for (int j = 0; j < 8; ++j) w[j] = A[lv[j]];                 // channels 2m | 2m + 1 of row j's neighbour
+        if (map.ablate & 2048) continue;                             // diagnostics: the LDS reads without the MFMAs
+        u32x4_t ra0, ra1;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) ra[j] = A[(32 * x + m) * WGO_PITCH + lv[j]];
-          if (map.ablate & 2048) continue;                           // diagnostics: the LDS reads without the MFMAs
-          acc[e][x][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra), fb0, acc[e][x][0], 0, 0, 0);
-          acc[e][x][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra), fb1, acc[e][x][1], 0, 0, 0);
+        for (int jj = 0; jj < 4; ++jj) {
+          ra0[jj] = __builtin_amdgcn_perm(w[2 * jj + 1], w[2 * jj], 0x05040100u);     // low halves
+          ra1[jj] = __builtin_amdgcn_perm(w[2 * jj + 1], w[2 * jj], 0x07060302u);     // high halves
         }
+        acc[e][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra0), fb0, acc[e][0][0], 0, 0, 0);
+        acc[e][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra0), fb1, acc[e][0][1], 0, 0, 0);
+        acc[e][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra1), fb0, acc[e][1][0], 0, 0, 0);
+        acc[e][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ra1), fb1, acc[e][1][1], 0, 0, 0);
       }
     }
   }
@@ -4285,7 +4291,7 @@ __global__ __launch_bounds__(64 * (WGO_CW + WGO_PW), 3) void conv_wgrad_go_kerne
         const int co = co0 + y * 32 + m;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int ci = ci0 + x * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+          const int ci = ci0 + 2 * (8 * (i >> 2) + 4 * kh + (i & 3)) + x;        // matrix row r of tile x = channel 2 r + x
           if (ci < Cin && co < Cout) dst[(int64_t)ci * Cout + co] = acc[e][x][y][i];
         }
       }

@@ -950,7 +950,11 @@ class _ConvFn(torch.autograd.Function):
             in_cs, out_cs, ksize = ctx.sets
             tu = tile_union(in_cs, out_cs, ksize, in_cs.stride)
             per = 2 * ((Cin + 63) // 64) * ((Cout + 63) // 64)
-            parts = max(1, min((n_out + 63) // 64, WGRAD_GO_BLOCKS // per))
+            tiles = (n_out + 63) // 64
+            # parts: a block takes ~2.9 us per tile of its part, a part costs its slab written and read back (~3 TB/s):
+            # T(parts) = tiles / parts * 2.9 + parts * slab_us, at most one block per CU
+            slab_us = 27 * Cin * Cout * 8 / 3e6
+            parts = max(1, min(tiles, WGRAD_GO_BLOCKS // per, int(round((tiles * 2.9 / slab_us) ** 0.5))))
             slabs = torch.empty((parts, K, Cin, Cout), dtype=torch.float32, device=g.device)
             call("cnrma_sparse_conv_wgrad_go_bf16", ptr(F.detach().contiguous().float()), Cin, ptr(tu), ptr(g), Cout, n_out, None,
                  parts, ptr(slabs), stream())
@@ -978,7 +982,15 @@ def _wgrad_go(ctx, K, Cin, Cout):
     are compact (WGRAD_GO "auto") -- a tile's offsets then share most of their input rows; True / False force the choice"""
     if ctx.precision != "bf16" or ctx.sets is None or K != 27 or ctx.n_out == 0 or Cin % 4 or Cout % 4 or WGRAD_GO is False:
         return False
-    return True if WGRAD_GO is True else bool(ctx.sets[0].compact and ctx.n_out >= WGRAD_GO_MIN_ROWS)
+    if WGRAD_GO is True:
+        return True
+    in_cs, out_cs, _ = ctx.sets
+    # a coarsening convolution whose outputs merge several inputs each reads ~27 DISTINCT rows per output: the unions of its
+    # tiles do not fit the image (many offset groups, staged in place) -- the block kernel is the faster one there
+    # (measured at S: 64 -> 128 over 72.9 k -> 11.2 k rows 150 us against 49).  A stride over a sparse sample merges nothing.
+    if out_cs is not in_cs and in_cs.n > 1.6 * ctx.n_out:
+        return False
+    return bool(in_cs.compact and ctx.n_out >= WGRAD_GO_MIN_ROWS)
 
 
 def conv_autograd(x, weight, kernel_size=3, stride=1, precision=None):
