@@ -2454,11 +2454,34 @@ __device__ __forceinline__ void go_load_frag(u32x4_t (&b)[2][2], const uint16_t*
                : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[1][0]), "=&v"(b[1][1]) : "v"(voff), "s"(sbase));
 }
 
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// the single-plane (bf16) variant: two loads per fragment (k-steps), the second plane's registers never named
+template <int N>
+__device__ __forceinline__ void go_waitn1(u32x4_t (&b)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0][0]), "+v"(b[0][1]) : "n"(N));
+}
+__device__ __forceinline__ void go_drain1(u32x4_t (&b)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]));
+}
+__device__ __forceinline__ void go_load_frag1(u32x4_t (&b)[2][2], const uint16_t* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\t"
+               "global_load_dwordx4 %0, %2, %3 offset:0\n\t"
+               "global_load_dwordx4 %1, %2, %3 offset:1024"
+               : "=&v"(b[0][0]), "=&v"(b[0][1]) : "v"(voff), "s"(sbase));
+}
+
 constexpr int GO2_US = (GO_UMAX + 2) * LDK;              // 16-bit elements of one plane of the image
 constexpr int GO2_RS = 288;                             // row numbers parked per tile (>= GO_UMAX; two loads per thread)
 constexpr int GO2_LDS = 2 * GO2_US * 2 + GO_BM * 27 * 2 + GO2_RS * 4;      // bytes: two planes, local indices, row numbers
 
-template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false>
+// BF1: ONE bf16 plane per operand (round to nearest, no scaling), one MFMA per product on v_mfma_f32_32x32x16_bf16 -- the
+// arithmetic of cnrma_sparse_conv_bf16 (autocast training) on the gather-once structure; weight image
+// [k][slice][column tile][k-step][lane][8] (cnrma_sparse_conv_prepare_weights_bf16_frag)
+template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false, bool BF1 = false>
 __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_go2_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag,
                                                                              Go2Map mp) {
   static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
@@ -2504,8 +2527,8 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
   const bool use_scale = p.scale != nullptr && p.splits == 1, use_shift = p.shift != nullptr && p.splits == 1;
   const float sc = use_scale ? p.scale[colc] : 1.0f;
   const float sh = use_shift ? p.shift[colc] : 0.0f;
-  const float a_scale = f16_scale_for(read_amax(p.in_amax));
-  const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
+  const float a_scale = BF1 ? 1.0f : f16_scale_for(read_amax(p.in_amax));
+  const float out_scale = BF1 ? 1.0f : 1.0f / (a_scale * f16_scale_for(*p.w_amax));
   if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls)[tid] = lv;
   Rs[tid] = rn0;
   if (tid < GO2_RS - 256) Rs[256 + tid] = rn1;
@@ -2527,10 +2550,11 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
   const unsigned lane16 = (unsigned)lane * 16u;
   const uint16_t* ls0 = Ls + (lane & 31) * 27;               // this lane's rows of the local indices: row, row + 32
   auto load_b = [&](u32x4_t (&bf)[2][2], int k, int slice) {
-    const uint64_t ba = reinterpret_cast<uint64_t>(wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc) * 2048);
+    const uint64_t ba = reinterpret_cast<uint64_t>(wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc) * (BF1 ? 1024 : 2048));
     const uint16_t* base = reinterpret_cast<const uint16_t*>(                          // uniform by construction: say so
         ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ba));
-    go_load_frag(bf, base, lane16);                            // [plane][k-step]: 1024 bytes apart
+    if constexpr (BF1) go_load_frag1(bf, base, lane16);        // [k-step]
+    else go_load_frag(bf, base, lane16);                       // [plane][k-step]: 1024 bytes apart
   };
   auto load_li = [&](int (&li)[TM], int k) {
 #pragma unroll
@@ -2538,6 +2562,24 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
   };
   // one offset: A fragments one ahead of their MFMAs (two registers in rotation), as in the first form
   auto mfma_k = [&](const u32x4_t (&bf)[2][2], const int (&li)[TM]) {
+    if constexpr (BF1) {                                     // one plane, one MFMA per (k-step, row tile); fragments one ahead
+      auto rdb = [&](int a, int ks) -> bf16x8_t {
+        return *reinterpret_cast<const bf16x8_t*>(Us + lds_slot(li[a], ks * 2 + fhalf));
+      };
+      bf16x8_t curb = rdb(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t bb = __builtin_bit_cast(bf16x8_t, bf[0][ks]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+          bf16x8_t nxtb = curb;
+          if (!(ks == 1 && a == TM - 1)) nxtb = a + 1 < TM ? rdb(a + 1, ks) : rdb(0, ks + 1);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(curb, bb, acc[a], 0, 0, 0);
+          curb = nxtb;
+        }
+      }
+      return;
+    }
     auto rd = [&](int a, int pl, int ks) -> f16x8_t {
       return *reinterpret_cast<const f16x8_t*>(Us + pl * GO2_US + lds_slot(li[a], ks * 2 + fhalf));
     };
@@ -2611,11 +2653,15 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
           // every loaded value is consumed on every path (tasks behind the union go to the dump row), see the first form
           const int tk = t0 + i * 256 + tid;
           const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tid & 7;
-          uint2 h, m;
-          split2(v[i], a_scale, h, m);
           __bf16* d = Us + lds_slot(u, kc >> 1) + (kc & 1) * 4;
-          *reinterpret_cast<uint2*>(d) = h;
-          *reinterpret_cast<uint2*>(d + GO2_US) = m;
+          if constexpr (BF1) {
+            *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16x2(v[i].x, v[i].y), pack_bf16x2(v[i].z, v[i].w));
+          } else {
+            uint2 h, m;
+            split2(v[i], a_scale, h, m);
+            *reinterpret_cast<uint2*>(d) = h;
+            *reinterpret_cast<uint2*>(d + GO2_US) = m;
+          }
         }
       }
       __syncthreads();
@@ -2632,7 +2678,8 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
 #pragma unroll
           for (int a = 0; a < TM; ++a) li[a] = lin[a];
           load_li(lin, kk[(j + 1) % NB]);                      // j + 1 < NB: this turn's next offset; else the next turn's first
-          go_waitn<(NB - 1) * 4>(bf[j]);                       // bf[j] has landed; the NB - 1 sets behind it may still fly
+          if constexpr (BF1) go_waitn1<(NB - 1) * 2>(bf[j]);
+          else go_waitn<(NB - 1) * 4>(bf[j]);                  // bf[j] has landed; the NB - 1 sets behind it may still fly
           mfma_k(bf[j], li);
           kk[j] = pop();                                       // behind the last offset: the last one again (never used)
           load_b(bf[j], kk[j], slice);
@@ -2641,7 +2688,10 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
       // the last <= NB offsets: nothing more to prefetch, and NO load may be left in flight (the asm loads are invisible to the
       // compiler, which is free to reuse their destination registers from here on)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) go_drain(bf[j]);
+      for (int j = 0; j < NB; ++j) {
+        if constexpr (BF1) go_drain1(bf[j]);
+        else go_drain(bf[j]);
+      }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         int li[TM];
@@ -4028,11 +4078,6 @@ static_assert(WGO_PT % 16 == 0, "a producer thread keeps its channel quad over i
 struct WgoMap { int parts, tiles_per_part, n_ci, n_co, by_part, ablate; };
 typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-
 // Roles: the dependent chain header -> union row numbers -> rows -> LDS costs three round trips per tile; done in place by
 // the waves that also hold the accumulators it took 6-8 us per tile and block against 2 us of LDS reads + MFMAs (measured with
 // the phases switched off one at a time, scripts/wgrad_go_ablate.py; a register pipeline in the same waves spilled and its
@@ -4865,9 +4910,9 @@ constexpr int GO_FORM_DEFAULT = 1;      // the second form everywhere (scripts/g
                                         // the layer classes of an S scene, never slower than the first form in its best work order)
 static int go_form_default(int64_t no_cap, int Cin, int Cout) { (void)no_cap; (void)Cin; (void)Cout; return GO_FORM_DEFAULT; }
 
-template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false>
+template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false, bool BF1 = false>
 static int launch_go2_one(unsigned blocks, const ConvArgs& p, const GoArgs& g, const uint16_t* wfrag, const Go2Map& mp, hipStream_t st) {
-  hipLaunchKernelGGL((sparse_conv_go2_kernel<WAVES_N, KS, HAS_RES, NB, STAMP>), dim3(blocks), dim3(256), GO2_LDS, st, p, g, wfrag, mp);
+  hipLaunchKernelGGL((sparse_conv_go2_kernel<WAVES_N, KS, HAS_RES, NB, STAMP, BF1>), dim3(blocks), dim3(256), GO2_LDS, st, p, g, wfrag, mp);
   return 0;
 }
 static_assert(GO2_LDS <= 48 * 1024 && 4 * GO2_LDS <= 160 * 1024, "four blocks per CU without raising the dynamic LDS limit");
@@ -4913,7 +4958,8 @@ static Go2Plan go2_plan(int64_t no_cap, int Cin, int Cout, bool has_ws, size_t w
   return pl;
 }
 
-static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, void* stamps, hipStream_t st) {
+static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, void* stamps, hipStream_t st,
+                      bool bf1 = false) {
   const Go2Map& mp = pl.mp;
   g.slices_per_split = pl.slices_per_split;
   p.splits = pl.splits;
@@ -4922,6 +4968,19 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
   const unsigned blocks = pl.blocks;
   const bool has_res = residual && pl.splits == 1;
   int rc = CNRMA_EINVAL;
+  if (bf1) {                                                 // training: no fused residual (conv_reduce_kernel adds one after a split)
+    if (has_res || stamps != nullptr) return CNRMA_EINVAL;
+    rc = pl.bn == 128 ? launch_go2_one<4, 1, false, 2, false, true>(blocks, p, g, wfrag, mp, st)
+                      : launch_go2_one<2, 2, false, 2, false, true>(blocks, p, g, wfrag, mp, st);
+    if (rc != 0) return rc;
+    if (pl.splits > 1) {
+      int64_t rb = ceil_div(p.no_cap * p.Cout / 4 + 1, 256);
+      if (rb > 4096) rb = 4096;
+      hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
+    }
+    CNRMA_LAUNCH_CHECK();
+    return 0;
+  }
 #define CNRMA_GO2(WN, KS_, NB_)                                                                              \
   rc = stamps != nullptr && !has_res ? launch_go2_one<WN, KS_, false, NB_, true>(blocks, p, g, wfrag, mp, st) \
        : has_res ? launch_go2_one<WN, KS_, true, NB_>(blocks, p, g, wfrag, mp, st)                           \
@@ -5125,6 +5184,67 @@ extern "C" int cnrma_sparse_conv_prepare_weights_f16_frag(const float* weight, i
   hipLaunchKernelGGL(prep_weights_f16_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, st, weight, wt, K, Cin, Cout, amax);
   CNRMA_LAUNCH_CHECK();
   return 0;
+}
+
+// W fp32 [K][Cin][Cout] -> bf16 fragment-order image [k][slice][column tile of 32][k-step (2)][lane (64)][8] of
+//   transpose == 0:  W itself;   transpose == 1: the data gradient's weights W'[k] = W[flip ? K - 1 - k : k]^T ([Cout] -> [Cin])
+// (lane = 32 * (kk / 8 % 2) + column % 32, kk = channel inside the slice = 16 * k-step + 8 * (lane / 32) + j: the B operand
+// registers of v_mfma_f32_32x32x16_bf16 -- one contiguous 1-KB load per wave and k-step)
+__global__ __launch_bounds__(256) void prep_weights_bf16_frag_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int K,
+                                                                     int Cin, int Cout, int transpose, int flip) {
+  const int Ci = transpose ? Cout : Cin, Co = transpose ? Cin : Cout;       // the image's input / output channels
+  const int Cp = conv_cout_padded(Co);
+  const int64_t total = (int64_t)K * Ci * Cp;
+  const int ns = Ci / BK, nt = Cp / 32;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(t & 7), lane = (int)((t >> 3) & 63), ks = (int)((t >> 9) & 1);
+    int64_t q = t >> 10;
+    const int tile = (int)(q % nt); q /= nt;
+    const int slice = (int)(q % ns);
+    const int k = (int)(q / ns);
+    const int cin = slice * BK + ks * 16 + (lane >> 5) * 8 + j, co = tile * 32 + (lane & 31);
+    const int ksrc = transpose && flip ? K - 1 - k : k;
+    float v = 0.0f;
+    if (co < Co) v = transpose ? w[((int64_t)ksrc * Cin + co) * Cout + cin] : w[((int64_t)ksrc * Cin + cin) * Cout + co];
+    wt[t] = (__bf16)v;
+  }
+}
+
+extern "C" size_t cnrma_sparse_conv_bf16_frag_weight_bytes(int K, int Cin, int Cout) {
+  return (size_t)K * Cin * conv_cout_padded(Cout) * 2;
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_bf16_frag(const float* weight, int K, int Cin, int Cout, int transpose, int flip,
+                                                           void* weight_frag, void* stream) {
+  if (K <= 0 || Cin <= 0 || Cout <= 0 || (transpose ? Cout : Cin) % BK != 0 || weight == nullptr || weight_frag == nullptr)
+    return CNRMA_EINVAL;
+  const int Ci = transpose ? Cout : Cin, Co = transpose ? Cin : Cout;
+  int64_t blocks = ceil_div((int64_t)K * Ci * conv_cout_padded(Co), 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_weights_bf16_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
+                     reinterpret_cast<__bf16*>(weight_frag), K, Cin, Cout, transpose ? 1 : 0, flip ? 1 : 0);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int cnrma_sparse_conv_go_bf16(const float* in_feats, int Cin, const void* tile_union, const void* weight_frag, int Cout,
+                                         float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (in_feats == nullptr || tile_union == nullptr || weight_frag == nullptr || out_feats == nullptr || Cin <= 0 || Cin % BK != 0 ||
+      Cout < 64 || no_cap <= 0)
+    return CNRMA_EINVAL;
+  const int K = 27;
+  const size_t tiles = (size_t)ceil_div(no_cap, GO_BM);
+  const char* w = reinterpret_cast<const char*>(tile_union);
+  GoArgs g;
+  g.hdr = reinterpret_cast<const int32_t*>(w);      w += go_align(tiles * GO_HDR * 4);
+  g.rows = reinterpret_cast<const int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
+  g.lidx = reinterpret_cast<const uint16_t*>(w);
+  ConvArgs p{in_feats, Cin, nullptr, K, nullptr, Cout, nullptr, nullptr, nullptr, 0, out_feats, no_cap, no_dev, 1, 1, K,
+             reinterpret_cast<float*>(workspace), nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  p.ablate = 0;
+  const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace != nullptr, workspace_bytes);
+  return launch_go2(pl, p, g, reinterpret_cast<const uint16_t*>(weight_frag), false, nullptr, as_stream(stream), true);
 }
 
 extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in_amax, int Cin, const void* tile_union,

@@ -640,6 +640,20 @@ def weights_bf16(weight):
     return _pinned(ws)
 
 
+def weights_bf16_frag(weight):
+    """weight fp32 [27,Cin,Cout] -> the bf16 MFMA-fragment image of cnrma_sparse_conv_go_bf16; cached on the weight tensor"""
+    tag = (weight._version, weight.data_ptr(), weight.device)
+    hit = _cache_get(weight, "_cnrma_bf16_frag")
+    if hit is not None and hit[0] == tag:
+        return _pinned(hit[1])
+    w = weight.detach().contiguous().float()
+    K, Cin, Cout = w.shape
+    ws = torch.empty(_lib.load().cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+    call("cnrma_sparse_conv_prepare_weights_bf16_frag", ptr(w), K, Cin, Cout, 0, 0, ptr(ws), stream())
+    _cache_put(weight, "_cnrma_bf16_frag", (tag, ws))
+    return _pinned(ws)
+
+
 def _precision(precision=None):
     """explicit > torch.autocast(bf16) region (the reference's training configuration: bf16 operands, fp32 accumulation,
     BASELINE configs[4]) > the module default CONV_PRECISION"""
@@ -846,6 +860,31 @@ def conv(x, weight, kernel_size=3, stride=1, scale=None, shift=None, residual=No
     return SparseTensor(out, out_cs, out_split)
 
 
+TRAIN_GO = "auto"       # bf16 training: forward and data gradient of the same-coordinates 3x3x3 convolutions on the gather-once
+                        # kernel (cnrma_sparse_conv_go_bf16) where the inference path would use it; True / False force it
+
+
+def _train_go(sets, n_out, Cin, Cout):
+    """(tile unions, True) when a bf16 convolution of the training step with Cin -> Cout runs on the gather-once kernel"""
+    if sets is None or TRAIN_GO is False or Cin % 32 or Cout < 64 or n_out == 0:
+        return False
+    in_cs, out_cs, ksize = sets
+    if out_cs is not in_cs or ksize != 3:
+        return False
+    return True if TRAIN_GO is True else _gather_once(in_cs, out_cs)
+
+
+def _conv_go_bf16(feats, sets, image, Cin, Cout):
+    in_cs, out_cs, ksize = sets
+    n = out_cs.n
+    out = torch.empty((n, Cout), dtype=torch.float32, device=feats.device)
+    go_ws_bytes = n * Cout * 4 * (Cin // 32) if n < GO_WS_ROWS else 0
+    go_ws = _workspace(go_ws_bytes, feats.device) if go_ws_bytes else None
+    call("cnrma_sparse_conv_go_bf16", ptr(feats.contiguous().float()), Cin, ptr(tile_union(in_cs, out_cs, ksize, in_cs.stride)),
+         ptr(image), Cout, ptr(out), n, None, ptr(go_ws), go_ws_bytes, stream())
+    return out
+
+
 def _dgrad_weights(w3, flip, precision):
     """the weights of the data gradient, W'[k] = W[K - 1 - k if flip else k]^T: under bf16 the prepared image straight
     from W (one kernel; the image cannot be cached -- the optimiser changes W every step), else the fp32 tensor"""
@@ -915,6 +954,10 @@ class _ConvFn(torch.autograd.Function):
         precision = _precision(precision)          # resolved here: the backward runs outside the autocast region
         ctx.nbr, ctx.n_out, ctx.precision, ctx.symmetric, ctx.sets = nbr, n_out, precision, symmetric, sets
         # the Parameter object itself goes down (its prepared image is cached on it until the optimiser changes it)
+        if precision == "bf16" and weight.dim() == 3 and weight.shape[0] == 27 and \
+                _train_go(sets, n_out, weight.shape[1], weight.shape[2]):
+            with torch.no_grad():
+                return _conv_go_bf16(F.detach(), sets, weights_bf16_frag(weight), weight.shape[1], weight.shape[2])
         return _conv_on_table(F.detach().float(), n_out, nbr, weight, precision)
 
     @staticmethod
@@ -939,8 +982,17 @@ class _ConvFn(torch.autograd.Function):
                     call("cnrma_sparse_kernel_map_transpose", ptr(nbr), n_out, None, K, n_in, ptr(nbr_t), stream())
                 else:
                     nbr_t.fill_(-1)
-            shape_t, wt = _dgrad_weights(w3, flip, ctx.precision)
-            if wt.dtype == torch.uint8:
+            if flip and ctx.precision == "bf16" and K == 27 and _train_go(ctx.sets, n_in, Cout, Cin):
+                # the gather-once kernel on the forward's tile unions, weights mirrored + transposed in fragment order
+                img = torch.empty(_lib.load().cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cout, Cin), dtype=torch.uint8, device=g.device)
+                call("cnrma_sparse_conv_prepare_weights_bf16_frag", ptr(w3.contiguous()), K, Cin, Cout, 1, 1, ptr(img), stream())
+                grad_F = _conv_go_bf16(g, ctx.sets, img, Cout, Cin)
+                shape_t = wt = None
+            else:
+                shape_t, wt = _dgrad_weights(w3, flip, ctx.precision)
+            if wt is None:
+                pass
+            elif wt.dtype == torch.uint8:
                 grad_F = _conv_on_table(g, n_in, nbr_t, None, ctx.precision, bf16_image=(shape_t, wt))
             else:
                 grad_F = _conv_on_table(g, n_in, nbr_t, wt, ctx.precision)

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 5   /* 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16; 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
+#define CNRMA_ABI_VERSION 5   /* 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16, cnrma_sparse_conv_go_bf16 (+ its weight image); 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
 
 int cnrma_abi_version(void);
 
@@ -528,6 +528,20 @@ int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* 
  * fp32 accumulation: same products as cnrma_sparse_conv_wgrad_bf16, summed in another (fixed) order. */
 int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, const void* tile_union, const float* grad_out, int Cout,
                                     int64_t no_cap, const int32_t* no_dev, int parts, float* slabs, void* stream);
+
+/* the bf16 convolution (cnrma_sparse_conv_bf16's arithmetic: one bf16 piece per operand, fp32 accumulation) on the
+ * gather-once structure of a 27-offset table (cnrma_sparse_tile_union_build): forward and data gradient of the autocast
+ * training step.  No epilogue (training composes BatchNorm / activations in torch).  Weight image in MFMA-fragment order:
+ *   transpose == 0: W [K][Cin][Cout] as it is (cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cin, Cout) bytes);
+ *   transpose == 1: the data gradient's weights W'[k] = W[flip ? K - 1 - k : k]^T (..._weight_bytes(K, Cout, Cin) bytes);
+ * the image's input width % 32 == 0, its output width >= 64.  workspace (optional): no_cap x Cout x 4 x (Cin / 32) bytes let
+ * short layers split over channel slices. */
+size_t cnrma_sparse_conv_bf16_frag_weight_bytes(int K, int Cin, int Cout);
+int cnrma_sparse_conv_prepare_weights_bf16_frag(const float* weight, int K, int Cin, int Cout, int transpose, int flip,
+                                                void* weight_frag, void* stream);
+int cnrma_sparse_conv_go_bf16(const float* in_feats, int Cin, const void* tile_union, const void* weight_frag, int Cout,
+                              float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* generative transposed convolution k=2 s=2 (fcaf3d_head.py:72-78): 8 children per parent, no overlap.
  * out_coords[8*i+k] = in_coords[i] + {0, half}^3 (k: x fastest); out_feats[8*i+k] = act((in[i] @ W[k])*scale+shift) */

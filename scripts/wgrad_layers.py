@@ -47,7 +47,7 @@ real_call = S.call
 
 
 def timed_call(name, *a):
-    if not name.startswith("cnrma_sparse_conv_wgrad") and name not in ("cnrma_sparse_conv_bf16", "cnrma_sparse_kernel_map_transpose"):
+    if not name.startswith("cnrma_sparse_conv_wgrad") and name not in ("cnrma_sparse_conv_bf16", "cnrma_sparse_conv_go_bf16", "cnrma_sparse_kernel_map_transpose"):
         return real_call(name, *a)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -57,6 +57,8 @@ def timed_call(name, *a):
         rows.append(("wgrad_go", a[1], a[4], 27, a[5], -(-a[5] // a[7]), e0.elapsed_time(e1) * 1e3))
     elif name.startswith("cnrma_sparse_conv_wgrad"):
         rows.append(("wgrad", a[1], a[5], a[3], a[6], a[8], e0.elapsed_time(e1) * 1e3))
+    elif name == "cnrma_sparse_conv_go_bf16":
+        rows.append(("conv_go", a[1], a[4], 27, a[6], 0, e0.elapsed_time(e1) * 1e3))
     elif name == "cnrma_sparse_conv_bf16":
         rows.append(("conv", a[1], a[5], a[3], a[11], 0, e0.elapsed_time(e1) * 1e3))
     else:

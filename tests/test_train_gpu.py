@@ -319,3 +319,41 @@ def test_gather_once_weight_gradient_equals_the_block_kernel(device, cin, cout, 
     assert np.abs(got[True] - got[False]).max() <= 2e-5 * scale
     _, gW = SO.conv_backward(c, _bf16_round(f), W, _bf16_round(g), 3, stride, 2, out_coords=oc)
     np.testing.assert_allclose(got[True], gW, rtol=2e-5, atol=2e-5 * np.abs(gW).max())
+
+
+@pytest.mark.parametrize("cin,cout,n_pts", [(64, 64, 9000), (64, 128, 9000), (128, 64, 2500), (256, 256, 700)])
+def test_gather_once_bf16_forward_and_data_gradient_equal_the_stage_kernel(device, cin, cout, n_pts):
+    """cnrma_sparse_conv_go_bf16 (forward, and the data gradient with the mirrored + transposed fragment image) against
+    cnrma_sparse_conv_bf16 on the same operands -- same bf16 products, another fp32 summation order -- and the forward against
+    the fp64 oracle on the rounded operands; small sets take the split over channel slices"""
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(cin + cout)
+    c = np.unique(np.concatenate((rng.randint(0, 2, size=(n_pts, 1)), rng.randint(-14, 14, size=(n_pts, 3))), axis=1), axis=0)
+    f = rng.randn(len(c), cin).astype(np.float32)
+    W = (rng.randn(27, cin, cout) / 20).astype(np.float32)
+    g = rng.randn(len(c), cout).astype(np.float32)
+    res = {}
+    for go in (True, False):
+        S.TRAIN_GO = go
+        try:
+            x = S.SparseTensor(torch.from_numpy(f).to(device).requires_grad_(True), S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 1))
+            Wd = torch.from_numpy(W).to(device).requires_grad_(True)
+            calls = []
+            orig = S.call
+            S.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
+            try:
+                y = S.conv_autograd(x, Wd, 3, 1, precision="bf16")
+                y.F.backward(torch.from_numpy(g).to(device))
+            finally:
+                S.call = orig
+            assert (calls.count("cnrma_sparse_conv_go_bf16") == 2) == go and ("cnrma_sparse_conv_bf16" in calls) == (not go)
+            res[go] = (y.F.detach().cpu().numpy(), x.F.grad.cpu().numpy(), y.C.cpu().numpy().astype(np.int64))
+        finally:
+            S.TRAIN_GO = "auto"
+    for a, b in zip(res[True][:2], res[False][:2]):
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+    oc, exp = SO.conv(c, _bf16_round(f), _bf16_round(W), 3, 1, 1)
+    got_c = res[True][2]
+    o1, o2 = np.lexsort(got_c.T[::-1]), np.lexsort(oc.T[::-1])
+    assert np.array_equal(got_c[o1], oc[o2])
+    np.testing.assert_allclose(res[True][0][o1], exp[o2], rtol=1e-5, atol=1e-5 * np.abs(exp).max())
