@@ -97,6 +97,7 @@ SIGNATURES = {
     "cnrma_sparse_conv_wgrad_go_bf16": (c_int, [P, I, P, P, I, L, P, I, P, P]),
     "cnrma_sparse_conv_bf16_frag_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights_bf16_frag": (c_int, [P, I, I, I, I, I, P, P]),
+    "cnrma_sparse_conv_prepare_weights_bf16_frag_pair": (c_int, [P, I, I, I, I, P, P, P]),
     "cnrma_sparse_conv_go_bf16": (c_int, [P, I, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_convtr_gen_f32": (c_int, [P, P, L, P, I, I, P, I, P, P, I, P, P, P]),
     "cnrma_sparse_maxpool_f32": (c_int, [P, I, P, I, P, L, P, P]),

@@ -5210,6 +5210,41 @@ __global__ __launch_bounds__(256) void prep_weights_bf16_frag_kernel(const float
   }
 }
 
+// both images of a weight tensor in ONE launch (training: the forward's and the mirrored-transposed one of its data gradient)
+__global__ __launch_bounds__(256) void prep_weights_bf16_frag_pair_kernel(const float* __restrict__ w, __bf16* __restrict__ wf,
+                                                                          __bf16* __restrict__ wtr, int K, int Cin, int Cout, int flip) {
+  const int64_t total_f = (int64_t)K * Cin * conv_cout_padded(Cout), total_t = (int64_t)K * Cout * conv_cout_padded(Cin);
+  for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total_f + total_t; t0 += (int64_t)gridDim.x * blockDim.x) {
+    const bool tr = t0 >= total_f;
+    const int64_t t = tr ? t0 - total_f : t0;
+    const int Ci = tr ? Cout : Cin, Co = tr ? Cin : Cout;
+    const int ns = Ci / BK, nt = conv_cout_padded(Co) / 32;
+    const int j = (int)(t & 7), lane = (int)((t >> 3) & 63), ks = (int)((t >> 9) & 1);
+    int64_t q = t >> 10;
+    const int tile = (int)(q % nt); q /= nt;
+    const int slice = (int)(q % ns);
+    const int k = (int)(q / ns);
+    const int cin = slice * BK + ks * 16 + (lane >> 5) * 8 + j, co = tile * 32 + (lane & 31);
+    const int ksrc = tr && flip ? K - 1 - k : k;
+    float v = 0.0f;
+    if (co < Co) v = tr ? w[((int64_t)ksrc * Cin + co) * Cout + cin] : w[((int64_t)ksrc * Cin + cin) * Cout + co];
+    (tr ? wtr : wf)[t] = (__bf16)v;
+  }
+}
+
+extern "C" int cnrma_sparse_conv_prepare_weights_bf16_frag_pair(const float* weight, int K, int Cin, int Cout, int flip,
+                                                                void* frag_forward, void* frag_transposed, void* stream) {
+  if (K <= 0 || Cin <= 0 || Cout <= 0 || Cin % BK != 0 || Cout % BK != 0 || weight == nullptr || frag_forward == nullptr ||
+      frag_transposed == nullptr)
+    return CNRMA_EINVAL;
+  int64_t blocks = ceil_div((int64_t)K * Cin * conv_cout_padded(Cout) + (int64_t)K * Cout * conv_cout_padded(Cin), 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(prep_weights_bf16_frag_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), weight,
+                     reinterpret_cast<__bf16*>(frag_forward), reinterpret_cast<__bf16*>(frag_transposed), K, Cin, Cout, flip ? 1 : 0);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t cnrma_sparse_conv_bf16_frag_weight_bytes(int K, int Cin, int Cout) {
   return (size_t)K * Cin * conv_cout_padded(Cout) * 2;
 }

@@ -640,18 +640,31 @@ def weights_bf16(weight):
     return _pinned(ws)
 
 
-def weights_bf16_frag(weight):
-    """weight fp32 [27,Cin,Cout] -> the bf16 MFMA-fragment image of cnrma_sparse_conv_go_bf16; cached on the weight tensor"""
+def weights_bf16_frag(weight, transposed=False):
+    """weight fp32 [27,Cin,Cout] -> the bf16 MFMA-fragment image of cnrma_sparse_conv_go_bf16 (transposed: the mirrored +
+    transposed image of the data gradient); cached on the weight tensor.  When both widths allow it the two images are made
+    by ONE launch at the first request of a step -- the forward's, whose host-bound launch stream has room for it"""
     tag = (weight._version, weight.data_ptr(), weight.device)
     hit = _cache_get(weight, "_cnrma_bf16_frag")
-    if hit is not None and hit[0] == tag:
-        return _pinned(hit[1])
+    if hit is not None and hit[0] == tag and hit[1 + int(transposed)] is not None:
+        return _pinned(hit[1 + int(transposed)])
     w = weight.detach().contiguous().float()
     K, Cin, Cout = w.shape
-    ws = torch.empty(_lib.load().cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
-    call("cnrma_sparse_conv_prepare_weights_bf16_frag", ptr(w), K, Cin, Cout, 0, 0, ptr(ws), stream())
-    _cache_put(weight, "_cnrma_bf16_frag", (tag, ws))
-    return _pinned(ws)
+    lib = _lib.load()
+    fwd = hit[1] if hit is not None and hit[0] == tag else None
+    tr = hit[2] if hit is not None and hit[0] == tag else None
+    if Cin % 32 == 0 and Cout % 32 == 0 and Cin >= 64 and fwd is None and tr is None:
+        fwd = torch.empty(lib.cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+        tr = torch.empty(lib.cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cout, Cin), dtype=torch.uint8, device=w.device)
+        call("cnrma_sparse_conv_prepare_weights_bf16_frag_pair", ptr(w), K, Cin, Cout, 1, ptr(fwd), ptr(tr), stream())
+    elif transposed:
+        tr = torch.empty(lib.cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cout, Cin), dtype=torch.uint8, device=w.device)
+        call("cnrma_sparse_conv_prepare_weights_bf16_frag", ptr(w), K, Cin, Cout, 1, 1, ptr(tr), stream())
+    else:
+        fwd = torch.empty(lib.cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cin, Cout), dtype=torch.uint8, device=w.device)
+        call("cnrma_sparse_conv_prepare_weights_bf16_frag", ptr(w), K, Cin, Cout, 0, 0, ptr(fwd), stream())
+    _cache_put(weight, "_cnrma_bf16_frag", (tag, fwd, tr))
+    return _pinned(tr if transposed else fwd)
 
 
 def _precision(precision=None):
@@ -984,9 +997,7 @@ class _ConvFn(torch.autograd.Function):
                     nbr_t.fill_(-1)
             if flip and ctx.precision == "bf16" and K == 27 and _train_go(ctx.sets, n_in, Cout, Cin):
                 # the gather-once kernel on the forward's tile unions, weights mirrored + transposed in fragment order
-                img = torch.empty(_lib.load().cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cout, Cin), dtype=torch.uint8, device=g.device)
-                call("cnrma_sparse_conv_prepare_weights_bf16_frag", ptr(w3.contiguous()), K, Cin, Cout, 1, 1, ptr(img), stream())
-                grad_F = _conv_go_bf16(g, ctx.sets, img, Cout, Cin)
+                grad_F = _conv_go_bf16(g, ctx.sets, weights_bf16_frag(weight, transposed=True), Cout, Cin)
                 shape_t = wt = None
             else:
                 shape_t, wt = _dgrad_weights(w3, flip, ctx.precision)

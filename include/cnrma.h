@@ -539,6 +539,10 @@ int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, const void* 
 size_t cnrma_sparse_conv_bf16_frag_weight_bytes(int K, int Cin, int Cout);
 int cnrma_sparse_conv_prepare_weights_bf16_frag(const float* weight, int K, int Cin, int Cout, int transpose, int flip,
                                                 void* weight_frag, void* stream);
+/* both images of one weight tensor in one launch: the forward's (transpose 0) and the data gradient's (transpose 1, `flip`);
+ * Cin % 32 == Cout % 32 == 0 */
+int cnrma_sparse_conv_prepare_weights_bf16_frag_pair(const float* weight, int K, int Cin, int Cout, int flip,
+                                                     void* frag_forward, void* frag_transposed, void* stream);
 int cnrma_sparse_conv_go_bf16(const float* in_feats, int Cin, const void* tile_union, const void* weight_frag, int Cout,
                               float* out_feats, int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes,
                               void* stream);
