@@ -501,7 +501,9 @@ int cnrma_sparse_conv_bf16(const float* in_feats, int Cin, const int32_t* nbr, i
                            const float* scale, const float* shift, const float* residual, int act, float* out_feats,
                            int64_t no_cap, const int32_t* no_dev, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Backward of the sparse convolution (training).
+/* Backward of the sparse convolution (training): what MinkowskiEngine's autograd runs under the reference's
+ * train step (ray_marching.py:409-451 forward_train -> fcaf3d_backbone.py:59-107 / fcaf3d_head.py:61-139 convolutions ->
+ * loss.backward() in mmcv's optimizer hook) for every ME.MinkowskiConvolution.
  * cnrma_sparse_kernel_map_transpose: nbr_t[n_in][K] with nbr_t[i][k] = o where nbr[o][k] == i (else -1); the data
  *   gradient is then the forward convolution of grad_out over nbr_t with the per-offset transposed weights.
  * cnrma_sparse_conv_wgrad_f32: slabs[chunk][K][Cin][Cout] = sum over the chunk's output rows o of
@@ -520,7 +522,8 @@ int cnrma_sparse_conv_wgrad_f32(const float* in_feats, int Cin, const int32_t* n
 int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* nbr, int K, const float* grad_out, int Cout,
                                  int64_t no_cap, const int32_t* no_dev, int rows_per_chunk, float* slabs, void* stream);
 
-/* the bf16 weight gradient of a 27-offset convolution on the gather-once structure of its forward
+/* (training, the same ME.MinkowskiConvolution backward; reference configuration: fp16 AMP of configs[4] -> bf16 autocast here)
+ * the bf16 weight gradient of a 27-offset convolution on the gather-once structure of its forward
  * (cnrma_sparse_tile_union_build over the same neighbour table): slabs[part][27][Cin][Cout], part = a range of
  * ceil(tiles / parts) 64-row tiles; the weight gradient is the sum of the `parts` slabs, every element of which is written.
  * A block stages a tile's distinct input rows and its grad_out rows once in LDS (bf16, transposed) and runs 7 offsets over
@@ -529,7 +532,9 @@ int cnrma_sparse_conv_wgrad_bf16(const float* in_feats, int Cin, const int32_t* 
 int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, const void* tile_union, const float* grad_out, int Cout,
                                     int64_t no_cap, const int32_t* no_dev, int parts, float* slabs, void* stream);
 
-/* the bf16 convolution (cnrma_sparse_conv_bf16's arithmetic: one bf16 piece per operand, fp32 accumulation) on the
+/* (training: forward and data gradient of the BasicBlock / head 3x3x3 stride-1 ME.MinkowskiConvolution of
+ * fcaf3d_backbone.py:59-87 and fcaf3d_head.py:61-83 under autocast)
+ * the bf16 convolution (cnrma_sparse_conv_bf16's arithmetic: one bf16 piece per operand, fp32 accumulation) on the
  * gather-once structure of a 27-offset table (cnrma_sparse_tile_union_build): forward and data gradient of the autocast
  * training step.  No epilogue (training composes BatchNorm / activations in torch).  Weight image in MFMA-fragment order:
  *   transpose == 0: W [K][Cin][Cout] as it is (cnrma_sparse_conv_bf16_frag_weight_bytes(K, Cin, Cout) bytes);
