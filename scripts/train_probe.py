@@ -56,5 +56,5 @@ if os.environ.get("CNRMA_CPROFILE"):
     for _ in range(3): step()
     torch.cuda.synchronize(); pr.disable()
     st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
-    st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("cumulative").print_stats(110)
 print(f"{shape} ({'bf16 autocast' if AUTOCAST else 'fp32'}): {(time.perf_counter() - t0) / n * 1e3:.1f} ms per training step, loss {l:.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
