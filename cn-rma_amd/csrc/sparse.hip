@@ -3703,6 +3703,123 @@ __global__ __launch_bounds__(256) void bn_backward_apply_kernel(const float* __r
   }
 }
 
+// ---- BatchNorm (training) fused with what follows it in a residual block (round 5): y = [relu]( bn(x) [+ residual] ) ---------------
+// forward: column statistics as above (fp64 sums in a fixed order); the final stage also updates the running statistics
+// (running_var takes the unbiased estimate, as nn.BatchNorm1d) and the batch counter -- eight tiny torch launches otherwise;
+// backward: with a ReLU behind the normalisation the incoming gradient is masked by y > 0 on the fly (y = the saved output),
+// the masked gradient is also the residual branch's gradient.
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ part, int nblk, int C, int64_t n,
+                                                             double* __restrict__ stats, float momentum,
+                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                             int64_t* __restrict__ batches) {
+  const int c = blockIdx.x;
+  __shared__ double ss[256], qq[256];
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) { s += part[(int64_t)b * 2 * C + c]; q += part[(int64_t)b * 2 * C + C + c]; }
+  ss[threadIdx.x] = s; qq[threadIdx.x] = q;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) { ss[threadIdx.x] += ss[threadIdx.x + d]; qq[threadIdx.x] += qq[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double nn = (double)n;
+    const double mean = ss[0] / nn;
+    double var = qq[0] / nn - mean * mean;   // biased variance
+    if (var < 0.0) var = 0.0;
+    stats[c] = mean;
+    stats[C + c] = var;
+    if (running_mean != nullptr) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var != nullptr) running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * (nn / (nn - 1.0)));
+    if (batches != nullptr && c == 0) *batches += 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ in, int64_t n, int C, const double* __restrict__ stats,
+                                                       const float* __restrict__ weight, const float* __restrict__ bias, float eps,
+                                                       const float* __restrict__ residual, int relu, float* __restrict__ out) {
+  const int64_t total4 = n * C / 4;                         // C % 4 == 0 (checked by the entry point)
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((t * 4) % C);
+    const float4 x = reinterpret_cast<const float4*>(in)[t];
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (residual) r = reinterpret_cast<const float4*>(residual)[t];
+    const float xv[4] = {x.x, x.y, x.z, x.w}, rv[4] = {r.x, r.y, r.z, r.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mean = (float)stats[c + j];
+      const float inv = 1.0f / sqrtf((float)stats[C + c + j] + eps);
+      float v = (xv[j] - mean) * inv;
+      if (weight) v = v * weight[c + j];
+      if (bias) v = v + bias[c + j];
+      if (residual) v = v + rv[j];
+      o[j] = relu ? fmaxf(v, 0.0f) : v;
+    }
+    reinterpret_cast<float4*>(out)[t] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// s1 / s2 of the MASKED gradient (y given: dy counts where y > 0)
+__global__ __launch_bounds__(256) void bn_colsum2_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ y, int64_t n, int C,
+                                                                 double* __restrict__ part) {
+  const int c = threadIdx.x % C;
+  const int groups = blockDim.x / C;
+  const int gi = threadIdx.x / C;
+  double s = 0.0, q = 0.0;
+  if (gi < groups) {
+    for (int64_t r = (int64_t)blockIdx.x * groups + gi; r < n; r += (int64_t)gridDim.x * groups) {
+      float gf = dy[r * C + c];
+      if (y != nullptr && !(y[r * C + c] > 0.0f)) gf = 0.0f;
+      const double g = (double)gf;
+      s += g;
+      q += g * (double)x[r * C + c];
+    }
+  }
+  __shared__ double sm[2 * 256];
+  sm[threadIdx.x] = s;
+  sm[256 + threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double ts = 0.0, tq = 0.0;
+    for (int g = 0; g < groups; ++g) { ts += sm[g * C + threadIdx.x]; tq += sm[256 + g * C + threadIdx.x]; }
+    part[(int64_t)blockIdx.x * 2 * C + threadIdx.x] = ts;
+    part[(int64_t)blockIdx.x * 2 * C + C + threadIdx.x] = tq;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_backward_apply2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ y, int64_t n, int C,
+                                                                 const double* __restrict__ stats, const double* __restrict__ sums,
+                                                                 const float* __restrict__ weight, float eps,
+                                                                 float* __restrict__ dx, float* __restrict__ dres) {
+  const int64_t total4 = n * C / 4;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((t * 4) % C);
+    const float4 g4 = reinterpret_cast<const float4*>(dy)[t], x4 = reinterpret_cast<const float4*>(x)[t];
+    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    if (y != nullptr) {
+      const float4 y4 = reinterpret_cast<const float4*>(y)[t];
+      const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (!(yv[j] > 0.0f)) gv[j] = 0.0f;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mean = (float)stats[c + j];
+      const float inv = 1.0f / sqrtf((float)stats[C + c + j] + eps);
+      const float xhat = (xv[j] - mean) * inv;
+      const float g = weight ? weight[c + j] : 1.0f;
+      o[j] = g * inv * (gv[j] - (float)sums[c + j] - xhat * (float)sums[C + c + j]);
+    }
+    reinterpret_cast<float4*>(dx)[t] = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres != nullptr) reinterpret_cast<float4*>(dres)[t] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ in, int64_t n_cap,
                                                      const int32_t* __restrict__ n_dev, int C, float* __restrict__ out) {
   const int64_t n = live_rows(n_cap, n_dev);
@@ -5505,6 +5622,48 @@ extern "C" int cnrma_bn_backward_f32(const float* grad_out, const float* x, int6
                      grad_bias, sums);
   hipLaunchKernelGGL(bn_backward_apply_kernel, dim3(grid_for(n * C, 256, 4096)), dim3(256), 0, st, grad_out, x, n, C, stats,
                      sums, weight, eps, grad_in);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// BatchNorm1d in training mode over the rows of x [n][C] (C <= 256, C % 4 == 0, n >= 2), fused with what follows it in a
+// residual block: out = [relu]( (x - mean) / sqrt(var + eps) * weight + bias [+ residual] ); running statistics and batch
+// counter updated in the statistics kernel (momentum given).  stats_ws: cnrma_instnorm_workspace_bytes(C); on return
+// stats_ws[0..C) = mean, [C..2C) = biased variance (fp64): the backward's `stats`.
+extern "C" int cnrma_bn_train_forward_f32(const float* x, int64_t n, int C, const float* weight, const float* bias, float eps,
+                                          const float* residual, int relu, float momentum, float* running_mean,
+                                          float* running_var, int64_t* num_batches_tracked, float* out, double* stats_ws,
+                                          void* stream) {
+  if (n < 2 || C <= 0 || C > 256 || (C & 3) || x == nullptr || out == nullptr || stats_ws == nullptr) return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = 1024;
+  double* part = stats_ws + 2 * C;
+  hipLaunchKernelGGL(colstats_partial_kernel, dim3(nblk), dim3(256), 0, st, x, n, nullptr, nullptr, C, part);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n, stats_ws, momentum, running_mean,
+                     running_var, num_batches_tracked);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n * C / 4, 256, 4096)), dim3(256), 0, st, x, n, C, stats_ws, weight, bias, eps,
+                     residual, relu, out);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
+// its backward: y != NULL: the forward ended in a ReLU -- grad_out is masked by y > 0 (y = the forward's output);
+// grad_residual != NULL: receives the masked gradient (the residual branch's).  ws: cnrma_instnorm_workspace_bytes(C).
+extern "C" int cnrma_bn_train_backward_f32(const float* grad_out, const float* x, const float* y, int64_t n, int C,
+                                           const double* stats, const float* weight, float eps, float* grad_in,
+                                           float* grad_residual, float* grad_weight, float* grad_bias, double* ws, void* stream) {
+  if (n <= 0 || C <= 0 || C > 256 || (C & 3) || grad_out == nullptr || x == nullptr || stats == nullptr || grad_in == nullptr ||
+      ws == nullptr)
+    return CNRMA_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int nblk = 1024;
+  double* sums = ws;                  // [2C]
+  double* part = ws + 2 * C;          // [nblk][2C]
+  hipLaunchKernelGGL(bn_colsum2_partial_kernel, dim3(nblk), dim3(256), 0, st, grad_out, x, y, n, C, part);
+  hipLaunchKernelGGL(bn_backward_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n, stats, eps, grad_weight,
+                     grad_bias, sums);
+  hipLaunchKernelGGL(bn_backward_apply2_kernel, dim3(grid_for(n * C / 4, 256, 4096)), dim3(256), 0, st, grad_out, x, y, n, C, stats,
+                     sums, weight, eps, grad_in, grad_residual);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }

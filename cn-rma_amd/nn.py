@@ -103,11 +103,15 @@ class MinkowskiBatchNorm(nn.Module):
                 self._folded = {key: S.fold_bn(self.bn, bias)}
         return self._folded[key]
 
-    def forward(self, x):
+    def forward(self, x, relu=False, residual=None):
+        """relu / residual (training mode): [relu]( bn(x) [+ residual.F] ) in one pass (S.batch_norm_train)"""
         if self.training:
-            return S.SparseTensor(S.batch_norm_train(x.F, self.bn), x.cs)
+            return S.SparseTensor(S.batch_norm_train(x.F, self.bn, relu, None if residual is None else residual.F), x.cs)
         scale, shift = self.folded()
-        return S.SparseTensor(x.F * scale + shift, x.cs)
+        y = x.F * scale + shift
+        if residual is not None:
+            y = y + residual.F
+        return S.SparseTensor(torch.relu(y) if relu else y, x.cs)
 
 
 class MinkowskiInstanceNorm(nn.Module):
@@ -179,6 +183,9 @@ class FusedSequential(nn.Sequential):
                 # the stem: the normalised tensor is never written -- the pooling normalises its candidates on the fly
                 x = S.instance_norm_max_pool(x, m.weight, m.bias, m.eps, relu=True, kernel_size=nxt2.kernel_size, stride=nxt2.stride)
                 i += 3
+            elif self.training and isinstance(m, MinkowskiBatchNorm) and isinstance(nxt, MinkowskiReLU):
+                x = m(x, relu=True)
+                i += 2
             elif isinstance(m, MinkowskiInstanceNorm) and isinstance(nxt, MinkowskiReLU):
                 x = m(x, relu=True)
                 i += 2
@@ -203,11 +210,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        if self.training:
-            out = self.relu(self.norm1(self.conv1(x)))
-            out = self.norm2(self.conv2(out))
+        if self.training:                                  # BatchNorm fused with the ReLU / the shortcut add + ReLU behind it
+            out = self.norm1(self.conv1(x), relu=True)
             res = self.downsample(x) if self.downsample is not None else x
-            return self.relu(S.SparseTensor(out.F + res.F, out.cs))
+            return self.norm2(self.conv2(out), relu=True, residual=res)
         s1, b1 = self.norm1.folded()
         out = self.conv1(x, scale=s1, shift=b1, act="relu")
         res = self.downsample(x) if self.downsample is not None else x
@@ -235,11 +241,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if self.training:
-            out = self.relu(self.norm1(self.conv1(x)))
-            out = self.relu(self.norm2(self.conv2(out)))
-            out = self.norm3(self.conv3(out))
+            out = self.norm1(self.conv1(x), relu=True)
+            out = self.norm2(self.conv2(out), relu=True)
             res = self.downsample(x) if self.downsample is not None else x
-            return self.relu(S.SparseTensor(out.F + res.F, out.cs))
+            return self.norm3(self.conv3(out), relu=True, residual=res)
         s1, b1 = self.norm1.folded()
         out = self.conv1(x, scale=s1, shift=b1, act="relu")
         s2, b2 = self.norm2.folded()

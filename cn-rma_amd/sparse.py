@@ -1251,61 +1251,65 @@ def instance_norm(x, weight=None, bias=None, eps=1e-8, relu=False):
     return SparseTensor(out, x.cs)
 
 
-BN_TRAIN_HIP = False     # training-mode BatchNorm on the library's kernels (deterministic fp64 column sums).  Off by default: the
-                         # training step is bound by the host's launch rate (2042 launches per step), and this path issues
-                         # more launches than torch's fused ones -- 34.8-35.5 vs 33.0-33.3 ms per step at the ScanNet shape
+BN_TRAIN_HIP = True      # training-mode BatchNorm on the library's kernels (deterministic fp64 column sums), fused with the ReLU /
+                         # shortcut add + ReLU behind it, running statistics updated by the statistics kernel.  Rounds 3-4: off
+                         # (its eight tiny running-statistics launches made the host-bound step slower: 34.8-35.5 vs 33.0-33.3 ms);
+                         # end of round 5, fused: 24.1 vs 25.3 ms per step at the ScanNet shape on the same box
 
 
 class _BatchNormTrainFn(torch.autograd.Function):
-    """nn.BatchNorm1d in training mode over the rows of F [n, C] (MinkowskiBatchNorm) on the library's column-statistics
-    kernels: forward = cnrma_sparse_instnorm_f32 with the layer's eps (fp64 sums in a fixed order; leaves mean / biased
-    variance in its workspace), backward = cnrma_bn_backward_f32.  torch's own kernels for a tall [n, C] matrix
-    (batch_norm_collect_statistics / _backward_reduce channels-last) took 4.4 of the 31 ms of a training step at the
-    ScanNet shape."""
+    """nn.BatchNorm1d in training mode over the rows of F [n, C] (MinkowskiBatchNorm), fused with what follows it in a residual
+    block: out = [relu]( bn(F) [+ residual] ).  forward = cnrma_bn_train_forward_f32 (fp64 column sums in a fixed order; the
+    statistics kernel also updates the running statistics and the batch counter), backward = cnrma_bn_train_backward_f32 (the
+    ReLU's mask is taken from the saved output; the masked gradient is the residual branch's).  torch's own kernels for a tall
+    [n, C] matrix (batch_norm_collect_statistics / _backward_reduce channels-last) read it at a fifth of HBM speed: 44 us of
+    backward kernels per layer at the ScanNet shape against 30 here, plus the ReLU's own backward launch."""
 
     @staticmethod
-    def forward(ctx, F, weight, bias, eps):
+    def forward(ctx, F, weight, bias, residual, eps, relu, momentum, running_mean, running_var, batches):
         Fd = F.detach().contiguous().float()
         n, C = Fd.shape
         out = torch.empty_like(Fd)
         ws = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=Fd.device)
-        w = weight.detach().contiguous().view(-1).float() if weight is not None else None
-        b = bias.detach().contiguous().view(-1).float() if bias is not None else None
-        call("cnrma_sparse_instnorm_f32", ptr(Fd), n, None, None, C, ptr(w), ptr(b), float(eps), 0, ptr(out), ptr(ws), stream())
-        stats = ws[:2 * C].clone()                    # mean, biased variance (fp64)
-        ctx.save_for_backward(Fd, stats, w)
-        ctx.eps, ctx.ws = float(eps), ws
-        ctx.mark_non_differentiable(stats)
-        return out, stats
+        w = weight.detach().contiguous().view(-1).float()
+        b = bias.detach().contiguous().view(-1).float()
+        r = residual.detach().contiguous().float() if residual is not None else None
+        call("cnrma_bn_train_forward_f32", ptr(Fd), n, C, ptr(w), ptr(b), float(eps), ptr(r), 1 if relu else 0, float(momentum),
+             ptr(running_mean), ptr(running_var), ptr(batches), ptr(out), ptr(ws), stream())
+        ctx.save_for_backward(Fd, w, out if relu else None)
+        ctx.eps, ctx.ws, ctx.has_res = float(eps), ws, residual is not None      # ws[:2C]: mean, biased variance (fp64)
+        return out
 
     @staticmethod
-    def backward(ctx, grad_out, _grad_stats):
-        Fd, stats, w = ctx.saved_tensors
+    def backward(ctx, grad_out):
+        Fd, w, y = ctx.saved_tensors
         n, C = Fd.shape
         g = grad_out.contiguous().float()
         dx = torch.empty_like(Fd)
+        dres = torch.empty_like(Fd) if ctx.has_res and y is not None else None
         dw = torch.empty(C, dtype=torch.float32, device=Fd.device)
         db = torch.empty(C, dtype=torch.float32, device=Fd.device)
-        call("cnrma_bn_backward_f32", ptr(g), ptr(Fd), n, C, ptr(stats), ptr(w), ctx.eps, ptr(dx), ptr(dw), ptr(db),
-             ptr(ctx.ws), stream())
-        return dx, (dw if w is not None else None), db, None
+        ws2 = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=Fd.device)
+        call("cnrma_bn_train_backward_f32", ptr(g), ptr(Fd), ptr(y), n, C, ptr(ctx.ws), ptr(w), ctx.eps, ptr(dx), ptr(dres),
+             ptr(dw), ptr(db), ptr(ws2), stream())
+        if ctx.has_res and dres is None:
+            dres = g                                    # no ReLU: the residual branch takes the incoming gradient as it is
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def batch_norm_train(F, bn):
-    """training-mode forward of an nn.BatchNorm1d `bn` on F [n, C] (+ its running-statistics update) through the HIP kernels;
-    falls back to torch for shapes the kernels do not take (C > 256, no rows, no affine-free support needed here)"""
+def batch_norm_train(F, bn, relu=False, residual=None):
+    """training-mode forward of an nn.BatchNorm1d `bn` on F [n, C], optionally fused with a residual add and a ReLU:
+    [relu]( bn(F) [+ residual] ), running statistics updated.  Through the HIP kernels where they take the shape (C <= 256,
+    C % 4 == 0, affine, fixed momentum); torch otherwise"""
     n, C = F.shape
-    if (not BN_TRAIN_HIP or not F.is_cuda or n < 2 or C > 256 or not bn.affine or not bn.track_running_stats
-            or F.dtype != torch.float32):
-        return bn(F)
-    out, stats = _BatchNormTrainFn.apply(F, bn.weight, bn.bias, bn.eps)
-    with torch.no_grad():
-        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-        bn.num_batches_tracked += 1
-        mean, var = stats[:C].float(), (stats[C:] * (n / (n - 1.0))).float()      # running_var takes the unbiased estimate
-        bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-        bn.running_var.mul_(1.0 - m).add_(var, alpha=m)
-    return out
+    if (not BN_TRAIN_HIP or not F.is_cuda or n < 2 or C > 256 or C % 4 or not bn.affine or not bn.track_running_stats
+            or bn.momentum is None or F.dtype != torch.float32 or (residual is not None and residual.dtype != torch.float32)):
+        out = bn(F)
+        if residual is not None:
+            out = out + residual
+        return torch.relu(out) if relu else out
+    return _BatchNormTrainFn.apply(F, bn.weight, bn.bias, residual, bn.eps, relu, bn.momentum, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked)
 
 
 def union_add(a, b):

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 5   /* 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16, cnrma_sparse_conv_go_bf16 (+ its weight image); 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
+#define CNRMA_ABI_VERSION 5   /* 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16, cnrma_sparse_conv_go_bf16 (+ its weight images), cnrma_bn_train_forward_f32 / _backward_f32; 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
 
 int cnrma_abi_version(void);
 
@@ -583,6 +583,19 @@ int cnrma_sparse_instnorm_maxpool_f32(const float* in_feats, int C, const double
  * cnrma_sparse_instnorm_f32 with the layer's eps (it leaves {mean, biased variance} in stats_ws); this is the backward:
  * grad_weight = sum dy * xhat, grad_bias = sum dy, grad_in = weight / sigma * (dy - mean(dy) - xhat * mean(dy * xhat)).
  * fp64 column sums in a fixed order (deterministic).  ws: cnrma_instnorm_workspace_bytes(C). */
+/* BatchNorm1d in training mode fused with what follows it in a residual block (ME.MinkowskiBatchNorm + MinkowskiReLU of
+ * ME's BasicBlock / Bottleneck, reached from fcaf3d_backbone.py:59-107 under the train step):
+ *   out = [relu]( (x - mean) / sqrt(var + eps) * weight + bias [+ residual] ),  C <= 256, C % 4 == 0, n >= 2;
+ * running_mean / running_var (unbiased estimate) / num_batches_tracked updated in place when given (momentum).
+ * stats_ws: cnrma_instnorm_workspace_bytes(C); on return {mean[C], biased variance[C]} in fp64 = the backward's `stats`.
+ * backward: y (the forward's output) != NULL masks grad_out by y > 0 (the ReLU); grad_residual != NULL receives the masked
+ * gradient.  fp64 column sums in a fixed order (deterministic). */
+int cnrma_bn_train_forward_f32(const float* x, int64_t n, int C, const float* weight, const float* bias, float eps,
+                               const float* residual, int relu, float momentum, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, float* out, double* stats_ws, void* stream);
+int cnrma_bn_train_backward_f32(const float* grad_out, const float* x, const float* y, int64_t n, int C, const double* stats,
+                                const float* weight, float eps, float* grad_in, float* grad_residual, float* grad_weight,
+                                float* grad_bias, double* ws, void* stream);
 int cnrma_bn_backward_f32(const float* grad_out, const float* x, int64_t n, int C, const double* stats, const float* weight,
                           float eps, float* grad_in, float* grad_weight, float* grad_bias, double* ws, void* stream);
 

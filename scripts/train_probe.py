@@ -37,17 +37,18 @@ def step():
     opt.step()
     return float(out["loss"].detach())
 from cnrma_amd import sparse as S_
-for bn_hip in (True, False, True, False):
+AB = os.environ.get("CNRMA_PROBE_AB", "1") == "1"       # the BatchNorm A/B phases (off under the profiler: one configuration only)
+for bn_hip in ((True, False, True, False) if AB else ()):
     S_.BN_TRAIN_HIP = bn_hip
     for _ in range(2): l = step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(5): l = step()
     torch.cuda.synchronize()
     print(f"  BatchNorm through {'the HIP kernels' if bn_hip else 'torch'}: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms per step", flush=True)
-S_.BN_TRAIN_HIP = False
+S_.BN_TRAIN_HIP = os.environ.get("CNRMA_BN_HIP", "1") == "1"
 for _ in range(2): l = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 5
+n = 5 if AB else 28
 for _ in range(n): l = step()
 torch.cuda.synchronize()
 if os.environ.get("CNRMA_CPROFILE"):

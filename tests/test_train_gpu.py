@@ -243,13 +243,16 @@ def test_full_size_train_step_at_scannet_shape(device, tmp_path):
 
 
 @pytest.mark.parametrize("n,C", [(5000, 64), (777, 128), (40000, 32), (300, 256)])
-def test_batch_norm_train_kernels_match_torch(device, n, C):
-    """MinkowskiBatchNorm in training mode runs on the library's column-statistics kernels (forward) and
-    cnrma_bn_backward_f32 (backward): output, running statistics and all three gradients against nn.BatchNorm1d"""
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True), (False, True)])
+def test_batch_norm_train_kernels_match_torch(device, n, C, relu, with_res):
+    """MinkowskiBatchNorm in training mode on the library's kernels (cnrma_bn_train_forward_f32 / _backward_f32), alone and
+    fused with the shortcut add and the ReLU behind it: output, running statistics and all gradients (input, residual, weight,
+    bias) against nn.BatchNorm1d (+ add + relu) composed in torch"""
     from cnrma_amd import sparse as S
     torch.manual_seed(n + C)
     x = (torch.randn(n, C, device=device) * 3 + 1.5)
     g = torch.randn(n, C, device=device)
+    r = torch.randn(n, C, device=device)
     ref = torch.nn.BatchNorm1d(C).to(device).train()
     got = torch.nn.BatchNorm1d(C).to(device).train()
     with torch.no_grad():
@@ -257,16 +260,31 @@ def test_batch_norm_train_kernels_match_torch(device, n, C):
         got.load_state_dict(ref.state_dict())
     xr = x.clone().requires_grad_(True)
     xg = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if with_res else None
+    rg = r.clone().requires_grad_(True) if with_res else None
     yr = ref(xr)
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
     prev, S.BN_TRAIN_HIP = S.BN_TRAIN_HIP, True
+    calls = []
+    orig = S.call
+    S.call = lambda name, *a: (calls.append(name), orig(name, *a))[1]
     try:
-        yg = S.batch_norm_train(xg, got)
+        yg = S.batch_norm_train(xg, got, relu=relu, residual=rg)
+        yr.backward(g)
+        yg.backward(g)
     finally:
         S.BN_TRAIN_HIP = prev
-    yr.backward(g)
-    yg.backward(g)
+        S.call = orig
+    assert calls == ["cnrma_bn_train_forward_f32", "cnrma_bn_train_backward_f32"]
     np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5)
+    if with_res:
+        # rows where the fused output sits within rounding of the ReLU's kink may take the other branch
+        mask = (yr.detach().abs() > 1e-5).cpu().numpy() if relu else np.ones((n, C), bool)
+        np.testing.assert_allclose(rg.grad.cpu().numpy()[mask], rr.grad.cpu().numpy()[mask], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(got.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(got.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(got.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
