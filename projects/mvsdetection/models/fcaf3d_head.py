@@ -89,8 +89,10 @@ class _IoU3DLoss(nn.Module):
         else:
             p_lo, p_hi = pred[:, :3] - pred[:, 3:6] / 2, pred[:, :3] + pred[:, 3:6] / 2
             t_lo, t_hi = target[:, :3] - target[:, 3:6] / 2, target[:, :3] + target[:, 3:6] / 2
-            inter = (torch.min(p_hi, t_hi) - torch.max(p_lo, t_lo)).clamp(min=0).prod(dim=1)
-            union = pred[:, 3:6].prod(dim=1) + target[:, 3:6].prod(dim=1) - inter
+            # products written out: prod()'s backward reads a scalar back (a host synchronisation inside loss.backward())
+            ov = (torch.min(p_hi, t_hi) - torch.max(p_lo, t_lo)).clamp(min=0)
+            inter = ov[:, 0] * ov[:, 1] * ov[:, 2]
+            union = pred[:, 3] * pred[:, 4] * pred[:, 5] + target[:, 3] * target[:, 4] * target[:, 5] - inter
             iou = inter / union.clamp(min=1e-8)
         loss = 1 - iou
         if weight is not None:
