@@ -106,7 +106,7 @@ SIGNATURES = {
     "cnrma_sparse_instnorm_maxpool_f32": (c_int, [P, I, P, P, P, F, I, P, I, P, L, P, P, P]),
     "cnrma_bn_backward_f32": (c_int, [P, P, L, I, P, P, F, P, P, P, P, P]),
     "cnrma_bn_train_forward_f32": (c_int, [P, L, I, P, P, F, P, I, F, P, P, P, P, P, P]),
-    "cnrma_bn_train_backward_f32": (c_int, [P, P, P, L, I, P, P, F, P, P, P, P, P, P]),
+    "cnrma_bn_train_backward_f32": (c_int, [P, P, P, I, L, I, P, P, F, P, P, P, P, P, P]),
     "cnrma_union_workspace_bytes": (c_size_t, [L]),
     "cnrma_sparse_union_add_f32": (c_int, [P, P, L, P, P, P, L, P, I, P, P, L, P, P, L, P, P, P]),
     "cnrma_sparse_interp_f32": (c_int, [P, L, P, P, P, P, L, I, P, P]),

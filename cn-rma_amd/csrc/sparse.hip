@@ -3754,7 +3754,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       if (weight) v = v * weight[c + j];
       if (bias) v = v + bias[c + j];
       if (residual) v = v + rv[j];
-      o[j] = relu ? fmaxf(v, 0.0f) : v;
+      o[j] = relu == 1 ? fmaxf(v, 0.0f) : (relu == 2 ? (v > 0.0f ? v : expm1f(v)) : v);      // 2: ELU (alpha 1)
     }
     reinterpret_cast<float4*>(out)[t] = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -3762,7 +3762,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // s1 / s2 of the MASKED gradient (y given: dy counts where y > 0)
 __global__ __launch_bounds__(256) void bn_colsum2_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                 const float* __restrict__ y, int64_t n, int C,
+                                                                 const float* __restrict__ y, int act, int64_t n, int C,
                                                                  double* __restrict__ part) {
   const int c = threadIdx.x % C;
   const int groups = blockDim.x / C;
@@ -3771,7 +3771,10 @@ __global__ __launch_bounds__(256) void bn_colsum2_partial_kernel(const float* __
   if (gi < groups) {
     for (int64_t r = (int64_t)blockIdx.x * groups + gi; r < n; r += (int64_t)gridDim.x * groups) {
       float gf = dy[r * C + c];
-      if (y != nullptr && !(y[r * C + c] > 0.0f)) gf = 0.0f;
+      if (y != nullptr) {
+        const float yv = y[r * C + c];
+        if (!(yv > 0.0f)) gf = act == 2 ? gf * (yv + 1.0f) : 0.0f;        // ELU: d/dx = y + 1 below zero; ReLU: 0
+      }
       const double g = (double)gf;
       s += g;
       q += g * (double)x[r * C + c];
@@ -3790,7 +3793,7 @@ __global__ __launch_bounds__(256) void bn_colsum2_partial_kernel(const float* __
 }
 
 __global__ __launch_bounds__(256) void bn_backward_apply2_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                 const float* __restrict__ y, int64_t n, int C,
+                                                                 const float* __restrict__ y, int act, int64_t n, int C,
                                                                  const double* __restrict__ stats, const double* __restrict__ sums,
                                                                  const float* __restrict__ weight, float eps,
                                                                  float* __restrict__ dx, float* __restrict__ dres) {
@@ -3804,7 +3807,7 @@ __global__ __launch_bounds__(256) void bn_backward_apply2_kernel(const float* __
       const float4 y4 = reinterpret_cast<const float4*>(y)[t];
       const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (!(yv[j] > 0.0f)) gv[j] = 0.0f;
+      for (int j = 0; j < 4; ++j) if (!(yv[j] > 0.0f)) gv[j] = act == 2 ? gv[j] * (yv[j] + 1.0f) : 0.0f;
     }
     float o[4];
 #pragma unroll
@@ -5627,7 +5630,8 @@ extern "C" int cnrma_bn_backward_f32(const float* grad_out, const float* x, int6
 }
 
 // BatchNorm1d in training mode over the rows of x [n][C] (C <= 256, C % 4 == 0, n >= 2), fused with what follows it in a
-// residual block: out = [relu]( (x - mean) / sqrt(var + eps) * weight + bias [+ residual] ); running statistics and batch
+// residual block: out = act( (x - mean) / sqrt(var + eps) * weight + bias [+ residual] ), act = `relu`: 0 none, 1 ReLU, 2 ELU;
+// running statistics and batch
 // counter updated in the statistics kernel (momentum given).  stats_ws: cnrma_instnorm_workspace_bytes(C); on return
 // stats_ws[0..C) = mean, [C..2C) = biased variance (fp64): the backward's `stats`.
 extern "C" int cnrma_bn_train_forward_f32(const float* x, int64_t n, int C, const float* weight, const float* bias, float eps,
@@ -5647,9 +5651,10 @@ extern "C" int cnrma_bn_train_forward_f32(const float* x, int64_t n, int C, cons
   return 0;
 }
 
-// its backward: y != NULL: the forward ended in a ReLU -- grad_out is masked by y > 0 (y = the forward's output);
+// its backward: y != NULL: the forward ended in an activation (act 1 ReLU: grad_out is masked by y > 0; 2 ELU: times y + 1 where
+// y <= 0; y = the forward's output);
 // grad_residual != NULL: receives the masked gradient (the residual branch's).  ws: cnrma_instnorm_workspace_bytes(C).
-extern "C" int cnrma_bn_train_backward_f32(const float* grad_out, const float* x, const float* y, int64_t n, int C,
+extern "C" int cnrma_bn_train_backward_f32(const float* grad_out, const float* x, const float* y, int act, int64_t n, int C,
                                            const double* stats, const float* weight, float eps, float* grad_in,
                                            float* grad_residual, float* grad_weight, float* grad_bias, double* ws, void* stream) {
   if (n <= 0 || C <= 0 || C > 256 || (C & 3) || grad_out == nullptr || x == nullptr || stats == nullptr || grad_in == nullptr ||
@@ -5659,10 +5664,10 @@ extern "C" int cnrma_bn_train_backward_f32(const float* grad_out, const float* x
   const int nblk = 1024;
   double* sums = ws;                  // [2C]
   double* part = ws + 2 * C;          // [nblk][2C]
-  hipLaunchKernelGGL(bn_colsum2_partial_kernel, dim3(nblk), dim3(256), 0, st, grad_out, x, y, n, C, part);
+  hipLaunchKernelGGL(bn_colsum2_partial_kernel, dim3(nblk), dim3(256), 0, st, grad_out, x, y, act, n, C, part);
   hipLaunchKernelGGL(bn_backward_final_kernel, dim3((unsigned)C), dim3(256), 0, st, part, nblk, C, n, stats, eps, grad_weight,
                      grad_bias, sums);
-  hipLaunchKernelGGL(bn_backward_apply2_kernel, dim3(grid_for(n * C / 4, 256, 4096)), dim3(256), 0, st, grad_out, x, y, n, C, stats,
+  hipLaunchKernelGGL(bn_backward_apply2_kernel, dim3(grid_for(n * C / 4, 256, 4096)), dim3(256), 0, st, grad_out, x, y, act, n, C, stats,
                      sums, weight, eps, grad_in, grad_residual);
   CNRMA_LAUNCH_CHECK();
   return 0;

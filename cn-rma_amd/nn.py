@@ -111,7 +111,8 @@ class MinkowskiBatchNorm(nn.Module):
         y = x.F * scale + shift
         if residual is not None:
             y = y + residual.F
-        return S.SparseTensor(torch.relu(y) if relu else y, x.cs)
+        y = nn.functional.elu(y) if relu == "elu" else (torch.relu(y) if relu else y)
+        return S.SparseTensor(y, x.cs)
 
 
 class MinkowskiInstanceNorm(nn.Module):
@@ -183,8 +184,8 @@ class FusedSequential(nn.Sequential):
                 # the stem: the normalised tensor is never written -- the pooling normalises its candidates on the fly
                 x = S.instance_norm_max_pool(x, m.weight, m.bias, m.eps, relu=True, kernel_size=nxt2.kernel_size, stride=nxt2.stride)
                 i += 3
-            elif self.training and isinstance(m, MinkowskiBatchNorm) and isinstance(nxt, MinkowskiReLU):
-                x = m(x, relu=True)
+            elif self.training and isinstance(m, MinkowskiBatchNorm) and _act_name(nxt) is not None:
+                x = m(x, relu=_act_name(nxt))                  # BatchNorm + ReLU / ELU in one pass (S.batch_norm_train)
                 i += 2
             elif isinstance(m, MinkowskiInstanceNorm) and isinstance(nxt, MinkowskiReLU):
                 x = m(x, relu=True)

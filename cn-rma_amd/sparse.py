@@ -1274,10 +1274,11 @@ class _BatchNormTrainFn(torch.autograd.Function):
         w = weight.detach().contiguous().view(-1).float()
         b = bias.detach().contiguous().view(-1).float()
         r = residual.detach().contiguous().float() if residual is not None else None
-        call("cnrma_bn_train_forward_f32", ptr(Fd), n, C, ptr(w), ptr(b), float(eps), ptr(r), 1 if relu else 0, float(momentum),
+        act = {False: 0, None: 0, True: 1, "relu": 1, "elu": 2}[relu]
+        call("cnrma_bn_train_forward_f32", ptr(Fd), n, C, ptr(w), ptr(b), float(eps), ptr(r), act, float(momentum),
              ptr(running_mean), ptr(running_var), ptr(batches), ptr(out), ptr(ws), stream())
-        ctx.save_for_backward(Fd, w, out if relu else None)
-        ctx.eps, ctx.ws, ctx.has_res = float(eps), ws, residual is not None      # ws[:2C]: mean, biased variance (fp64)
+        ctx.save_for_backward(Fd, w, out if act else None)
+        ctx.eps, ctx.ws, ctx.has_res, ctx.act = float(eps), ws, residual is not None, act      # ws[:2C]: mean, biased variance (fp64)
         return out
 
     @staticmethod
@@ -1290,7 +1291,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
         dw = torch.empty(C, dtype=torch.float32, device=Fd.device)
         db = torch.empty(C, dtype=torch.float32, device=Fd.device)
         ws2 = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=Fd.device)
-        call("cnrma_bn_train_backward_f32", ptr(g), ptr(Fd), ptr(y), n, C, ptr(ctx.ws), ptr(w), ctx.eps, ptr(dx), ptr(dres),
+        call("cnrma_bn_train_backward_f32", ptr(g), ptr(Fd), ptr(y), ctx.act, n, C, ptr(ctx.ws), ptr(w), ctx.eps, ptr(dx), ptr(dres),
              ptr(dw), ptr(db), ptr(ws2), stream())
         if ctx.has_res and dres is None:
             dres = g                                    # no ReLU: the residual branch takes the incoming gradient as it is
@@ -1298,8 +1299,8 @@ class _BatchNormTrainFn(torch.autograd.Function):
 
 
 def batch_norm_train(F, bn, relu=False, residual=None):
-    """training-mode forward of an nn.BatchNorm1d `bn` on F [n, C], optionally fused with a residual add and a ReLU:
-    [relu]( bn(F) [+ residual] ), running statistics updated.  Through the HIP kernels where they take the shape (C <= 256,
+    """training-mode forward of an nn.BatchNorm1d `bn` on F [n, C], optionally fused with a residual add and an activation
+    (relu: False / True = "relu" / "elu"): act( bn(F) [+ residual] ), running statistics updated.  Through the HIP kernels where they take the shape (C <= 256,
     C % 4 == 0, affine, fixed momentum); torch otherwise"""
     n, C = F.shape
     if (not BN_TRAIN_HIP or not F.is_cuda or n < 2 or C > 256 or C % 4 or not bn.affine or not bn.track_running_stats
@@ -1307,7 +1308,7 @@ def batch_norm_train(F, bn, relu=False, residual=None):
         out = bn(F)
         if residual is not None:
             out = out + residual
-        return torch.relu(out) if relu else out
+        return torch.nn.functional.elu(out) if relu == "elu" else (torch.relu(out) if relu else out)
     return _BatchNormTrainFn.apply(F, bn.weight, bn.bias, residual, bn.eps, relu, bn.momentum, bn.running_mean, bn.running_var,
                                    bn.num_batches_tracked)
 

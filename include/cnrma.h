@@ -585,15 +585,17 @@ int cnrma_sparse_instnorm_maxpool_f32(const float* in_feats, int C, const double
  * fp64 column sums in a fixed order (deterministic).  ws: cnrma_instnorm_workspace_bytes(C). */
 /* BatchNorm1d in training mode fused with what follows it in a residual block (ME.MinkowskiBatchNorm + MinkowskiReLU of
  * ME's BasicBlock / Bottleneck, reached from fcaf3d_backbone.py:59-107 under the train step):
- *   out = [relu]( (x - mean) / sqrt(var + eps) * weight + bias [+ residual] ),  C <= 256, C % 4 == 0, n >= 2;
+ *   out = act( (x - mean) / sqrt(var + eps) * weight + bias [+ residual] ),  C <= 256, C % 4 == 0, n >= 2;
+ *   act (`relu` / `act`): 0 none, 1 ReLU, 2 ELU (alpha 1: the head's blocks, fcaf3d_head.py:61-83);
  * running_mean / running_var (unbiased estimate) / num_batches_tracked updated in place when given (momentum).
  * stats_ws: cnrma_instnorm_workspace_bytes(C); on return {mean[C], biased variance[C]} in fp64 = the backward's `stats`.
- * backward: y (the forward's output) != NULL masks grad_out by y > 0 (the ReLU); grad_residual != NULL receives the masked
+ * backward: y (the forward's output) != NULL applies the activation's derivative to grad_out (ReLU: y > 0; ELU: y + 1 where
+ * y <= 0); grad_residual != NULL receives that
  * gradient.  fp64 column sums in a fixed order (deterministic). */
 int cnrma_bn_train_forward_f32(const float* x, int64_t n, int C, const float* weight, const float* bias, float eps,
                                const float* residual, int relu, float momentum, float* running_mean, float* running_var,
                                int64_t* num_batches_tracked, float* out, double* stats_ws, void* stream);
-int cnrma_bn_train_backward_f32(const float* grad_out, const float* x, const float* y, int64_t n, int C, const double* stats,
+int cnrma_bn_train_backward_f32(const float* grad_out, const float* x, const float* y, int act, int64_t n, int C, const double* stats,
                                 const float* weight, float eps, float* grad_in, float* grad_residual, float* grad_weight,
                                 float* grad_bias, double* ws, void* stream);
 int cnrma_bn_backward_f32(const float* grad_out, const float* x, int64_t n, int C, const double* stats, const float* weight,

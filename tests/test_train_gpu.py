@@ -243,7 +243,7 @@ def test_full_size_train_step_at_scannet_shape(device, tmp_path):
 
 
 @pytest.mark.parametrize("n,C", [(5000, 64), (777, 128), (40000, 32), (300, 256)])
-@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True), (False, True)])
+@pytest.mark.parametrize("relu,with_res", [(False, False), (True, False), (True, True), (False, True), ("elu", False)])
 def test_batch_norm_train_kernels_match_torch(device, n, C, relu, with_res):
     """MinkowskiBatchNorm in training mode on the library's kernels (cnrma_bn_train_forward_f32 / _backward_f32), alone and
     fused with the shortcut add and the ReLU behind it: output, running statistics and all gradients (input, residual, weight,
@@ -266,7 +266,7 @@ def test_batch_norm_train_kernels_match_torch(device, n, C, relu, with_res):
     if with_res:
         yr = yr + rr
     if relu:
-        yr = torch.relu(yr)
+        yr = torch.nn.functional.elu(yr) if relu == "elu" else torch.relu(yr)
     prev, S.BN_TRAIN_HIP = S.BN_TRAIN_HIP, True
     calls = []
     orig = S.call
@@ -283,7 +283,7 @@ def test_batch_norm_train_kernels_match_torch(device, n, C, relu, with_res):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.cpu().numpy(), rtol=1e-3, atol=2e-5)
     if with_res:
         # rows where the fused output sits within rounding of the ReLU's kink may take the other branch
-        mask = (yr.detach().abs() > 1e-5).cpu().numpy() if relu else np.ones((n, C), bool)
+        mask = (yr.detach().abs() > 1e-5).cpu().numpy() if relu is True else np.ones((n, C), bool)
         np.testing.assert_allclose(rg.grad.cpu().numpy()[mask], rr.grad.cpu().numpy()[mask], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(got.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
     np.testing.assert_allclose(got.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
