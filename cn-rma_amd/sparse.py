@@ -731,7 +731,8 @@ def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1, go=-1, nb
         call("cnrma_debug_conv_tuning", None, 0)
         return
     # ablate (diagnostic kernels, timing only -- results are wrong): bit 0 no MFMAs, 1 no A loads, 2 no B loads, 3 no LDS
-    # stores, 4 no barriers after a block's first stage
+    # stores, 4 no barriers after a block's first stage; the gather-once weight gradient reads 256 no consumer phase, 512 no
+    # LDS stores, 1024 no row loads, 2048 LDS reads without MFMAs (scripts/wgrad_go_ablate.py)
     # ws: LDS ring slots of the warp-specialised f16x3 kernel (2..4; 0 = the stage kernel; -1 = the launcher's default)
     # xcd: stage kernel: 1 = each XCD works on one contiguous eighth of the row tiles (0 = tiles dealt round-robin);
     #      gather-once second form: 0 plain order, 1 (column tile, slice split) groups -> XCDs, 2 row tiles -> XCDs
