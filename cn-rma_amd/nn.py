@@ -184,6 +184,11 @@ class FusedSequential(nn.Sequential):
                 # the stem: the normalised tensor is never written -- the pooling normalises its candidates on the fly
                 x = S.instance_norm_max_pool(x, m.weight, m.bias, m.eps, relu=True, kernel_size=nxt2.kernel_size, stride=nxt2.stride)
                 i += 3
+            elif self.training and isinstance(m, MinkowskiConvolution) and isinstance(nxt, MinkowskiBatchNorm) and \
+                    torch.is_grad_enabled():
+                act = _act_name(nxt2)                          # conv -> BatchNorm -> [ReLU / ELU]: one autograd node
+                x = _conv_bn_act(m, nxt, x, act)
+                i += 3 if act else 2
             elif self.training and isinstance(m, MinkowskiBatchNorm) and _act_name(nxt) is not None:
                 x = m(x, relu=_act_name(nxt))                  # BatchNorm + ReLU / ELU in one pass (S.batch_norm_train)
                 i += 2
@@ -194,6 +199,14 @@ class FusedSequential(nn.Sequential):
                 x = m(x)
                 i += 1
         return x
+
+
+def _conv_bn_act(conv, norm, x, act=None, residual=None):
+    """training mode: conv -> BatchNorm -> [+ residual] -> act as one autograd node (S.conv_bn_act_train) for bias-free
+    convolutions; the module-by-module composition otherwise"""
+    if conv.bias is None and isinstance(conv, MinkowskiConvolution):
+        return S.conv_bn_act_train(x, conv.kernel, norm.bn, conv.kernel_size, conv.stride, act, residual)
+    return norm(conv(x), relu=act if act else False, residual=residual)
 
 
 class BasicBlock(nn.Module):
@@ -212,9 +225,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if self.training:                                  # BatchNorm fused with the ReLU / the shortcut add + ReLU behind it
-            out = self.norm1(self.conv1(x), relu=True)
+            out = _conv_bn_act(self.conv1, self.norm1, x, "relu")
             res = self.downsample(x) if self.downsample is not None else x
-            return self.norm2(self.conv2(out), relu=True, residual=res)
+            return _conv_bn_act(self.conv2, self.norm2, out, "relu", res)
         s1, b1 = self.norm1.folded()
         out = self.conv1(x, scale=s1, shift=b1, act="relu")
         res = self.downsample(x) if self.downsample is not None else x
@@ -242,10 +255,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         if self.training:
-            out = self.norm1(self.conv1(x), relu=True)
-            out = self.norm2(self.conv2(out), relu=True)
+            out = _conv_bn_act(self.conv1, self.norm1, x, "relu")
+            out = _conv_bn_act(self.conv2, self.norm2, out, "relu")
             res = self.downsample(x) if self.downsample is not None else x
-            return self.norm3(self.conv3(out), relu=True, residual=res)
+            return _conv_bn_act(self.conv3, self.norm3, out, "relu", res)
         s1, b1 = self.norm1.folded()
         out = self.conv1(x, scale=s1, shift=b1, act="relu")
         s2, b2 = self.norm2.folded()

@@ -958,87 +958,166 @@ WGRAD_GO_MIN_ROWS = 256
 DGRAD_MIRROR = True     # data gradient of a same-coordinates convolution on the forward table (mirrored offsets)
 
 
+def _conv_fwd(st, F, weight):
+    """forward of the differentiable convolution; st: an object with nbr, n_out, precision, sets (an autograd ctx)"""
+    # the Parameter object itself goes down (its prepared image is cached on it until the optimiser changes it)
+    if st.precision == "bf16" and weight.dim() == 3 and weight.shape[0] == 27 and \
+            _train_go(st.sets, st.n_out, weight.shape[1], weight.shape[2]):
+        with torch.no_grad():
+            return _conv_go_bf16(F.detach(), st.sets, weights_bf16_frag(weight), weight.shape[1], weight.shape[2])
+    return _conv_on_table(F.detach().float(), st.n_out, st.nbr, weight, st.precision)
+
+
+def _conv_bwd(st, F, weight, grad_out, need_F, need_W):
+    """data and weight gradient of the convolution (st as in _conv_fwd, + symmetric)"""
+    nbr, n_out = st.nbr, st.n_out
+    w = weight.detach().float()
+    w3 = w.unsqueeze(0) if w.dim() == 2 else w
+    K, Cin, Cout = w3.shape
+    g = grad_out.contiguous().float()
+    n_in = F.shape[0]
+    grad_F = grad_W = None
+    if need_F:
+        # same coordinates on both sides (odd kernel, stride 1): nbr_t[i][k] = nbr[i][K - 1 - k] -- the forward table
+        # with the offsets of the weights mirrored; else the table is transposed by a kernel
+        flip = bool(st.symmetric and nbr is not None and n_in == n_out and DGRAD_MIRROR)
+        if nbr is None or flip:
+            nbr_t = nbr
+        else:
+            nbr_t = torch.empty((n_in, K), dtype=torch.int32, device=g.device)
+            if n_in and n_out:
+                call("cnrma_sparse_kernel_map_transpose", ptr(nbr), n_out, None, K, n_in, ptr(nbr_t), stream())
+            else:
+                nbr_t.fill_(-1)
+        if flip and st.precision == "bf16" and K == 27 and _train_go(st.sets, n_in, Cout, Cin):
+            # the gather-once kernel on the forward's tile unions, weights mirrored + transposed in fragment order
+            grad_F = _conv_go_bf16(g, st.sets, weights_bf16_frag(weight, transposed=True), Cout, Cin)
+            shape_t = wt = None
+        else:
+            shape_t, wt = _dgrad_weights(w3, flip, st.precision)
+        if wt is None:
+            pass
+        elif wt.dtype == torch.uint8:
+            grad_F = _conv_on_table(g, n_in, nbr_t, None, st.precision, bf16_image=(shape_t, wt))
+        else:
+            grad_F = _conv_on_table(g, n_in, nbr_t, wt, st.precision)
+    if need_W and _wgrad_go(st, K, Cin, Cout):
+        # bf16, 27 offsets, compact rows: on the tile unions of the forward's gather-once structure (cached on the
+        # coordinate set: the convolutions of a residual stage share them)
+        in_cs, out_cs, ksize = st.sets
+        tu = tile_union(in_cs, out_cs, ksize, in_cs.stride)
+        per = 2 * ((Cin + 63) // 64) * ((Cout + 63) // 64)
+        tiles = (n_out + 63) // 64
+        # parts: a block takes ~2.9 us per tile of its part, a part costs its slab written and read back (~3 TB/s):
+        # T(parts) = tiles / parts * 2.9 + parts * slab_us, at most one block per CU
+        slab_us = 27 * Cin * Cout * 8 / 3e6
+        parts = max(1, min(tiles, WGRAD_GO_BLOCKS // per, int(round((tiles * 2.9 / slab_us) ** 0.5))))
+        slabs = torch.empty((parts, K, Cin, Cout), dtype=torch.float32, device=g.device)
+        call("cnrma_sparse_conv_wgrad_go_bf16", ptr(F.detach().contiguous().float()), Cin, ptr(tu), ptr(g), Cout, n_out, None,
+             parts, ptr(slabs), stream())
+        grad_W = (slabs[0] if parts == 1 else slabs.sum(dim=0)).view(weight.shape)
+    elif need_W:
+        # one block of 8 waves per (row chunk, offset, 64x64 weight tile), one slab per block: chunks sized for ~1024
+        # blocks (8 waves per SIMD over the launch), at least 8 steps of 32 rows each
+        tiles = ((Cin + 63) // 64) * ((Cout + 63) // 64)
+        want = max(1, WGRAD_BLOCKS // (K * tiles))
+        rows = max(256, -(-max(n_out, 1) // want))
+        rows = (rows + 31) // 32 * 32
+        chunks = _lib.load().cnrma_sparse_conv_wgrad_chunks(max(n_out, 1), rows)
+        # the kernel writes every element of every slab
+        slabs = (torch.empty if n_out else torch.zeros)((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
+        if n_out:
+            # under autocast(bf16) the weight gradient is a bf16 x bf16 -> fp32 reduction too (what AMP computes)
+            call("cnrma_sparse_conv_wgrad_bf16" if st.precision == "bf16" else "cnrma_sparse_conv_wgrad_f32",
+                 ptr(F.detach().contiguous().float()), Cin, ptr(nbr), K, ptr(g), Cout, n_out, None, rows, ptr(slabs), stream())
+        grad_W = (slabs[0] if chunks == 1 else slabs.sum(dim=0)).view(weight.shape)
+    return grad_F, grad_W
+
+
 class _ConvFn(torch.autograd.Function):
     """sum_k F[nbr[:, k]] @ W[k] with gradients: dgrad = the same convolution of grad_out over the transposed table with
-    W[k]^T, wgrad = cnrma_sparse_conv_wgrad_f32."""
+    W[k]^T (or the forward table with mirrored offsets), wgrad = cnrma_sparse_conv_wgrad_* (SURVEY.md 8f rank 3)."""
 
     @staticmethod
     def forward(ctx, F, weight, nbr, n_out, precision, symmetric=False, sets=None):
         ctx.save_for_backward(F, weight)
         precision = _precision(precision)          # resolved here: the backward runs outside the autocast region
         ctx.nbr, ctx.n_out, ctx.precision, ctx.symmetric, ctx.sets = nbr, n_out, precision, symmetric, sets
-        # the Parameter object itself goes down (its prepared image is cached on it until the optimiser changes it)
-        if precision == "bf16" and weight.dim() == 3 and weight.shape[0] == 27 and \
-                _train_go(sets, n_out, weight.shape[1], weight.shape[2]):
-            with torch.no_grad():
-                return _conv_go_bf16(F.detach(), sets, weights_bf16_frag(weight), weight.shape[1], weight.shape[2])
-        return _conv_on_table(F.detach().float(), n_out, nbr, weight, precision)
+        return _conv_fwd(ctx, F, weight)
 
     @staticmethod
     def backward(ctx, grad_out):
         F, weight = ctx.saved_tensors
-        nbr, n_out = ctx.nbr, ctx.n_out
-        w = weight.detach().float()
-        w3 = w.unsqueeze(0) if w.dim() == 2 else w
-        K, Cin, Cout = w3.shape
-        g = grad_out.contiguous().float()
-        n_in = F.shape[0]
-        grad_F = grad_W = None
-        if ctx.needs_input_grad[0]:
-            # same coordinates on both sides (odd kernel, stride 1): nbr_t[i][k] = nbr[i][K - 1 - k] -- the forward table
-            # with the offsets of the weights mirrored; else the table is transposed by a kernel
-            flip = bool(ctx.symmetric and nbr is not None and n_in == n_out and DGRAD_MIRROR)
-            if nbr is None or flip:
-                nbr_t = nbr
-            else:
-                nbr_t = torch.empty((n_in, K), dtype=torch.int32, device=g.device)
-                if n_in and n_out:
-                    call("cnrma_sparse_kernel_map_transpose", ptr(nbr), n_out, None, K, n_in, ptr(nbr_t), stream())
-                else:
-                    nbr_t.fill_(-1)
-            if flip and ctx.precision == "bf16" and K == 27 and _train_go(ctx.sets, n_in, Cout, Cin):
-                # the gather-once kernel on the forward's tile unions, weights mirrored + transposed in fragment order
-                grad_F = _conv_go_bf16(g, ctx.sets, weights_bf16_frag(weight, transposed=True), Cout, Cin)
-                shape_t = wt = None
-            else:
-                shape_t, wt = _dgrad_weights(w3, flip, ctx.precision)
-            if wt is None:
-                pass
-            elif wt.dtype == torch.uint8:
-                grad_F = _conv_on_table(g, n_in, nbr_t, None, ctx.precision, bf16_image=(shape_t, wt))
-            else:
-                grad_F = _conv_on_table(g, n_in, nbr_t, wt, ctx.precision)
-        if ctx.needs_input_grad[1] and _wgrad_go(ctx, K, Cin, Cout):
-            # bf16, 27 offsets, compact rows: on the tile unions of the forward's gather-once structure (cached on the
-            # coordinate set: the convolutions of a residual stage share them)
-            in_cs, out_cs, ksize = ctx.sets
-            tu = tile_union(in_cs, out_cs, ksize, in_cs.stride)
-            per = 2 * ((Cin + 63) // 64) * ((Cout + 63) // 64)
-            tiles = (n_out + 63) // 64
-            # parts: a block takes ~2.9 us per tile of its part, a part costs its slab written and read back (~3 TB/s):
-            # T(parts) = tiles / parts * 2.9 + parts * slab_us, at most one block per CU
-            slab_us = 27 * Cin * Cout * 8 / 3e6
-            parts = max(1, min(tiles, WGRAD_GO_BLOCKS // per, int(round((tiles * 2.9 / slab_us) ** 0.5))))
-            slabs = torch.empty((parts, K, Cin, Cout), dtype=torch.float32, device=g.device)
-            call("cnrma_sparse_conv_wgrad_go_bf16", ptr(F.detach().contiguous().float()), Cin, ptr(tu), ptr(g), Cout, n_out, None,
-                 parts, ptr(slabs), stream())
-            grad_W = (slabs[0] if parts == 1 else slabs.sum(dim=0)).view(weight.shape)
-        elif ctx.needs_input_grad[1]:
-            # one block of 8 waves per (row chunk, offset, 64x64 weight tile), one slab per block: chunks sized for ~1024
-            # blocks (8 waves per SIMD over the launch), at least 8 steps of 32 rows each
-            tiles = ((Cin + 63) // 64) * ((Cout + 63) // 64)
-            want = max(1, WGRAD_BLOCKS // (K * tiles))
-            rows = max(256, -(-max(n_out, 1) // want))
-            rows = (rows + 31) // 32 * 32
-            chunks = _lib.load().cnrma_sparse_conv_wgrad_chunks(max(n_out, 1), rows)
-            # the kernel writes every element of every slab
-            slabs = (torch.empty if n_out else torch.zeros)((chunks, K, Cin, Cout), dtype=torch.float32, device=g.device)
-            if n_out:
-                # under autocast(bf16) the weight gradient is a bf16 x bf16 -> fp32 reduction too (what AMP computes)
-                call("cnrma_sparse_conv_wgrad_bf16" if ctx.precision == "bf16" else "cnrma_sparse_conv_wgrad_f32",
-                     ptr(F.detach().contiguous().float()), Cin, ptr(nbr), K, ptr(g), Cout, n_out, None, rows, ptr(slabs), stream())
-            grad_W = (slabs[0] if chunks == 1 else slabs.sum(dim=0)).view(weight.shape)
+        grad_F, grad_W = _conv_bwd(ctx, F, weight, grad_out, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return grad_F, grad_W, None, None, None, None, None
+
+
+class _ConvBnActFn(torch.autograd.Function):
+    """convolution -> BatchNorm (training) -> [+ residual] -> [ReLU / ELU] as ONE autograd node (the training forward is bound by
+    the host's launch rate: one Function.apply, no intermediate SparseTensor / module calls per layer).  The same kernels
+    as _ConvFn followed by _BatchNormTrainFn."""
+
+    @staticmethod
+    def forward(ctx, F, weight, bn_w, bn_b, residual, nbr, n_out, precision, symmetric, sets, eps, act, momentum,
+                running_mean, running_var, batches):
+        ctx.nbr, ctx.n_out, ctx.precision, ctx.symmetric, ctx.sets = nbr, n_out, _precision(precision), symmetric, sets
+        y0 = _conv_fwd(ctx, F, weight)                           # the BatchNorm's input
+        n, C = y0.shape
+        out = torch.empty_like(y0)
+        ws = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=y0.device)
+        w = bn_w.detach().contiguous().view(-1).float()
+        b = bn_b.detach().contiguous().view(-1).float()
+        r = residual.detach().contiguous().float() if residual is not None else None
+        call("cnrma_bn_train_forward_f32", ptr(y0), n, C, ptr(w), ptr(b), float(eps), ptr(r), act, float(momentum),
+             ptr(running_mean), ptr(running_var), ptr(batches), ptr(out), ptr(ws), stream())
+        ctx.save_for_backward(F, weight, y0, w, out if act else None)
+        ctx.eps, ctx.ws, ctx.has_res, ctx.act = float(eps), ws, residual is not None, act
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        F, weight, y0, w, y = ctx.saved_tensors
+        n, C = y0.shape
+        g = grad_out.contiguous().float()
+        dx = torch.empty_like(y0)
+        dres = torch.empty_like(y0) if ctx.has_res and y is not None else None
+        dw = torch.empty(C, dtype=torch.float32, device=y0.device)
+        db = torch.empty(C, dtype=torch.float32, device=y0.device)
+        ws2 = torch.empty(_lib.load().cnrma_instnorm_workspace_bytes(C) // 8, dtype=torch.float64, device=y0.device)
+        call("cnrma_bn_train_backward_f32", ptr(g), ptr(y0), ptr(y), ctx.act, n, C, ptr(ctx.ws), ptr(w), ctx.eps, ptr(dx), ptr(dres),
+             ptr(dw), ptr(db), ptr(ws2), stream())
+        if ctx.has_res and dres is None:
+            dres = g
+        grad_F, grad_W = _conv_bwd(ctx, F, weight, dx, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (grad_F, grad_W, dw, db, dres) + (None,) * 11
+
+
+FUSE_CONV_BN = True     # training: conv -> BatchNorm -> [+ shortcut] -> activation as one autograd node where the fused BatchNorm applies
+
+
+def conv_bn_act_train(x, weight, bn, kernel_size=3, stride=1, act=None, residual=None, precision=None):
+    """training-mode conv -> bn -> [+ residual.F] -> act (None / "relu" / "elu") on SparseTensor x; one autograd node when
+    the fused BatchNorm takes the shape (see batch_norm_train), the composition of conv_autograd and batch_norm_train else"""
+    _lib.require_gpu()
+    Cout = weight.shape[-1]
+    res_f = None if residual is None else residual.F
+    if (not FUSE_CONV_BN or not BN_TRAIN_HIP or Cout > 256 or Cout % 4 or not bn.affine or not bn.track_running_stats
+            or bn.momentum is None or (res_f is not None and res_f.dtype != torch.float32)):
+        y = conv_autograd(x, weight, kernel_size, stride, precision)
+        return SparseTensor(batch_norm_train(y.F, bn, act if act else False, res_f), y.cs)
+    K = kernel_size ** 3
+    in_cs = x.cs
+    out_cs = in_cs if stride == 1 else in_cs.strided(stride)
+    if out_cs.n < 2:
+        y = conv_autograd(x, weight, kernel_size, stride, precision)
+        return SparseTensor(batch_norm_train(y.F, bn, act if act else False, res_f), y.cs)
+    nbr = None if (kernel_size == 1 and stride == 1) else in_cs.neighbours(out_cs, kernel_size, in_cs.stride)
+    assert (weight.shape[0] if weight.dim() == 3 else 1) == K
+    out = _ConvBnActFn.apply(x.F, weight, bn.weight, bn.bias, res_f, nbr, out_cs.n, precision,
+                             out_cs is in_cs and kernel_size % 2 == 1, (in_cs, out_cs, kernel_size) if K == 27 else None,
+                             bn.eps, {None: 0, "relu": 1, "elu": 2}[act], bn.momentum, bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked)
+    return SparseTensor(out, out_cs)
 
 
 def _wgrad_go(ctx, K, Cin, Cout):

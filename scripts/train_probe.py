@@ -46,6 +46,7 @@ for bn_hip in ((True, False, True, False) if AB else ()):
     torch.cuda.synchronize()
     print(f"  BatchNorm through {'the HIP kernels' if bn_hip else 'torch'}: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms per step", flush=True)
 S_.BN_TRAIN_HIP = os.environ.get("CNRMA_BN_HIP", "1") == "1"
+S_.FUSE_CONV_BN = os.environ.get("CNRMA_FUSE", "1") == "1"
 for _ in range(2): l = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 5 if AB else 28

@@ -375,3 +375,38 @@ def test_gather_once_bf16_forward_and_data_gradient_equal_the_stage_kernel(devic
     o1, o2 = np.lexsort(got_c.T[::-1]), np.lexsort(oc.T[::-1])
     assert np.array_equal(got_c[o1], oc[o2])
     np.testing.assert_allclose(res[True][0][o1], exp[o2], rtol=1e-5, atol=1e-5 * np.abs(exp).max())
+
+
+@pytest.mark.parametrize("inplanes,planes,stride,prec", [(64, 64, 1, "bf16"), (64, 128, 2, "bf16"), (32, 64, 1, None)])
+def test_fused_conv_batchnorm_node_equals_the_module_composition(device, inplanes, planes, stride, prec):
+    """a BasicBlock in training mode with conv -> BatchNorm -> [+ shortcut] -> ReLU as one autograd node
+    (sparse.conv_bn_act_train) against the same block composed module by module: outputs, every gradient and the running
+    statistics (the same kernels in the same order: equal up to nothing but identical launches -> exact)"""
+    import copy
+    from cnrma_amd import nn as snn, sparse as S
+    rng = np.random.RandomState(inplanes + planes + stride)
+    c = np.unique(np.concatenate((rng.randint(0, 2, size=(7000, 1)), rng.randint(-12, 12, size=(7000, 3))), axis=1), axis=0)
+    f = rng.randn(len(c), inplanes).astype(np.float32)
+    down = None
+    if stride != 1 or inplanes != planes:
+        down = snn.FusedSequential(snn.MinkowskiConvolution(inplanes, planes, kernel_size=1, stride=stride, dimension=3),
+                                   snn.MinkowskiBatchNorm(planes))
+    torch.manual_seed(3)
+    blk = snn.BasicBlock(inplanes, planes, stride=stride, downsample=down).to(device).train()
+    res = {}
+    for fused in (True, False):
+        b = copy.deepcopy(blk)
+        S.FUSE_CONV_BN = fused
+        try:
+            x = S.SparseTensor(torch.from_numpy(f).to(device).requires_grad_(True), S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 1))
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=prec == "bf16"):
+                y = b(x)
+            g = torch.from_numpy(np.random.RandomState(1).randn(*y.F.shape).astype(np.float32)).to(device)
+            y.F.backward(g)
+        finally:
+            S.FUSE_CONV_BN = True
+        res[fused] = ([y.F.detach().cpu().numpy(), x.F.grad.cpu().numpy()] + [p.grad.cpu().numpy() for p in b.parameters()]
+                      + [bf.cpu().numpy().astype(np.float64) for bf in b.buffers()])
+    assert len(res[True]) == len(res[False]) > 6
+    for a, e in zip(res[True], res[False]):
+        np.testing.assert_array_equal(a, e)
