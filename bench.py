@@ -141,6 +141,10 @@ def parse():
                          "nchw = the reference's layout, converted by the layout pass inside the timed path")
     ap.add_argument("--detail", default="", help="where the full result (kernel tables, per-layer convolution table, stage times, notes) "
                     "goes; default: bench_detail.json beside bench.py (and a copy under gpurun_out/ when that directory exists)")
+    ap.add_argument("--dump-exchange", default="", help="test aid: directory that receives, after the last timed step of the main "
+                    "workload, every rank's own padded detections (rank<r>_of<N>.npz) and rank 0's gathered block (gathered.npz)")
+    ap.add_argument("--as-rank", type=int, default=-1, help="test aid (single process): generate the scenes rank R of a multi-rank "
+                    "run would generate")
     ap.add_argument("--dense-tuning", default="", help="A/B aid: schedule switches of the dense kernel for this run, e.g. "
                     "'variant=0' = the round-2 kernel (cnrma_debug_dense_tuning; never set by the driver)")
     return ap.parse_args()
@@ -361,17 +365,20 @@ def cpu_baseline(shape_name, Ms_full, C):
 class Workload:
     """>= n_scenes distinct synthetic scenes of one shape resident in HBM + `slots` captured scene graphs"""
 
-    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6, plugin=False, layout=None):
+    def __init__(self, name, device, rank, world, args, n_classes=18, n_reg=6, plugin=False, layout=None,
+                 config="ray_marching_scannet.py"):
         import torch
         self.plugin = plugin
+        self.config_file = config
         self.layout = layout or args.feature_layout
         from cnrma_amd import pipeline, synth
         self.torch, self.pipeline = torch, pipeline
         self.name, self.device, self.rank, self.world, self.args = name, device, rank, world, args
         self.V, self.C, self.H, self.W, self.dims, self.stride = synth.SHAPES[name]
         self.scenes = []
+        self.seed_rank = rank if getattr(args, "as_rank", -1) < 0 else args.as_rank
         for i in range(args.scenes):
-            sc = synth.make_scene(name, seed=1000 * rank + i, boxes=2 + i % 4, device=device, channels_last=self.layout == "channels_last")
+            sc = synth.make_scene(name, seed=1000 * self.seed_rank + i, boxes=2 + i % 4, device=device, channels_last=self.layout == "channels_last")
             f = sc["features"][:, 0]                       # [V,C,H,W]; channels_last: a permuted view of a [V,H,W,C] block
             self.scenes.append(dict(features=f if self.layout == "channels_last" else f.contiguous(), projection=sc["projection"][:, 0],
                                     tsdf=sc["tsdf"][0, 0].to(device)))
@@ -396,7 +403,7 @@ class Workload:
         import torch
         import projects.mvsdetection  # noqa: F401
         from projects.mvsdetection.registry import build_model as build_detector
-        cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
+        cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", self.config_file))
         m = dict(cfg["model"])
         self.save_dir = tempfile.mkdtemp(prefix="cnrma_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         # the config's model section as shipped (max_points, point sampler, graph path: its defaults); only what defines the
@@ -614,7 +621,7 @@ def time_windows(wl, args, world, barrier):
     return sps, secs
 
 
-def measure(name, device, rank, world, args, barrier, precision=None, plugin=False, layout=None):
+def measure(name, device, rank, world, args, barrier, precision=None, plugin=False, layout=None, config=None):
     """build + time one workload; returns the result block"""
     import torch
     from cnrma_amd import sparse as S
@@ -623,13 +630,22 @@ def measure(name, device, rank, world, args, barrier, precision=None, plugin=Fal
         S.CONV_PRECISION = precision
     try:
         log(f"workload {name}{' (' + precision + ' conv)' if precision else ''}: generating {args.scenes} scenes")
-        wl = Workload(name, device, rank, world, args, plugin=plugin, layout=layout)
+        wl = Workload(name, device, rank, world, args, plugin=plugin, layout=layout, **({"config": config} if config else {}))
         log("calibrating + capturing the scene graphs")
         wl.build()
         log("timing")
         c0 = os.times()
         sps, secs = time_windows(wl, args, world, barrier)
         c1 = os.times()
+        if getattr(args, "dump_exchange", "") and not plugin and precision is None and layout is None and getattr(wl, "det", None) is not None:
+            import numpy as np
+            torch.cuda.synchronize()
+            os.makedirs(args.dump_exchange, exist_ok=True)
+            np.savez(os.path.join(args.dump_exchange, f"rank{wl.seed_rank}_of{world}.npz"), det=wl.det.cpu().numpy(),
+                     valid=wl.det_valid.cpu().numpy(), sizes=np.asarray(wl.slots[0].out["sizes"], dtype=np.int64))
+            if world > 1 and rank == 0:
+                np.savez(os.path.join(args.dump_exchange, "gathered.npz"), det_all=wl.det_all.cpu().numpy(),
+                         valid_all=wl.valid_all.cpu().numpy())
         bad = wl.violations()
         med = sorted(secs)[len(secs) // 2]
         block = dict(value=world * args.steps * sps / med, ms_per_step=med / args.steps * 1e3, ms_per_scene=med / args.steps / sps * 1e3,
@@ -766,6 +782,7 @@ def train_block(device, steps=8, warm=3):
     for _ in range(warm):
         loss = step()
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()        # the block's own peak, not that of the inference workloads measured before it
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
@@ -839,9 +856,9 @@ def compact_line(result):
                          conv_ms_per_scene=(s.get("conv") or {}).get("ms_per_scene"),
                          conv_mfma_busy=(s.get("conv") or {}).get("mfma_busy_gather_once"),
                          roofline=_roof(s.get("roofline")), cpu_baseline=_cpu(s.get("cpu_baseline"), sample=False))
-    for k in ("through_plugin", "nchw_input", "f32_conv", "St", "train_S"):
+    for k in ("through_plugin", "nchw_input", "f32_conv", "St", "A", "train_S"):
         if result.get(k):
-            line[k] = {kk: result[k][kk] for kk in ("value", "ms_per_step") if kk in result[k]}
+            line[k] = {kk: result[k][kk] for kk in ("value", "ms_per_step", "graph_nodes_per_scene", "n_reg_outs") if kk in result[k]}
     if result.get("dist"):
         d = result["dist"]
         line["dist"] = dict(world_size=d.get("world_size"), backend=d.get("backend"))
@@ -849,7 +866,7 @@ def compact_line(result):
     line = _r(line)
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     if len(text) >= LINE_LIMIT:                                          # never print a line the driver cannot parse
-        for k in ("train_S", "St", "f32_conv", "nchw_input", "through_plugin", "dist"):
+        for k in ("train_S", "St", "A", "f32_conv", "nchw_input", "through_plugin", "dist"):
             line.pop(k, None)
         line["config"] = {k: v for k, v in line["config"].items() if k in ("workload", "scenes_per_step")}
         line["config"]["workload"] = line["config"].get("workload", "")[:200]
@@ -1015,6 +1032,28 @@ def main():
                                             "plan_violations", "graph_nodes_per_scene", "M_rows", "M_selected", "M_unique", "level_rows", "head_rows")}
         result["St"]["workload"] = "St: ScanNet test shape, V=50, C=32, 120x160 maps (stride 4), grid 256x256x96 (ray_marching_scannet.py:16,19)"
         del wlt
+        torch.cuda.empty_cache()
+    if not args.no_secondary and not args.through_plugin:
+        # ---- BASELINE configs[2]: the ARKitScenes detector (ray_marching_arkit.py: 17 classes, 8 regression outputs, yaw decode)
+        # built from its shipped model section and driven through the plugin API at its own shape (40 views, 192 x 192 x 80)
+        try:
+            wla, ba = measure("S", device, rank, world, args, barrier, plugin=True, config="ray_marching_arkit.py")
+            head = wla.model.detection_head
+            result["A"] = {k: ba[k] for k in ("value", "ms_per_step", "ms_per_scene", "scenes_per_step", "windows_scenes_per_s",
+                                              "plan_violations", "graph_nodes_per_scene", "M_rows", "M_selected", "M_unique",
+                                              "level_rows", "head_rows") if k in ba}
+            result["A"].update(n_classes=int(head.n_classes), n_reg_outs=int(head.n_reg_outs),
+                               workload="A: projects/configs/mvsdetection/ray_marching_arkit.py model section through the plugin "
+                                        "(model(return_loss=False, ...) per scene, result files on tmpfs): V=40, C=32, 120x160 maps "
+                                        "(stride 4), grid 192x192x80, oriented boxes (BASELINE configs[2])")
+            import shutil
+            shutil.rmtree(wla.save_dir, ignore_errors=True)
+            del wla, head
+        except Exception as e:                                           # noqa: BLE001 -- a secondary block must not cost the line
+            if world > 1:
+                raise                                                    # the windows hold collectives: no rank may skip them alone
+            log(f"A block failed: {e!r}")
+            result["A"] = None
         torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_secondary and not args.through_plugin:
         log("training step at the ScanNet shape (bf16 autocast)")

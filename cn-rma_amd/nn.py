@@ -103,12 +103,24 @@ class MinkowskiBatchNorm(nn.Module):
                 self._folded = {key: S.fold_bn(self.bn, bias)}
         return self._folded[key]
 
+    def batch_stats(self):
+        """True when this layer normalises with batch statistics and updates the running ones.  Frozen BatchNorm inside a
+        train-mode network (mmcv's norm_eval walks modules() and calls .eval() on the nn.BatchNorm1d, i.e. on self.bn, or on
+        this wrapper) must keep its running statistics: every fused training path asks here first."""
+        return self.training and self.bn.training
+
     def forward(self, x, relu=False, residual=None):
         """relu / residual (training mode): [relu]( bn(x) [+ residual.F] ) in one pass (S.batch_norm_train)"""
-        if self.training:
+        if self.batch_stats():
             return S.SparseTensor(S.batch_norm_train(x.F, self.bn, relu, None if residual is None else residual.F), x.cs)
-        scale, shift = self.folded()
-        y = x.F * scale + shift
+        if torch.is_grad_enabled() and (self.bn.weight.requires_grad or self.bn.bias.requires_grad):
+            # frozen statistics, trainable affine map (fine-tuning): torch's eval-mode batch_norm keeps the gradients of
+            # weight / bias, which the cached folded() constants would cut
+            y = nn.functional.batch_norm(x.F, self.bn.running_mean, self.bn.running_var, self.bn.weight, self.bn.bias, False, 0.0,
+                                         self.bn.eps)
+        else:
+            scale, shift = self.folded()
+            y = x.F * scale + shift
         if residual is not None:
             y = y + residual.F
         y = nn.functional.elu(y) if relu == "elu" else (torch.relu(y) if relu else y)
@@ -185,11 +197,11 @@ class FusedSequential(nn.Sequential):
                 x = S.instance_norm_max_pool(x, m.weight, m.bias, m.eps, relu=True, kernel_size=nxt2.kernel_size, stride=nxt2.stride)
                 i += 3
             elif self.training and isinstance(m, MinkowskiConvolution) and isinstance(nxt, MinkowskiBatchNorm) and \
-                    torch.is_grad_enabled():
+                    nxt.batch_stats() and torch.is_grad_enabled():
                 act = _act_name(nxt2)                          # conv -> BatchNorm -> [ReLU / ELU]: one autograd node
                 x = _conv_bn_act(m, nxt, x, act)
                 i += 3 if act else 2
-            elif self.training and isinstance(m, MinkowskiBatchNorm) and _act_name(nxt) is not None:
+            elif self.training and isinstance(m, MinkowskiBatchNorm) and m.batch_stats() and _act_name(nxt) is not None:
                 x = m(x, relu=_act_name(nxt))                  # BatchNorm + ReLU / ELU in one pass (S.batch_norm_train)
                 i += 2
             elif isinstance(m, MinkowskiInstanceNorm) and isinstance(nxt, MinkowskiReLU):
@@ -203,8 +215,9 @@ class FusedSequential(nn.Sequential):
 
 def _conv_bn_act(conv, norm, x, act=None, residual=None):
     """training mode: conv -> BatchNorm -> [+ residual] -> act as one autograd node (S.conv_bn_act_train) for bias-free
-    convolutions; the module-by-module composition otherwise"""
-    if conv.bias is None and isinstance(conv, MinkowskiConvolution):
+    convolutions whose BatchNorm runs on batch statistics; the module-by-module composition otherwise (a frozen BatchNorm --
+    norm.eval() / norm.bn.eval() inside a train-mode block -- normalises with its running statistics and leaves them alone)"""
+    if conv.bias is None and isinstance(conv, MinkowskiConvolution) and norm.batch_stats():
         return S.conv_bn_act_train(x, conv.kernel, norm.bn, conv.kernel_size, conv.stride, act, residual)
     return norm(conv(x), relu=act if act else False, residual=residual)
 

@@ -92,7 +92,23 @@ def test_northstar_march_full_size_invariants(device):
     nhwc = rma.to_nhwc(sc["features"][:, 0].to(device))
     pinv = rma.projection_inverse(sc["projection"][:, 0], 1).to(device)
     tsdf = sc["tsdf"][0, 0].to(device)
-    a, pa = rma.rma_view_rows(nhwc, pinv, tsdf, sc["dims"], 0.04, sc["origin"], single_march=True)
+    # the free-space skip table is a default of this size only ("auto": from MARCH_SKIP_MIN_RAYS rays on): assert that it WAS in
+    # use -- table builder and march both handed a non-null skip pointer -- or the comparison below proves nothing about it
+    assert rma.MARCH_SKIP == "auto" and 40 * 480 * 640 >= rma.MARCH_SKIP_MIN_RAYS
+    seen, orig = {}, rma.call
+
+    def spy(name, *args):
+        if name == "cnrma_rma_march_tables_f32":
+            seen["tables_skip"] = args[5]
+        elif name == "cnrma_rma_neus_march_f32":
+            seen["march_skip"] = args[-2]
+        return orig(name, *args)
+    rma.call = spy
+    try:
+        a, pa = rma.rma_view_rows(nhwc, pinv, tsdf, sc["dims"], 0.04, sc["origin"], single_march=True)
+    finally:
+        rma.call = orig
+    assert seen.get("tables_skip") and seen.get("march_skip") and seen["tables_skip"] == seen["march_skip"], seen
     assert a.shape[0] > 60_000_000 and bool((pa > 1_000_000).all())
     b, pb = rma.rma_view_rows(nhwc, pinv, tsdf, sc["dims"], 0.04, sc["origin"], single_march=False)
     assert torch.equal(pa, pb) and torch.equal(a.view(torch.int32), b.view(torch.int32))

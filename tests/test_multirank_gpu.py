@@ -39,6 +39,52 @@ def test_bench_spawns_its_ranks_and_exchanges_detections(tmp_path):
     assert abs(r["value"] - d["value"]) < 1e-3 * d["value"]                 # the line rounds to 4 significant digits
 
 
+def test_eight_rank_rehearsal_gathers_what_eight_single_ranks_compute(tmp_path):
+    """BASELINE configs[3] rehearsed on what exists: `bench.py --gpus 8` on ONE device over gloo --
+    rank r works on the scenes of seed block r -- against eight single-process runs of the same blocks: the gathered
+    [8, S, K, W] block of the last step equals the eight single-rank results row for row (bit for bit: the same graphs, the
+    same seeds), and the line's `dist` block reports world size 8.  No scaling number: all ranks share one GPU."""
+    import numpy as np
+    common = ["--workload", "tiny", "--steps", "2", "--warmup", "1", "--scenes", "2", "--slots", "2", "--windows", "1",
+              "--scenes-per-step", "2", "--no-secondary", "--no-cpu-baseline", "--no-profile"]
+    multi = tmp_path / "multi"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dump-exchange", str(multi),
+           "--detail", str(tmp_path / "detail8.json")] + common
+    p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 8 and r["dist"] == {"world_size": 8, "backend": "gloo"} and r["plan_violations"] == 0
+    g = np.load(multi / "gathered.npz")
+    det_all, valid_all = g["det_all"], g["valid_all"]
+    assert det_all.shape[0] == 8 and det_all.shape[1] == 2 and valid_all.shape[:2] == (8, 2)
+    single = tmp_path / "single"
+    procs = []
+    for rk in range(8):                                       # four at a time: each is a fresh process with its own graphs
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--as-rank", str(rk), "--dump-exchange", str(single),
+               "--detail", str(tmp_path / f"detail1_{rk}.json")] + common
+        procs.append(subprocess.Popen(cmd, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+        if len(procs) == 4 or rk == 7:
+            for q in procs:
+                out, err = q.communicate(timeout=900)
+                assert q.returncode == 0, err[-3000:]
+            procs = []
+    some = 0
+    for rk in range(8):
+        own = np.load(multi / f"rank{rk}_of8.npz")             # what rank rk itself held when the exchange ran
+        one = np.load(single / f"rank{rk}_of1.npz")            # the same scenes in a process that knows no other rank
+        # (bit patterns: rows behind the live ones are whatever the static buffers held, NaN patterns included)
+        assert np.array_equal(det_all[rk].view(np.int32), own["det"].view(np.int32)) and np.array_equal(valid_all[rk], own["valid"])
+        assert np.array_equal(valid_all[rk], one["valid"]) and np.array_equal(own["sizes"], one["sizes"]), rk
+        for sc in range(det_all.shape[1]):                     # live rows of every level block (rows behind them are padding)
+            r0 = 0
+            for k, v in zip(one["sizes"], valid_all[rk, sc]):
+                assert np.array_equal(det_all[rk, sc, r0:r0 + v].view(np.int32), one["det"][sc, r0:r0 + v].view(np.int32)), (rk, sc)
+                r0 += int(k)
+        some += int(valid_all[rk].sum())
+    assert some > 0                                           # the blocks hold detections, not padding only
+    assert len({det_all[rk].tobytes() for rk in range(8)}) == 8      # eight different scene blocks
+
+
 def test_ddp_gradient_allreduce():
     port = 29600 + os.getpid() % 1000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",

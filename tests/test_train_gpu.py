@@ -171,6 +171,48 @@ def test_eval_mode_forward_keeps_gradients_when_asked(device):
     assert x.grad is not None and float(x.grad.abs().sum()) > 0 and blk.conv1.kernel.grad is not None
 
 
+@pytest.mark.parametrize("how", ["wrapper", "inner"])
+def test_frozen_batchnorm_inside_a_train_mode_block_keeps_its_statistics(device, how):
+    """norm_eval fine-tuning: the block stays in train mode, its BatchNorms are frozen with .eval() -- on the
+    MinkowskiBatchNorm wrapper or, as mmcv's norm_eval does by walking modules(), on the nn.BatchNorm1d inside it.  The fused
+    conv -> BatchNorm node must not be taken: running statistics untouched, output = the eval-mode (folded) block's, gradients
+    still reach the input, the kernels and the BatchNorm's affine parameters."""
+    from cnrma_amd import nn as snn
+    from cnrma_amd import sparse as S
+    rng = np.random.RandomState(11)
+    c = np.unique(np.concatenate((np.zeros((3000, 1), dtype=np.int64), rng.randint(0, 24, size=(3000, 3)) * 2), axis=1), axis=0)
+    f = torch.from_numpy(rng.randn(len(c), 32).astype(np.float32)).to(device)
+    cs = S.CoordSet(torch.from_numpy(c.astype(np.int32)).to(device), 2)
+    blk = snn.BasicBlock(32, 32).to(device)
+    seq = snn.FusedSequential(snn.MinkowskiConvolution(32, 32, kernel_size=3), snn.MinkowskiBatchNorm(32), snn.MinkowskiELU()).to(device)
+    norms = [blk.norm1, blk.norm2, seq[1]]
+    with torch.no_grad():
+        for n in norms:
+            n.bn.running_mean.normal_(0, 0.1); n.bn.running_var.uniform_(0.5, 1.5)
+            n.bn.weight.uniform_(0.5, 1.5); n.bn.bias.normal_(0, 0.1)
+    blk.eval(); seq.eval()
+    with torch.no_grad():
+        ref_blk, ref_seq = blk(S.SparseTensor(f, cs)).F, seq(S.SparseTensor(f, cs)).F
+    blk.train(); seq.train()
+    for n in norms:
+        (n if how == "wrapper" else n.bn).eval()
+    before = [(n.bn.running_mean.clone(), n.bn.running_var.clone(), n.bn.num_batches_tracked.clone()) for n in norms]
+    x = f.clone().requires_grad_(True)
+    y_blk, y_seq = blk(S.SparseTensor(x, cs)).F, seq(S.SparseTensor(x, cs)).F
+    for n, (m, v, k) in zip(norms, before):
+        assert torch.equal(n.bn.running_mean, m) and torch.equal(n.bn.running_var, v) and torch.equal(n.bn.num_batches_tracked, k)
+    np.testing.assert_allclose(y_blk.detach().cpu().numpy(), ref_blk.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(y_seq.detach().cpu().numpy(), ref_seq.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    (y_blk.square().sum() + y_seq.square().sum()).backward()
+    assert x.grad is not None and float(x.grad.abs().sum()) > 0
+    assert blk.conv1.kernel.grad is not None and blk.norm2.bn.weight.grad is not None and seq[1].bn.bias.grad is not None
+    # and the unfrozen block does update them (the fused node is still what runs in plain training)
+    for n in norms:
+        n.train()
+    blk(S.SparseTensor(f, cs))
+    assert not torch.equal(blk.norm1.bn.running_mean, before[0][0])
+
+
 def test_full_size_train_step_at_scannet_shape(device, tmp_path):
     """BASELINE configs[4] on one GPU at FULL size: RayMarching.train_step at the ScanNet training shape (40 views x 32 ch x
     120x160 -> 192x192x80, 4.14 M aggregated rows, max_points 500 000 drawn on the device, MinkResNet34 + head, the three
