@@ -1,6 +1,12 @@
 """ctypes binding of csrc/libcnrma_hip.so (the C-ABI declared in include/cnrma.h).
 
 The product path has NO fallback: if the library is missing or a symbol is absent this module raises.
+
+Two libraries are built from the same sources: libcnrma_hip.so (the product: shipped kernels only, no cnrma_debug_* entry point,
+no tuning state) and libcnrma_hip_exp.so (-DCNRMA_EXPERIMENTS: + the measured-and-rejected kernel forms behind
+cnrma_debug_conv_tuning / cnrma_debug_dense_tuning).  Product code only ever sees the first; `experiments(True)` -- called by
+sparse.conv_tuning(...) / rma.dense_tuning(...) with arguments, i.e. by scripts/ and by the bit-identity tests -- routes this
+process's calls through the second until `experiments(False)`.
 """
 import ctypes
 import threading
@@ -9,6 +15,7 @@ from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcnrma_hip.so")
+EXP_LIB_PATH = os.path.join(_HERE, "csrc", "libcnrma_hip_exp.so")
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
@@ -19,7 +26,6 @@ SIGNATURES = {
     "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
     "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
     "cnrma_backproject_accum_ref_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
-    "cnrma_debug_dense_tuning": (c_int, [P, I]),
     "cnrma_backproject_backward_f32": (c_int, [P, P, P, I, I, I, I, I, I, I, F, F, F, F, P, P]),
     "cnrma_backproject_index_f32": (c_int, [P, I, I, I, I, I, F, F, F, F, P, P, P, P]),
     "cnrma_ray_params_f32": (c_int, [P, I, I, I, P, P, P]),
@@ -28,7 +34,6 @@ SIGNATURES = {
                                         P, I, P, I, P, I, P, P]),
     "cnrma_rma_neus_rows_backward_f32": (c_int, [P, I, I, I, I, I, P, P, I, P, P, P, P]),
     "cnrma_rma_sigmoid_table_f32": (c_int, [P, L, P, P]),
-    "cnrma_debug_div_by_voxel_size_f32": (c_int, [P, L, F, P, P, P]),
     "cnrma_rma_skip_table_bytes": (c_size_t, [I, I, I]),
     "cnrma_rma_march_tables_f32": (c_int, [P, I, I, I, P, P, P]),
     "cnrma_rma_neus_march_f32": (c_int, [P, P, P, I, I, I, I, I, I, F, F, F, F, I, F, F, P, P, P, I, P, P, P]),
@@ -61,7 +66,6 @@ SIGNATURES = {
     "cnrma_sparse_kernel_map_strided": (c_int, [P, L, P, I, I, P, P, L, P, L, I, P]),
     "cnrma_sparse_conv_workspace_bytes": (c_size_t, [L, I, I]),
     "cnrma_sparse_conv_plan": (c_int, [L, I, I, I, I, I, c_size_t, P]),
-    "cnrma_debug_conv_tuning": (c_int, [P, I]),
     "cnrma_sparse_conv_f32": (c_int, [P, I, P, I, P, I, P, P, P, I, P, L, P, P, c_size_t, P]),
     "cnrma_sparse_conv_weight_bytes": (c_size_t, [I, I, I]),
     "cnrma_sparse_conv_prepare_weights": (c_int, [P, I, I, I, P, P]),
@@ -121,31 +125,61 @@ SIGNATURES = {
     "cnrma_fcaf3d_scores_f32": (c_int, [P, P, L, I, P, P, P]),
 }
 
-_lib = None
-ABI_VERSION = 5
+# libcnrma_hip_exp.so exports these on top of SIGNATURES (include/cnrma.h: the prototypes under #ifdef CNRMA_EXPERIMENTS)
+EXPERIMENT_SIGNATURES = {
+    "cnrma_debug_dense_tuning": (c_int, [P, I]),
+    "cnrma_debug_div_by_voxel_size_f32": (c_int, [P, L, F, P, P, P]),
+    "cnrma_debug_conv_tuning": (c_int, [P, I]),
+}
+
+_libs = {}            # False: product library, True: experiments library
+_active = False       # which of the two load() / call() use
+_exp_users = set()    # who asked for the experiments library ("conv", "dense", a test): product again when nobody is left
+ABI_VERSION = 6
 
 
 class CnrmaError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library once; raise loudly when it is not built (no CPU fallback exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise CnrmaError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py build` "
+def load(experiments=None):
+    """The library this process's calls go to, loaded once; raises loudly when it is not built (no CPU fallback exists).
+    experiments: None = the active one (the product library unless experiments(True) was called), False / True = that one."""
+    which = _active if experiments is None else bool(experiments)
+    lib = _libs.get(which)
+    if lib is not None:
+        return lib
+    path = EXP_LIB_PATH if which else LIB_PATH
+    if not os.path.exists(path):
+        raise CnrmaError(f"{path} not found: build it with `python __graft_entry__.py build` "
                          f"(or `make -C cn-rma_amd/csrc`). There is no CPU fallback for the product path.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    lib = ctypes.CDLL(path)
+    table = dict(SIGNATURES, **EXPERIMENT_SIGNATURES) if which else SIGNATURES
+    for name, (res, args) in table.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     if lib.cnrma_abi_version() != ABI_VERSION:
         raise CnrmaError("ABI version mismatch")
-    _lib = lib
+    _libs[which] = lib
     return lib
+
+
+def experiments(on=True, who="caller"):
+    """route this process's C-ABI calls through libcnrma_hip_exp.so (True) or back through the product library (False, once
+    every `who` that asked for it has let go).  The two libraries are the same sources; the experiments one adds kernels and the
+    cnrma_debug_* switches.  Never called by product code."""
+    global _active
+    if on:
+        load(True)
+        _exp_users.add(who)
+    else:
+        _exp_users.discard(who)
+    _active = bool(_exp_users)
+
+
+def experiments_active():
+    return _active
 
 
 def ptr(t):

@@ -138,99 +138,6 @@ __global__ __launch_bounds__(256) void backproject_accum_kernel(DenseParams p, c
   if (blockIdx.y == 0) count[g] = cnt;
 }
 
-// ---- cooperative-gather variant (C % 4 == 0) -------------------------------------------------------------------
-// A wave owns 64 consecutive voxels.  Per view every lane projects ITS voxel; then the wave walks the voxels in
-// groups of 64/LPV and LPV lanes read one pixel's channel vector together (LPV x 16 B = one full 128-B line at
-// C = 32), so a gather instruction touches 64/LPV lines instead of 64 and every fetched byte is used.  Lane l ends
-// up holding channels 4*(l % LPV) .. +3 of voxels (g * 64/LPV + l / LPV), g = 0 .. LPV-1.
-template <int LPV>
-__global__ __launch_bounds__(256) void backproject_accum_coop_kernel(DenseParams p, const float* __restrict__ feat,
-                                                                     const float* __restrict__ proj,
-                                                                     float* __restrict__ volume,
-                                                                     int32_t* __restrict__ count, int chunk_blocks,
-                                                                     int64_t n_phys, SlabOrder ord) {
-  constexpr int VPG = 64 / LPV;              // voxels served per gather instruction
-  const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  const int lane = threadIdx.x & 63;
-  // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group), each with a
-  // private L2.  A pixel's channel vector is re-read by the ~9 voxels along its ray; with consecutive blocks on
-  // different XCDs every one of those reads misses its L2 (profiles/r02: 22 % hit rate, 80 GB over the fabric per launch
-  // at the north-star shape against 20 GB of compulsory traffic).  Here an XCD group owns whole chunks of `chunk_blocks`
-  // consecutive blocks (one x-plane of the grid) -- chunks c, c + 8, c + 16, ... --, so rays that run inside a plane find
-  // their pixels in the group's L2; the chunks stay interleaved over the whole grid, which keeps the groups evenly
-  // loaded (8 contiguous slabs, one per XCD, measured 17 % slower: the frustum makes slabs unequal).
-  // persistent form: the grid may be smaller than the number of logical blocks (gridDim.x a multiple of 8, so that
-  // b % 8 -- the XCD group -- is the same for every logical block a workgroup takes); each workgroup walks
-  // pb = blockIdx.x, blockIdx.x + gridDim.x, ...
-  for (int64_t pb = blockIdx.x; pb < n_phys; pb += gridDim.x) {
-  int64_t lb = pb;
-  if (chunk_blocks > 0) {
-    const int64_t grp = pb & 7, k = pb >> 3;
-    lb = (grp + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
-  }
-  const int64_t wave_base = (lb * blockDim.x + threadIdx.x) - lane;
-  const int64_t g = wave_base + lane;
-  const int c0 = blockIdx.y * (4 * LPV);
-  float wx = 0.f, wy = 0.f, wz = 0.f;
-  bool in_grid;
-  int64_t lin = -1;                               // this lane's voxel as an index into [X][Y][Z] (-1: none)
-  if (ord.on) {
-    int x = 0, y = 0, z = 0;
-    in_grid = slab_decode(p, ord, g, &x, &y, &z);
-    if (__ballot(in_grid) == 0ull) continue;
-    if (in_grid) {
-      lin = ((int64_t)x * p.Y + y) * p.Z + z;
-      wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;      // as voxel_world()
-    }
-  } else {
-    if (wave_base >= G) continue;
-    in_grid = g < G;
-    if (in_grid) { voxel_world(p, g, &wx, &wy, &wz); lin = g; }
-  }
-  float4 acc[LPV];
-#pragma unroll
-  for (int i = 0; i < LPV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  int cnt = 0;
-  const int sub = lane % LPV, vsel = lane / LPV;
-  const int64_t plane = (int64_t)p.H * p.W * p.C;
-  for (int v = 0; v < p.V; ++v) {
-    float rx, ry;
-    const bool ok = in_grid && project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry);
-    const unsigned long long any = __ballot(ok);
-    if (any == 0ull) continue;
-    cnt += ok ? 1 : 0;
-    const int pix = ok ? ((int)ry * p.W + (int)rx) : -1;
-    const float* fv = feat + v * plane + c0 + 4 * sub;
-#pragma unroll
-    for (int grp = 0; grp < LPV; ++grp) {
-      if (((any >> (grp * VPG)) & ((VPG == 64) ? ~0ull : ((1ull << VPG) - 1ull))) == 0ull) continue;   // wave-uniform
-      const int pq = __shfl(pix, grp * VPG + vsel, 64);
-      if (pq >= 0) {
-        const float4 q = *reinterpret_cast<const float4*>(fv + (int64_t)pq * p.C);
-        acc[grp].x += q.x; acc[grp].y += q.y; acc[grp].z += q.z; acc[grp].w += q.w;
-      }
-    }
-  }
-  // the count of the voxel a lane accumulates for (group grp) lives in lane grp*VPG + vsel
-#pragma unroll
-  for (int grp = 0; grp < LPV; ++grp) {
-    const int cv = __shfl(cnt, grp * VPG + vsel, 64);
-    const int lo = __shfl((int)(lin & 0xffffffffLL), grp * VPG + vsel, 64), hi = __shfl((int)(lin >> 32), grp * VPG + vsel, 64);
-    const int64_t gv = ((int64_t)hi << 32) | (uint32_t)lo;
-    if (gv >= 0) {
-      const float denom = (float)cv;
-      const float4 a = acc[grp];
-      const int c = c0 + 4 * sub;
-      volume[(int64_t)(c + 0) * G + gv] = cv > 0 ? a.x / denom : 0.0f;
-      volume[(int64_t)(c + 1) * G + gv] = cv > 0 ? a.y / denom : 0.0f;
-      volume[(int64_t)(c + 2) * G + gv] = cv > 0 ? a.z / denom : 0.0f;
-      volume[(int64_t)(c + 3) * G + gv] = cv > 0 ? a.w / denom : 0.0f;
-    }
-  }
-  if (blockIdx.y == 0 && in_grid) count[lin] = cnt;
-  }
-}
-
 // ---- pipelined cooperative-gather kernel (round 3; the product kernel) ------------------------------------------------
 // Same lane <-> voxel / channel mapping and the same arithmetic as backproject_accum_coop_kernel (results bit-identical),
 // but built for memory-level parallelism.  The round-2 loop put every gather inside its own conditional block, and the
@@ -455,145 +362,9 @@ __global__ __launch_bounds__(256, PIPE == 1 ? 4 : 3) void backproject_accum_pipe
   }
 }
 
-// ---- hoisted kernel (variant 2) ------------------------------------------------------------------------------------------
-// Measured on the pipelined kernel: with feature maps small enough to sit in L2 it still needs 6.4 ms at the north-star
-// grid -- the loop body is VALU-bound (the projection, two IEEE divisions per voxel and view, is repeated in each of the 8
-// channel sweeps, for the 73 % of (voxel, view) pairs that are out of the frustum as well).  Here a workgroup handles ALL
-// channel sweeps of its 256 voxels: phase A projects every view once, keeps the pixel index of each (voxel, view) in LDS
-// ([wave][V][64] int32) and a wave-uniform bit mask of the views that see any of the wave's voxels; phase B runs the sweeps
-// over the SET bits only -- no projection, no work at all for views the wave is outside of -- with the gathers of the next
-// active view in flight while the current one is added (software pipeline of depth 2).
-// Lockstep form: bricks of st x st x 32; a workgroup takes 8 z-columns on a (st/2 x st/4) lattice over the brick instead of
-// a compact tile, so that all workgroups of a brick meet every view's frustum boundary in the same proportion and stay
-// in phase without waiting for each other (the compact assignment made the lockstep grid 2x slower: 20.8 vs 9.8 ms).
-template <int LPV, int LOCK>
-__global__ __launch_bounds__(256, 4) void backproject_accum_hoist_kernel(DenseParams p, const float* __restrict__ feat,
-                                                                         const float* __restrict__ proj,
-                                                                         float* __restrict__ volume,
-                                                                         int32_t* __restrict__ count, int chunk_blocks,
-                                                                         int64_t n_phys, SlabOrder ord,
-                                                                         unsigned int* __restrict__ bar, int use_barrier) {
-  extern __shared__ int32_t lds_pix[];                       // [4 waves][V][64]
-  constexpr int VPG = 64 / LPV;
-  const int64_t G = (int64_t)p.X * p.Y * p.Z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int32_t* wp = lds_pix + (size_t)wave * p.V * 64 + lane;
-  const int sub = lane % LPV, vsel = lane / LPV;
-  const int n_sweeps = (int)ceil_div_dev(p.C, 4 * LPV);
-  const uint32_t row_bytes = (uint32_t)p.C * 4u;
-  const int64_t plane = (int64_t)p.H * p.W * p.C;
-
-  const int grp_id = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int64_t n_chunks = chunk_blocks > 0 ? n_phys / chunk_blocks : 0;
-  for (int64_t it = 0;; ++it) {
-    int64_t lb;
-    if constexpr (LOCK != 0) {
-      const int64_t ch = grp_id + 8 * it;
-      if (ch >= n_chunks) break;
-      lb = ch * chunk_blocks + slot;
-    } else {
-      if (it > 0) break;
-      lb = blockIdx.x;
-      if (chunk_blocks > 0) {
-        const int64_t g8 = lb & 7, k = lb >> 3;
-        lb = (g8 + 8 * (k / chunk_blocks)) * chunk_blocks + k % chunk_blocks;
-      }
-    }
-    // ---- this lane's voxel
-    float wx = 0.f, wy = 0.f, wz = 0.f;
-    bool in_grid = false;
-    int64_t lin = -1;
-    if (LOCK != 0) {
-      int x = 0, y = 0, z = 0;
-      in_grid = lattice_decode(p, ord, lb, (int)threadIdx.x, &x, &y, &z);
-      if (in_grid) {
-        lin = ((int64_t)x * p.Y + y) * p.Z + z;
-        wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;
-      }
-    } else if (ord.on) {
-      int x = 0, y = 0, z = 0;
-      in_grid = slab_decode(p, ord, lb * 256 + threadIdx.x, &x, &y, &z);
-      if (in_grid) {
-        lin = ((int64_t)x * p.Y + y) * p.Z + z;
-        wx = (float)x * p.vs + p.ox; wy = (float)y * p.vs + p.oy; wz = (float)z * p.vs + p.oz;      // as voxel_world()
-      }
-    } else {
-      const int64_t g = lb * 256 + threadIdx.x;
-      in_grid = g < G;
-      if (in_grid) { voxel_world(p, g, &wx, &wy, &wz); lin = g; }
-    }
-    if (__ballot(in_grid) != 0ull) {
-      // ---- phase A: every projection once
-      unsigned long long active = 0ull;
-      int cnt = 0;
-      for (int v = 0; v < p.V; ++v) {
-        float rx, ry;
-        const bool ok = in_grid && project(proj + v * 12, wx, wy, wz, p.H, p.W, &rx, &ry);
-        wp[v * 64] = ok ? (int)(((uint32_t)(int)ry * (uint32_t)p.W + (uint32_t)(int)rx) * row_bytes) : -1;   // byte offset of the pixel row
-        cnt += ok ? 1 : 0;
-        if (__ballot(ok) != 0ull) active |= 1ull << v;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (in_grid) count[lin] = cnt;
-      // who writes which voxel: the count / linear index of the voxel a lane accumulates for (group grp) live in lane grp*VPG + vsel
-      // ---- phase B: the channel sweeps over the active views
-      for (int sw = 0; sw < n_sweeps; ++sw) {
-        const char* fbase = reinterpret_cast<const char*>(feat + sw * (4 * LPV) + 4 * sub);
-        float4 acc[LPV];
-#pragma unroll
-        for (int i = 0; i < LPV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto gather = [&](int v, float4* q) {
-          const int off = wp[v * 64];
-          const char* fv = fbase + (int64_t)v * plane * 4;
-#pragma unroll
-          for (int grp = 0; grp < LPV; ++grp) {
-            const int oq = __shfl(off, grp * VPG + vsel, 64);
-            q[grp] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oq >= 0) q[grp] = *reinterpret_cast<const float4*>(fv + (uint32_t)oq);
-          }
-        };
-        auto add = [&](const float4* q) {
-#pragma unroll
-          for (int grp = 0; grp < LPV; ++grp) {
-            acc[grp].x += q[grp].x; acc[grp].y += q[grp].y; acc[grp].z += q[grp].z; acc[grp].w += q[grp].w;
-          }
-        };
-        unsigned long long m = active;
-        float4 qa[LPV], qb[LPV];
-        bool has = m != 0ull;
-        if (has) { const int v = __builtin_ctzll(m); m &= m - 1; gather(v, qa); }
-        while (has) {
-          const bool hasb = m != 0ull;
-          if (hasb) { const int v = __builtin_ctzll(m); m &= m - 1; gather(v, qb); }
-          add(qa);
-          if (!hasb) break;
-          has = m != 0ull;
-          if (has) { const int v = __builtin_ctzll(m); m &= m - 1; gather(v, qa); }
-          add(qb);
-        }
-        const int c = sw * (4 * LPV) + 4 * sub;
-#pragma unroll
-        for (int grp = 0; grp < LPV; ++grp) {
-          const int cv = __shfl(cnt, grp * VPG + vsel, 64);
-          const int lo = __shfl((int)(lin & 0xffffffffLL), grp * VPG + vsel, 64), hi = __shfl((int)(lin >> 32), grp * VPG + vsel, 64);
-          const int64_t gv = ((int64_t)hi << 32) | (uint32_t)lo;
-          if (gv >= 0) {
-            const float denom = (float)cv;
-            const float4 a = acc[grp];
-            volume[(int64_t)(c + 0) * G + gv] = cv > 0 ? a.x / denom : 0.0f;
-            volume[(int64_t)(c + 1) * G + gv] = cv > 0 ? a.y / denom : 0.0f;
-            volume[(int64_t)(c + 2) * G + gv] = cv > 0 ? a.z / denom : 0.0f;
-            volume[(int64_t)(c + 3) * G + gv] = cv > 0 ? a.w / denom : 0.0f;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if constexpr (LOCK != 0) {
-      if (use_barrier) group_barrier(bar + grp_id * 32, (unsigned)chunk_blocks);
-    }
-  }
-}
+#ifdef CNRMA_EXPERIMENTS
+#include "dense_exp.inc"
+#endif
 
 // Debug / A-B switches of the dense kernel.  Product code never reads the environment: the defaults below ARE the shipped
 // configuration, and only cnrma_debug_dense_tuning() (scripts/dense_ab.py, tests of the alternative orders) changes them.
@@ -614,12 +385,19 @@ struct DenseTune {
   int lattice = 0;      // variant 1 lockstep: 1 = lattice assignment of columns to workgroups (balanced), 0 = compact tiles
   int lockstep = 0;     // variants 1, 2: persistent grid, every XCD group walks one brick at a time (1: behind a barrier, 2: no barrier)
 };
-static DenseTune g_tune;
+#ifdef CNRMA_EXPERIMENTS
+static DenseTune g_tune;                     // libcnrma_hip_exp.so only: written by cnrma_debug_dense_tuning
+#define CNRMA_DENSE_TUNE g_tune
+#else
+// the product library has no tuning state: the defaults above ARE the shipped configuration (pipelined kernel, brick order)
+static constexpr DenseTune k_dense_tune{};
+#define CNRMA_DENSE_TUNE k_dense_tune
+#endif
 
 template <int LPV>
 int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj, float* volume, int32_t* count,
                       unsigned int* bar, hipStream_t st, const float* const* feat_ref = nullptr) {
-  const DenseTune t = g_tune;
+  const DenseTune t = CNRMA_DENSE_TUNE;
   if (feat_ref != nullptr && t.variant != 1) return CNRMA_EINVAL;      // by-reference hand-off: the product kernel only
   const int64_t G = (int64_t)p.X * p.Y * p.Z;
   int64_t nb = ceil_div(G, 256);
@@ -638,6 +416,7 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   int64_t gx = nb;
   if (cb > 0 && (nb >= 16 * cb || ord.on)) gx = ceil_div(ceil_div(nb, cb), 8) * 8 * cb;      // whole chunks for every XCD group
   else cb = 0;
+#ifdef CNRMA_EXPERIMENTS
   if (t.variant == 0) {
     int64_t launch_x = gx;
     if (t.persist > 0 && gx > (int64_t)256 * t.persist) launch_x = (int64_t)256 * t.persist;     // a multiple of 8
@@ -659,11 +438,13 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
     CNRMA_LAUNCH_CHECK();
     return 0;
   }
+#endif
   const int lock = (t.lockstep == 1 && bar != nullptr && ord.on && cb > 0 && cb <= 256) ? 1 : 0;
   if (t.lattice && ord.on && ord.zt == 32 && ord.st % 8 == 0) ord.on = 2;
   const int n_sweeps = (int)ceil_div(p.C, 4 * LPV);
   if (t.own && !lock && ord.on && n_sweeps == 8 && nb * 8 < ((int64_t)1 << 31)) ord.own = 1;
   dim3 grid(lock ? (unsigned)(ord.groups * cb) : (ord.own ? (unsigned)(nb * 8) : (unsigned)gx), (lock || ord.own) ? 1u : (unsigned)n_sweeps);
+#ifdef CNRMA_EXPERIMENTS
 #define CNRMA_DENSE_LAUNCH(PIPE, EPI)                                                                                      \
   do {                                                                                                                     \
     if (lock)                                                                                                              \
@@ -676,6 +457,11 @@ int launch_accum_coop(const DenseParams& p, const float* feat, const float* proj
   if (t.pipe == 2) { if (t.epi) CNRMA_DENSE_LAUNCH(2, 1); else CNRMA_DENSE_LAUNCH(2, 0); }
   else             { if (t.epi) CNRMA_DENSE_LAUNCH(1, 1); else CNRMA_DENSE_LAUNCH(1, 0); }
 #undef CNRMA_DENSE_LAUNCH
+#else                                   // the product schedule: one view in flight per wave, direct stores, free-running grid
+  (void)lock;
+  hipLaunchKernelGGL((backproject_accum_pipe_kernel<LPV, 1, 0, 0>), grid, dim3(256), 0, st, p, feat, proj, volume, count, (int)cb, gx,
+                     ord, bar, feat_ref);
+#endif
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -707,6 +493,7 @@ int launch_accum(const DenseParams& p, const float* feat, const float* proj, flo
 
 }  // namespace
 
+#ifdef CNRMA_EXPERIMENTS
 extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
   // v = {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups, ldspad}; n < 18 keeps the remaining defaults;
   // n == 0 restores the product configuration.  Host-side global state: debug / A-B runs only.
@@ -717,6 +504,7 @@ extern "C" int cnrma_debug_dense_tuning(const int* v, int n) {
   g_tune = t;
   return 0;
 }
+#endif
 
 static int backproject_accum_any(const float* feat_nhwc, const float* const* feat_ref, const float* proj, int V, int C, int H,
                                  int W, int X, int Y, int Z, float voxel_size, float ox, float oy, float oz, float* volume,
@@ -725,7 +513,7 @@ static int backproject_accum_any(const float* feat_nhwc, const float* const* fea
   DenseParams p{V, C, H, W, X, Y, Z, voxel_size, ox, oy, oz};
   hipStream_t st = as_stream(stream);
   unsigned int* bar = (workspace != nullptr && workspace_bytes >= CNRMA_DENSE_WORKSPACE_BYTES) ? static_cast<unsigned int*>(workspace) : nullptr;
-  const int l = g_tune.lpv;
+  const int l = CNRMA_DENSE_TUNE.lpv;
   if (l == 16 && C % 64 == 0) return launch_accum_coop<16>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
   if (l == 4 && C % 16 == 0) return launch_accum_coop<4>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);
   if (C % 32 == 0) return launch_accum_coop<8>(p, feat_nhwc, proj, volume, count, bar, st, feat_ref);

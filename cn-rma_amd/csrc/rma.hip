@@ -691,6 +691,7 @@ extern "C" int cnrma_rma_neus_count_f32(const float* proj_inv, const float* tsdf
   return 0;
 }
 
+#ifdef CNRMA_EXPERIMENTS       // libcnrma_hip_exp.so only (tests/test_rma_gpu.py: the fast division against the compiler's IEEE expansion)
 // parity aid: q_fast[i] = div_by_vs(a[i]) next to q_ref[i] = a[i] / vs (the compiler's IEEE expansion)
 __global__ __launch_bounds__(256) void div_check_kernel(const float* __restrict__ a, int64_t n, float vs,
                                                         float* __restrict__ q_fast, float* __restrict__ q_ref) {
@@ -708,6 +709,7 @@ extern "C" int cnrma_debug_div_by_voxel_size_f32(const float* a, int64_t n, floa
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
 extern "C" int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* table, void* stream) {
   if (n <= 0 || tsdf == nullptr || table == nullptr) return CNRMA_EINVAL;

@@ -1311,252 +1311,6 @@ __global__ __launch_bounds__(256, 2) void sparse_conv_bf16x6_kernel(ConvArgs p, 
   }
 }
 
-// ================================================================================================================
-// Warp-specialised form of the f16x3 stage kernel (round 4).  The ablation of the kernel above (diagnostic ABL build:
-// profiles/r04_conv_ablation_S.log) shows its phases ADD UP instead of overlapping -- on the 277 k-row 64 -> 64 layer: loop
-// skeleton (barriers + index bookkeeping) 92 us, global loads 110, LDS stores 30-60, fragment reads + MFMAs 100 of 356 --
-// because every wave of a block walks through all of them between two block-wide barriers.  Here a block is 8 waves with
-// fixed roles: waves 4-7 PRODUCE stages (neighbour indices, gathers, weight tiles, fp32 -> 2 x fp16 split, LDS stores)
-// into a ring of NSLOT LDS slots, waves 0-3 CONSUME them (fragment reads + MFMAs) and never execute a load, a conversion
-// or a store; the two sides meet only through per-slot counters in LDS (full / empty, monotonic), no s_barrier after
-// the prologue.  Same stage order, same products, same sums as the stage kernel: results are bit-identical.
-// ================================================================================================================
-__device__ __forceinline__ bool ws_wait(const int* cnt, int target) {
-  // bounded spin (a lost signal must never hang the GPU): ~0.5 s, then the caller flags the launch as failed
-  for (int spin = 0; spin < (1 << 24); ++spin) {
-    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return false;
-}
-
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int NSLOT, int NWP = 4>
-__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NWP), (WAVES_M * WAVES_N > 4 ? 3 : (TM * TN >= 4 ? 2 : 4)))
-void sparse_conv_ws_kernel(ConvArgs p, const __bf16* __restrict__ wt) {
-  constexpr int NWC = WAVES_M * WAVES_N, PT = 64 * NWP, NTHREADS = 64 * (NWC + NWP);      // consumer waves, producer threads
-  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N, NP = 2;
-  constexpr int A_ITERS = (BM << 3) / PT;
-  constexpr int B_CHUNKS = NP * BN * (BK / 8);
-  constexpr int B_ITERS = (B_CHUNKS + PT - 1) / PT;
-  constexpr int A_ELEMS = NP * BM * LDK, B_ELEMS = NP * BN * LDK, SLOT_ELEMS = A_ELEMS + B_ELEMS;
-  static_assert((BM << 3) % PT == 0 && A_ITERS >= 1 && B_ITERS >= 1, "tile shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
-  __bf16* ring = reinterpret_cast<__bf16*>(ws_lds);                       // [NSLOT][A planes | B planes]
-  int* ctl = reinterpret_cast<int*>(ws_lds + (size_t)NSLOT * SLOT_ELEMS * sizeof(__bf16));
-  int* full_cnt = ctl;                   // [NSLOT] producer waves that finished writing the slot (monotonic)
-  int* empty_cnt = ctl + NSLOT;          // [NSLOT] consumer waves that finished reading it
-  unsigned* mask_s = reinterpret_cast<unsigned*>(ctl + 2 * NSLOT);
-  int* done_cnt = ctl + 2 * NSLOT + 1;
-  float* amax_s = reinterpret_cast<float*>(ctl + 2 * NSLOT + 2);         // [NWC]
-
-  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
-  const int64_t tile0 = (int64_t)blockIdx.x * BM;
-  if (tile0 >= n_live) return;
-  const int cout0 = blockIdx.y * BN;
-  const int zs = blockIdx.z;
-  const int Cin = p.Cin, Cout = p.Cout, K = p.K;
-  const int Cout_p = conv_cout_padded(Cout);
-  const int64_t plane_elems = (int64_t)(p.slices > 1 ? p.slices : 1) * (p.tile_tap ? p.w_taps : K) * Cin * Cout_p;
-  const __bf16* Wz = wt + (p.slices > 1 ? (int64_t)zs * K * Cin * Cout_p : 0) +
-                     (p.tile_tap ? (int64_t)p.tile_tap[tile0 >> 7] * Cin * Cout_p : 0);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const bool producer = wid >= NWC;
-
-  int k_lo = 0, k_hi = K;
-  if (p.splits > 1) { k_lo = zs * p.k_per_split; k_hi = min(K, k_lo + p.k_per_split); }
-  const int rows_here = (int)min((int64_t)BM, n_live - tile0);
-  if (tid < 2 * NSLOT + 2) ctl[tid] = 0;
-  __syncthreads();
-  if (p.nbr == nullptr) {
-    if (tid == 0) *mask_s = 1u;
-  } else {
-    unsigned local = 0;
-    const int32_t* nb = p.nbr + tile0 * K;
-    const int kr = k_hi - k_lo;
-    for (int i = tid; i < rows_here * kr; i += NTHREADS) {
-      const int row = i / kr, k = k_lo + (i - row * kr);
-      if (nb[row * K + k] >= 0) local |= 1u << k;
-    }
-    if (local) atomicOr(mask_s, local);
-  }
-  __syncthreads();                          // the last block-wide barrier
-  const unsigned mask = *mask_s;
-  auto next_active = [&](int k) { const unsigned rest = mask & ~((2u << k) - 1u); return rest ? __ffs(rest) - 1 : -1; };
-
-  if (producer) {
-    // ---------------------------------------------------------------------------------------------- producers (waves 4-7)
-    const int ptid = tid - 64 * NWC;
-    const float a_scale = f16_scale_for(read_amax(p.in_amax));
-    int32_t src_cur[A_ITERS], src_nxt[A_ITERS];
-    auto load_src = [&](int k, int32_t* dst) {
-#pragma unroll
-      for (int i = 0; i < A_ITERS; ++i) {
-        const int row = (ptid + i * PT) >> 3;
-        int32_t v = -1;
-        if (row < rows_here && k >= 0) v = p.nbr ? p.nbr[(tile0 + row) * K + k] : (int32_t)(tile0 + row);
-        dst[i] = v;
-      }
-    };
-    typedef AStageRegs<false, A_ITERS, PT> ARegs;
-    ARegs areg;
-    u32x4_t rb[B_ITERS];
-    auto load_stage = [&](int k, int cin0, const int32_t* srcs) {
-      areg.load(p.in, nullptr, 0, ptid, srcs, cin0, 0, Cin);
-      const __bf16* Wk = Wz + ((int64_t)k * (Cin / BK) + cin0 / BK) * Cout_p * BK;
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) {
-        int idx = ptid + i * PT;
-        idx = idx < B_CHUNKS ? idx : 0;
-        const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
-        rb[i] = *reinterpret_cast<const u32x4_t*>(Wk + pl * plane_elems + (int64_t)(cout0 + row) * BK + chunk * 8);
-      }
-    };
-    int k = mask ? __ffs(mask) - 1 : -1;
-    int cin0 = 0;
-    load_src(k, src_cur);
-    load_src(k >= 0 ? next_active(k) : -1, src_nxt);
-    if (k >= 0) load_stage(k, 0, src_cur);
-    for (int s = 0; k >= 0; ++s) {
-      const int slot = s % NSLOT, round = s / NSLOT;
-      __bf16* A = ring + (size_t)slot * SLOT_ELEMS;
-      __bf16* B = A + A_ELEMS;
-      if (round > 0 && !ws_wait(&empty_cnt[slot], NWC * round)) { if (lane == 0) *done_cnt = -1000; return; }
-      areg.template store<1>(ptid, A, A + BM * LDK, A + BM * LDK, a_scale);
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i) {
-        const int idx = ptid + i * PT;
-        if (idx < B_CHUNKS) {
-          const int chunk = idx & 3, row = (idx >> 2) % BN, pl = idx / (4 * BN);
-          *reinterpret_cast<u32x4_t*>(&B[pl * BN * LDK + lds_slot(row, chunk)]) = rb[i];
-        }
-      }
-      // LDS executes one wave's operations in order: the counter update below lands behind the stores above
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      if (lane == 0) __hip_atomic_fetch_add(&full_cnt[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      cin0 += BK;
-      if (cin0 >= Cin) {
-        cin0 = 0;
-        k = next_active(k);
-#pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) src_cur[i] = src_nxt[i];
-        if (k >= 0) load_src(next_active(k), src_nxt);
-      }
-      if (k >= 0) load_stage(k, cin0, src_cur);
-    }
-    return;
-  }
-
-  // ------------------------------------------------------------------------------------------------ consumers (waves 0-3)
-  const int wr = wid / WAVES_N, wc = wid % WAVES_N;
-  const float out_scale = 1.0f / (f16_scale_for(read_amax(p.in_amax)) * f16_scale_for(*p.w_amax));
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-  const int n_stages = __popc(mask) * (Cin / BK);
-  const int a_row = wr * (32 * TM) + (lane & 31), b_row = wc * (32 * TN) + (lane & 31), fhalf = lane >> 5;
-  bool ok = true;
-  for (int s = 0; s < n_stages; ++s) {
-    const int slot = s % NSLOT, round = s / NSLOT;
-    const __bf16* A = ring + (size_t)slot * SLOT_ELEMS;
-    const __bf16* B = A + A_ELEMS;
-    if (!ws_wait(&full_cnt[slot], NWP * (round + 1))) { ok = false; break; }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-#pragma unroll
-    for (int ks = 0; ks < BK; ks += 16) {
-      f16x8_t af[TM][2], bf[TN][2];
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) af[a][pl] = *reinterpret_cast<const f16x8_t*>(&A[pl * BM * LDK + lds_slot(a_row + a * 32, (ks >> 3) + fhalf)]);
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) bf[b][pl] = *reinterpret_cast<const f16x8_t*>(&B[pl * BN * LDK + lds_slot(b_row + b * 32, (ks >> 3) + fhalf)]);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x16 c = acc[a][b];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][1], bf[b][0], c, 0, 0, 0);    // m*h
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][1], c, 0, 0, 0);    // h*m
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a][0], bf[b][0], c, 0, 0, 0);    // h*h
-          acc[a][b] = c;
-        }
-    }
-    // the fragment reads have returned (the MFMAs above consumed them): the slot may be overwritten
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    if (lane == 0) __hip_atomic_fetch_add(&empty_cnt[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  if (!ok) return;
-
-  const bool partial = p.splits > 1;
-  float* dst = partial ? p.slab + (int64_t)zs * p.no_cap * Cout : p.out;
-  const int child = p.slices > 1 ? morton_child(zs) : 0, row_step = p.slices > 1 ? p.slices : 1;   // see slice_out_row()
-  const bool use_scale = !partial && p.scale != nullptr, use_shift = !partial && p.shift != nullptr;
-  const int act = partial ? 0 : p.act;
-  float mx = 0.0f;
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
-    const bool col_ok = col < Cout;
-    const int colc = col_ok ? col : 0;
-    const float sc = use_scale ? p.scale[colc] : 1.0f;
-    const float sh = use_shift ? p.shift[colc] : 0.0f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float res[4];
-        if constexpr (HAS_RES) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int64_t row = row0 + q + 8 * rg;
-            const int64_t rc = row < n_live ? row : n_live - 1;
-            res[q] = p.residual[(rc * row_step + child) * Cout + colc];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int64_t row = row0 + q + 8 * rg;
-          float v = acc[a][b][rg * 4 + q];
-          v = v * out_scale;
-          v = v * sc;
-          v = v + sh;
-          if constexpr (HAS_RES) v = v + res[q];
-          v = apply_act(v, act);
-          if (col_ok && row < n_live) {
-            dst[(row * row_step + child) * Cout + col] = v;
-            mx = fmaxf(mx, fabsf(v));
-          }
-        }
-      }
-    }
-  }
-  if (!partial && p.out_amax != nullptr) {
-    // block maximum without a block barrier (the producer waves are gone): the consumer wave that arrives last publishes
-    mx = wave_max(mx);
-    if (lane == 0) amax_s[wid] = mx;
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    int arrived = 0;
-    if (lane == 0) arrived = __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    arrived = __shfl(arrived, 0, 64);
-    if (arrived == NWC - 1 && lane == 0) {
-      float m = amax_s[0];
-      for (int i = 1; i < NWC; ++i) m = fmaxf(m, amax_s[i]);
-      const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (AMAX_SLOTS - 1);
-      unsigned* d = reinterpret_cast<unsigned*>(p.out_amax + slot * AMAX_STRIDE);
-      const unsigned bits = __float_as_uint(m);
-      if (bits > __hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(d, bits);
-    }
-  }
-}
-
 // reduce the split-K slabs in a fixed order and apply the fused epilogue
 __global__ __launch_bounds__(256) void conv_reduce_kernel(ConvArgs p) {
   const int64_t n_live = live_rows(p.no_cap, p.no_dev);
@@ -1643,52 +1397,27 @@ int choose_splits(int64_t rows, int Cout, int K, int bm, int bn, size_t ws_bytes
   return s < 2 ? 1 : s;
 }
 
-template <int WM, int WN, int TM_, int TN_, int NSLOT>
-int launch_ws_one(bool has_res, dim3 grid, const ConvArgs& p, const __bf16* wt, hipStream_t st) {
-  constexpr int BM = 32 * TM_ * WM, BN = 32 * TN_ * WN, NWC = WM * WN, NWP = 4;
-  const size_t lds = (size_t)NSLOT * (BM + BN) * LDK * 2 * sizeof(uint16_t) + (2 * NSLOT + 2 + NWC) * sizeof(int);
-  if (lds > 160 * 1024) return CNRMA_EINVAL;
-  auto go = [&](auto kernel) -> int {
-    if (lds > 48 * 1024) {
-      static bool raised = false;           // per instantiation (the lambda is instantiated per kernel type)
-      if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        raised = true;
-      }
-    }
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * (NWC + NWP)), lds, st, p, wt);
-    return 0;
-  };
-  return has_res ? go(sparse_conv_ws_kernel<WM, WN, TM_, TN_, true, NSLOT>) : go(sparse_conv_ws_kernel<WM, WN, TM_, TN_, false, NSLOT>);
-}
-
-template <int NSLOT>
-int launch_ws_shape(int shape, bool has_res, dim3 grid, const ConvArgs& p, const __bf16* wt, hipStream_t st) {
-  switch (shape) {
-    case 0: return launch_ws_one<2, 2, 2, 2, NSLOT>(has_res, grid, p, wt, st);      // 128x128
-    case 1: return launch_ws_one<4, 1, 1, 2, NSLOT>(has_res, grid, p, wt, st);      // 128x64
-    case 2: return launch_ws_one<2, 2, 1, 1, NSLOT>(has_res, grid, p, wt, st);      // 64x64
-    case 4: return launch_ws_one<2, 2, 1, 2, NSLOT>(has_res, grid, p, wt, st);      // 64x128
-    case 5: return launch_ws_one<4, 2, 2, 2, NSLOT>(has_res, grid, p, wt, st);      // 256x128: 8 consumer waves of 64x64
-    case 6: return launch_ws_one<4, 2, 2, 1, NSLOT>(has_res, grid, p, wt, st);      // 256x64:  8 consumer waves of 64x32
-    default: return CNRMA_EINVAL;
-  }
-}
-
-int launch_conv_ws(int shape, int slots, bool has_res, dim3 grid, const ConvArgs& p, const __bf16* wt, hipStream_t st) {
-  if (slots >= 4 && shape != 0 && shape < 5) return launch_ws_shape<4>(shape, has_res, grid, p, wt, st);
-  if (slots >= 3 && (shape < 5 || shape == 6)) return launch_ws_shape<3>(shape, has_res, grid, p, wt, st);
-  return launch_ws_shape<2>(shape, has_res, grid, p, wt, st);
-}
+#ifdef CNRMA_EXPERIMENTS
+#include "sparse_exp_ws.inc"
+#endif
 
 constexpr int CONV_XCD_ORDER = 0;      // product default of the XCD-aware tile order of the stage kernel -- until measured
+#ifdef CNRMA_EXPERIMENTS
 constexpr int CONV_WS_SLOTS = 0;       // product default of the warp-specialised kernel's ring (0: stage kernel) -- until measured
+#endif
 
 // Debug / A-B switches of the convolution launcher (cnrma_debug_conv_tuning: scripts/conv_sweep.py and the tests that force a
 // variant).  Product code never changes them; -1 = the launcher's own choice.
 struct ConvTune { int shape = -1; int splits = -1; int pf = -1; int ablate = 0; int ws = -1; int xcd = -1; int go = -1; int nb = -1; };   // ws: LDS ring slots of the warp-specialised kernel (0 = stage kernel)
-static ConvTune g_conv_tune;
+#ifdef CNRMA_EXPERIMENTS
+static ConvTune g_conv_tune;                 // libcnrma_hip_exp.so only: written by cnrma_debug_conv_tuning
+#define CNRMA_CONV_TUNE g_conv_tune
+#else
+// the product library has no tuning state at all: every launcher decision is a pure function of its arguments (no
+// global mutable state), the experimental kernels and cnrma_debug_conv_tuning are not compiled in
+static constexpr ConvTune k_conv_tune{};
+#define CNRMA_CONV_TUNE k_conv_tune
+#endif
 
 enum ConvShape { T128x128, T128x64, T64x64, T128x32, T64x128, T256x128, T256x64, N_CONV_SHAPES };   // the last two: warp-specialised kernel only
 struct ConvPlan { int shape, bm, bn, splits, k_per_split, pf; };
@@ -1711,7 +1440,7 @@ ConvPlan plan_conv(int64_t no_cap, int Cin, int Cout, int K, int mode, bool six,
   else if (Cout >= 128) sh = T128x128;
   else if (six && Cin <= 32) sh = T64x64;
   else sh = T128x64;
-  const ConvTune t = g_conv_tune;
+  const ConvTune t = CNRMA_CONV_TUNE;
   if (t.shape >= 0 && t.shape < N_CONV_SHAPES && (six || t.shape < T64x128) && (t.shape < T256x128 || (six && mode == 1 && t.ws >= 2)))
     sh = t.shape;
   ConvPlan pl{sh, bms[sh], bns[sh], 1, K, 1};
@@ -1756,12 +1485,12 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   const bool six = weight_split != nullptr && Cin % 32 == 0;
   const ConvPlan pl = plan_conv(no_cap, Cin, Cout, K, mode, six, slices, workspace != nullptr, ws_bytes);
   const int shape = pl.shape, bm = pl.bm, bn = pl.bn;
-  p.ablate = g_conv_tune.ablate;
+  p.ablate = CNRMA_CONV_TUNE.ablate;
   p.splits = pl.splits;
   p.k_per_split = pl.k_per_split;
   dim3 grid((unsigned)ceil_div(no_cap, bm), (unsigned)ceil_div(Cout, bn), (unsigned)(slices > 1 ? slices : p.splits));
   // XCD-aware tile order (stage kernel on prepared weights; the pair-list runs keep their tile_tap order)
-  const int xcd = g_conv_tune.xcd >= 0 ? g_conv_tune.xcd : CONV_XCD_ORDER;
+  const int xcd = CNRMA_CONV_TUNE.xcd >= 0 ? CNRMA_CONV_TUNE.xcd : CONV_XCD_ORDER;
   if (xcd && weight_split != nullptr && Cin % 32 == 0 && tile_tap == nullptr && grid.x >= 64) {
     p.xcd_tiles = (int)grid.x;
     grid.x = (grid.x + 7u) / 8u * 8u;
@@ -1770,14 +1499,20 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
   const bool has_res = residual != nullptr && p.splits == 1;   // split layers add the residual in the reduce kernel
   if (weight_split != nullptr && Cin % 32 == 0) {
     const __bf16* wt = reinterpret_cast<const __bf16*>(weight_split);
+#ifdef CNRMA_EXPERIMENTS            // the diagnostic (ablation) instantiation of the stage kernel
+#define CNRMA_CONV6_ABL(WM, WN, TM_, TN_)                                                                          \
+    else if (mode == 1 && !has_res && CNRMA_CONV_TUNE.ablate != 0)                                                 \
+      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 1, 1, true>), grid, dim3(256), 0, st, p, wt);
+#else
+#define CNRMA_CONV6_ABL(WM, WN, TM_, TN_)
+#endif
 #define CNRMA_CONV6_LAUNCH(WM, WN, TM_, TN_)                                                                       \
   do {                                                                                                             \
     if (mode == 2 && has_res)                                                                                      \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 2>), grid, dim3(256), 0, st, p, wt);  \
     else if (mode == 2)                                                                                            \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 2>), grid, dim3(256), 0, st, p, wt); \
-    else if (mode == 1 && !has_res && g_conv_tune.ablate != 0)                                                     \
-      hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 1, 1, true>), grid, dim3(256), 0, st, p, wt); \
+    CNRMA_CONV6_ABL(WM, WN, TM_, TN_)                                                                              \
     else if (mode == 1 && has_res && pl.pf == 2)                                                                   \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, true, false, 1, (TM_ * TN_ <= 2 ? 2 : 1)>), grid, dim3(256), 0, st, p, wt);  \
     else if (mode == 1 && pl.pf == 2)                                                                              \
@@ -1795,12 +1530,14 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
     else                                                                                                           \
       hipLaunchKernelGGL((sparse_conv_bf16x6_kernel<WM, WN, TM_, TN_, false, false, 0>), grid, dim3(256), 0, st, p, wt); \
   } while (0)
-    const int ws_slots = mode == 1 && in_split == nullptr && shape != T128x32 ? (g_conv_tune.ws >= 0 ? g_conv_tune.ws : CONV_WS_SLOTS) : 0;
-    if (ws_slots >= 2 && g_conv_tune.ablate == 0) {
+#ifdef CNRMA_EXPERIMENTS
+    const int ws_slots = mode == 1 && in_split == nullptr && shape != T128x32 ? (CNRMA_CONV_TUNE.ws >= 0 ? CNRMA_CONV_TUNE.ws : CONV_WS_SLOTS) : 0;
+    if (ws_slots >= 2 && CNRMA_CONV_TUNE.ablate == 0) {
       // warp-specialised kernel: 8 waves, dynamic LDS = ring + counters (above 64 KB the limit is raised per kernel)
       const int rc = launch_conv_ws(shape, ws_slots, has_res, grid, p, wt, st);
       if (rc != 0) return rc;
     } else
+#endif
     switch (shape) {
       case T128x128: CNRMA_CONV6_LAUNCH(2, 2, 2, 2); break;
       case T128x64: CNRMA_CONV6_LAUNCH(4, 1, 1, 2); break;
@@ -1810,6 +1547,7 @@ int launch_conv(const float* in, int Cin, const int32_t* nbr, int K, const float
       default: return CNRMA_EINVAL;
     }
 #undef CNRMA_CONV6_LAUNCH
+#undef CNRMA_CONV6_ABL
     if (p.splits > 1) {
       int64_t blocks = ceil_div(no_cap * Cout / 4 + 1, 256);
       if (blocks > 4096) blocks = 4096;
@@ -2078,326 +1816,9 @@ __global__ __launch_bounds__(256) void prep_weights_f16_frag_kernel(const float*
   }
 }
 
-// Weight fragments of the gather-once kernel are fetched with explicit instructions and explicit waits: hipcc's own
-// s_waitcnt placement put vmcnt(0) in front of every offset's MFMAs (it cannot count loads issued around a loop back-edge), so
-// every offset waited for the fragment fetched one step before it -- an L2 round trip per step.  The asm loads are invisible
-// to that pass; go_wait4() names the registers it releases, which keeps their uses behind it.  Older outstanding loads never
-// invalidate a compiler-placed vmcnt(n) (returns are in order), and inside the offset loop there are no other vector loads.
-template <int OFF>
-__device__ __forceinline__ void go_load16(u32x4_t& d, const uint16_t* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF));       // no "memory": see above
-}
-__device__ __forceinline__ void go_wait0(u32x4_t (&a)[1][2][2], u32x4_t (&b)[1][2][2]) {      // every load has landed
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0][0][0]), "+v"(a[0][0][1]), "+v"(a[0][1][0]), "+v"(a[0][1][1]),
-               "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]));
-}
-__device__ __forceinline__ void go_wait4(u32x4_t (&b)[1][2][2]) {          // everything but the 4 newest loads has landed
-  asm volatile("s_waitcnt vmcnt(4)" : "+v"(b[0][0][0]), "+v"(b[0][0][1]), "+v"(b[0][1][0]), "+v"(b[0][1][1]));
-}
-
-// KS = 2 (the 64-column tile): the four waves are 2 column halves x 2 OFFSET halves -- a wave owns all 64 rows x 32 columns for
-// every second offset of the group, so that a weight fragment is fetched by exactly one wave of the block and feeds two row
-// tiles (with 2 x 2 waves over rows x columns every fragment was fetched twice per block and fed one: the vector-memory
-// path, 64 B/clk/CU, carried 16 KB per 192 MFMA cycles); the two partial sums meet in LDS before the epilogue.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool HAS_RES, int KS = 1, bool ABL = false>
-__global__ __launch_bounds__(256, 4) void sparse_conv_go_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag) {
-  // ABL: the diagnostic instantiation (cnrma_debug_conv_tuning ablation mask != 0); the product kernel has none of its branches
-  // (a branch around a load makes hipcc wait for every load on its own)
-  const int abl = ABL ? p.ablate : 0;
-  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-  static_assert(BM == GO_BM && WAVES_M * WAVES_N * KS == 4, "tile shape");
-  static_assert(KS == 1 || (KS == 2 && TM == 2 && TN == 1 && WAVES_M == 1), "offset halves: one wave = 64 rows x 32 columns");
-  __shared__ __attribute__((aligned(16))) __bf16 Us[2][(GO_UMAX + 2) * LDK];      // fp16 bit patterns; row GO_UMAX = zeros, GO_UMAX + 1 = dump
-  __shared__ uint16_t Ls[GO_BM * 27];
-  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
-  const int64_t tile = blockIdx.x, tile0 = tile * BM;
-  if (tile0 >= n_live) return;
-  const int cout0 = blockIdx.y * BN, zs = blockIdx.z;
-  const int Cin = p.Cin, Cout = p.Cout;
-  const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int kg = wid / (WAVES_M * WAVES_N), w2 = wid % (WAVES_M * WAVES_N);
-  const int wr = w2 / WAVES_N, wc = w2 % WAVES_N;
-  const float a_scale = f16_scale_for(read_amax(p.in_amax));
-  const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
-  const int32_t* th = g.hdr + tile * GO_HDR;
-  const int32_t* tr = g.rows + tile * GO_ROWS;
-  for (int i = tid; i < GO_BM * 27; i += 256) Ls[i] = (abl & 32) ? (uint16_t)(i & 127) : g.lidx[tile * (GO_BM * 27) + i];
-  if (tid < 16) {                                            // the zero row of both planes (64 bytes each)
-    reinterpret_cast<uint32_t*>(&Us[0][GO_UMAX * LDK])[tid] = 0u;
-    reinterpret_cast<uint32_t*>(&Us[1][GO_UMAX * LDK])[tid] = 0u;
-  }
-  const int n_groups = th[0];
-  int s_lo = 0, s_hi = ns;
-  if (p.splits > 1) { s_lo = zs * g.slices_per_split; s_hi = min(ns, s_lo + g.slices_per_split); }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-
-  const int a_row0 = wr * (32 * TM) + (lane & 31), fhalf = lane >> 5;
-  // B fragments of one (offset, slice): [TN][plane][k-step] x 16 bytes per lane, straight from the fragment-order image
-  static_assert(TN == 1, "one 32-column fragment set per wave");
-  auto load_b = [&](u32x4_t (&bf)[TN][2][2], int k, int slice) {
-    const uint16_t* base = wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc * TN) * 2048 + lane * 8;
-    go_load16<0>(bf[0][0][0], base);                           // [plane][k-step]: 1024 bytes apart
-    go_load16<1024>(bf[0][0][1], base);
-    go_load16<2048>(bf[0][1][0], base);
-    go_load16<3072>(bf[0][1][1], base);
-  };
-  // A fragments come from LDS one at a time, each read issued BEFORE the MFMAs of the fragment in front of it (two 16-byte
-  // registers in rotation): the register budget of four waves per SIMD leaves no room for a k-step's four fragments at once,
-  // and with a single register hipcc had every MFMA group wait for its own LDS round trip (8 per offset: ~1000 cycles for 384
-  // cycles of MFMAs).  Order per k-step and row tile: the low plane (one product), then the high plane (two products).
-  auto mfma_k = [&](const u32x4_t (&bf)[TN][2][2], int k) {
-    int li[TM];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) li[a] = Ls[(a_row0 + a * 32) * 27 + k];
-    auto rd = [&](int a, int pl, int ks) -> f16x8_t {
-      return *reinterpret_cast<const f16x8_t*>(&Us[pl][lds_slot(li[a], ks * 2 + fhalf)]);
-    };
-    f16x8_t cur = rd(0, 1, 0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const f16x8_t bh = __builtin_bit_cast(f16x8_t, bf[0][0][ks]), bm = __builtin_bit_cast(f16x8_t, bf[0][1][ks]);
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        f16x8_t nxt = rd(a, 0, ks);                                              // this row tile's high plane
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh, acc[a][0], 0, 0, 0);       // m*h
-        cur = nxt;
-        const bool last = ks == 1 && a == TM - 1;
-        if (!last) nxt = a + 1 < TM ? rd(a + 1, 1, ks) : rd(0, 1, ks + 1);       // the next low plane
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bm, acc[a][0], 0, 0, 0);       // h*m
-        acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur, bh, acc[a][0], 0, 0, 0);       // h*h
-        cur = nxt;
-      }
-    }
-  };
-
-  for (int slice = s_lo; slice < s_hi; ++slice) {
-    const int cin0 = slice * BK;
-    for (int grp = 0; grp < n_groups; ++grp) {
-      const unsigned mask = (unsigned)th[1 + 3 * grp];
-      const int ub = th[2 + 3 * grp], un = th[3 + 3 * grp];
-      unsigned mymask = mask;
-      if constexpr (KS == 2) {                               // every second offset of the group
-        mymask = 0;
-        unsigned m = mask;
-        int r = 0;
-        while (m) {
-          const unsigned low = m & (0u - m);
-          if ((r & 1) == kg) mymask |= low;
-          m ^= low;
-          ++r;
-        }
-      }
-      // two offsets' weights in flight, in a pattern the compiler can count: EVERY step issues exactly one offset's four loads,
-      // unconditionally (behind the last offset the last one again), so the wait in front of an offset's MFMAs is "all but
-      // the four newest loads" -- with conditional prefetches hipcc emitted s_waitcnt vmcnt(0) there and every offset waited
-      // for the weights fetched one step before it (an L2 round trip per step: 0.75 us for 0.18 us of MFMAs)
-      u32x4_t b0[TN][2][2], b1[TN][2][2];
-      unsigned rest = mymask;
-      const int n_off = __popc(mymask);
-      int k_last = 0;
-      auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
-      int k0 = pop(), k1 = pop();
-      load_b(b0, k0, slice);
-      load_b(b1, k1, slice);
-      __syncthreads();                                       // the previous stage's fragment reads are done
-      // ---- the union rows of this group, once: 8 lanes per row (4 channels each), 4 rows per thread in flight (more in
-      // flight, or the row numbers of all batches up front, costs the third wave per SIMD: measured 20-35 % slower)
-      const int tasks = un * 8;
-      for (int t0 = 0; t0 < tasks; t0 += 256 * 4) {
-        float4 v[4];
-        int32_t src[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                          // the four row numbers first, then the four rows: two round trips
-          const int t = t0 + i * 256 + tid;                    // per batch instead of up to eight
-          src[i] = tr[ub + (t < tasks ? (t >> 3) : 0)];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int t = t0 + i * 256 + tid;
-          if (!(abl & 2)) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (t & 7) * 4);
-          else v[i] = make_float4(0.f, 0.f, 0.f, (float)src[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // EVERY loaded value is consumed here, on every path (tasks behind the union go to a dump row): a load whose use
-          // sits behind a branch stays "pending" for hipcc's wait placement, and the wait for it lands in the header of the
-          // offset loop below -- where it would drain the weight prefetches on every iteration
-          const int t = t0 + i * 256 + tid;
-          const int u = t < tasks ? (t >> 3) : GO_UMAX + 1, kc = t & 7;
-          uint2 h, m;
-          split2(v[i], a_scale, h, m);
-          const int o = lds_slot(u, kc >> 1) + (kc & 1) * 4;
-          if (!(abl & 8)) {
-            *reinterpret_cast<uint2*>(&Us[0][o]) = h;
-            *reinterpret_cast<uint2*>(&Us[1][o]) = m;
-          } else if (h.x == 0x12345678u) Us[0][0] = (__bf16)0.0f;
-        }
-      }
-      __syncthreads();
-      // ---- the group's offsets back to back: no barrier, no LDS store, no index load from memory
-      int i = 0;
-      for (; i + 2 < n_off; i += 2) {                          // steady state: two offsets per turn, their successors prefetched
-        go_wait4(b0);                                          // b0 has landed; b1's four loads may still fly
-        if (!(abl & 1)) mfma_k(b0, k0);
-        k0 = pop();
-        load_b(b0, k0, slice);
-        go_wait4(b1);                                          // b1 has landed; the four just issued may fly
-        if (!(abl & 1)) mfma_k(b1, k1);
-        k1 = pop();                                            // behind the last offset: the last one again (never used)
-        load_b(b1, k1, slice);
-      }
-      // the last one or two offsets: nothing more to prefetch, and NO load may be left in flight -- the asm loads are invisible
-      // to the compiler, which is free to reuse their destination registers from here on
-      go_wait0(b0, b1);
-      if (i < n_off && !(abl & 1)) mfma_k(b0, k0);
-      if (i + 1 < n_off && !(abl & 1)) mfma_k(b1, k1);
-    }
-  }
-
-  if constexpr (KS == 2) {
-    // the two offset halves meet: each wave hands the row tile it does not finish to its partner through LDS (the images
-    // are dead) and finishes the other -- wave (kg, wc) writes rows 32 * kg .. + 31 of columns 32 * wc .. + 31
-    __syncthreads();
-    float* X = reinterpret_cast<float*>(&Us[0][0]);          // 4 x 4 KB of the 20-KB plane
-    float* mine = X + (wc * 2 + kg) * 1024, *theirs = X + (wc * 2 + (kg ^ 1)) * 1024;
-    if (kg == 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[1][0][i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[0][0][i];
-    }
-    __syncthreads();
-    if (kg == 0) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][0][i] += theirs[i * 64 + lane];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[1][0][i] += theirs[i * 64 + lane];
-    }
-  }
-
-  // ---- epilogue (as the stage kernel).  Split over channel slices: every block leaves its partial tile in its slab; with a
-  // counter array (g.counters, zero between launches) the LAST block of a tile to arrive adds the slabs up in slab order --
-  // the sums conv_reduce_kernel forms, bit for bit -- and finishes the tile itself: no reduce launch behind the kernel.
-  // The partial tiles cross XCDs inside one kernel: they are written and read with device-scope accesses, and a release /
-  // acquire fence pair stands around the counter.
-  bool partial = p.splits > 1;
-  float oscale = out_scale;
-  if (partial) {
-    float* slab = p.slab + (int64_t)zs * p.no_cap * Cout;
-    const bool here = g.counters != nullptr;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        if (KS == 2 && a != kg) continue;
-        const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
-          if (col < Cout && row < n_live) {
-            const float v = acc[a][b][i] * out_scale;
-            slab[row * Cout + col] = v;
-          }
-        }
-      }
-    }
-    if (!here) return;                                       // conv_reduce_kernel follows
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-      unsigned* c = g.counters + (blockIdx.x * gridDim.y + blockIdx.y);
-      const unsigned old = atomicAdd(c, 1u);
-      s_last = old == (unsigned)p.splits - 1u;
-      if (s_last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const int64_t slab_stride = p.no_cap * Cout;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        if (KS == 2 && a != kg) continue;
-        const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
-          float sum = 0.0f;
-          if (col < Cout && row < n_live) {
-            const float* q = p.slab + row * Cout + col;
-            sum = __builtin_nontemporal_load(q);
-            for (int z = 1; z < p.splits; ++z) sum += __builtin_nontemporal_load(q + (int64_t)z * slab_stride);
-          }
-          acc[a][b][i] = sum;
-        }
-      }
-    }
-    partial = false;
-    oscale = 1.0f;
-  }
-  float* dst = p.out;
-  const bool use_scale = p.scale != nullptr, use_shift = p.shift != nullptr;
-  const int act = p.act;
-  const bool has_res_rt = !HAS_RES && p.residual != nullptr;  // a split launch is instantiated without the residual template
-  float mx = 0.0f;
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int col = cout0 + wc * (32 * TN) + b * 32 + (lane & 31);
-    const bool col_ok = col < Cout;
-    const int colc = col_ok ? col : 0;
-    const float sc = use_scale ? p.scale[colc] : 1.0f;
-    const float sh = use_shift ? p.shift[colc] : 0.0f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      if (KS == 2 && a != kg) continue;
-      const int64_t row0 = tile0 + wr * (32 * TM) + a * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float res[4];
-        if (HAS_RES || has_res_rt) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int64_t row = row0 + q + 8 * rg;
-            const int64_t rc = row < n_live ? row : n_live - 1;
-            res[q] = p.residual[rc * Cout + colc];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int64_t row = row0 + q + 8 * rg;
-          float v = acc[a][b][rg * 4 + q];
-          v = v * oscale;
-          v = v * sc;
-          v = v + sh;
-          if (HAS_RES || has_res_rt) v = v + res[q];
-          v = apply_act(v, act);
-          if (col_ok && row < n_live && !((abl & 16) && v != 12345.678f)) {
-            dst[row * Cout + col] = v;
-            mx = fmaxf(mx, fabsf(v));
-          }
-        }
-      }
-    }
-  }
-  if (p.out_amax != nullptr) {
-    __syncthreads();
-    block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(&Us[0][0]));
-  }
-}
+#ifdef CNRMA_EXPERIMENTS
+#include "sparse_exp_go1.inc"
+#endif
 
 // ================================================================================================================
 // Gather-once convolution, second form (round 5).  The first form's blocks were timed phase by phase with s_memtime stamps
@@ -3055,401 +2476,9 @@ __global__ __launch_bounds__(256, 4) void sparse_conv_gof_kernel(ConvArgs p, GoA
   }
 }
 
-// ================================================================================================================
-// Gather-once convolution, third form (round 5, sparse.conv_tuning(go=2)): persistent blocks, two union images, the next
-// stage's gather under the current stage's MFMAs.
-// The second form's blocks still spend more than half of their life outside the offset loops (stamps: header + first barrier,
-// two gathers, the barrier between the slices, merge + epilogue), and inside them a wave alone reaches ~46 % of the matrix
-// pipe's rate (every MFMA group waits for its own LDS round trip); four blocks per CU average that out to an MFMA-busy
-// fraction of 0.54-0.58 (profiles/r05_*_pmc_SQ.csv).  This form spends the LDS of a CU on TWO blocks with two images each, and
-// the registers that frees on deeper software pipelines:
-//   * a block is persistent: it walks its share of the (row tile, column / split group) items; a *stage* = one (item,
-//     32-channel slice, offset group).  While the offsets of stage s run from image s % 2, the union rows of stage s + 1 are
-//     fetched and split into image (s + 1) % 2 by the same waves: per offset step a thread issues one 16-byte row load (inline
-//     asm, like the weight loads) and finishes the load issued three steps earlier (split to two fp16 planes, two ds_write).
-//     The vector-memory issue pattern of a step is constant -- four weight loads, then one row load, dummies behind the last
-//     real one -- so the waits are counted: vmcnt(6) before a step's weights, vmcnt(15) before the row load three steps old;
-//   * the metadata of the next item (header, local indices, the row numbers of its first offset group) is requested behind the
-//     first barrier of an item's first stage and parked in LDS behind that stage's offsets, so that the item's LAST stage can
-//     already gather the next item's first image; items with one stage only (single-slice splits) and offset groups other
-//     than the first fall back to a gather in front of their stage, as in the second form;
-//   * the A fragments of a whole offset are read one offset ahead (two register sets): the MFMAs of an offset never wait for LDS.
-// Same sums in the same order as the other two forms (bit-identical: the test).
-// ================================================================================================================
-struct Go3Map { int tiles, ncol, ng, n_items, per_xcd, bpx, flags; };   // flags (A/B aid): bit 0 = never gather ahead   // item = tile * ng + group; XCD x owns items [x per_xcd, (x + 1) per_xcd)
-constexpr int GO3_RS = 288;                                       // row numbers parked per tile (>= GO_UMAX, two 256-thread loads)
-constexpr int GO3_IMG = 2 * GO2_US * 2;                           // bytes of one image (two planes)
-constexpr int GO3_LDS = 2 * GO3_IMG + 2 * (GO_BM * 27 * 2) + 2 * (GO3_RS * 4);
-static_assert(2 * GO3_LDS <= 160 * 1024 && GO_UMAX <= GO3_RS, "two blocks per CU");
-
-// one 16-byte row load: SGPR base (the feature tensor) + 32-bit byte offset per lane
-__device__ __forceinline__ void go_load_row(f32x4_t& d, const float* sbase, unsigned voff) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase));
-}
-
-template <int WAVES_N, int KS, bool HAS_RES, bool STAMP = false>
-__global__ __launch_bounds__(256, 2) void sparse_conv_go3_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag, Go3Map mp) {
-  static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
-  constexpr int TM = 2, BN = 32 * WAVES_N, NB = 2, RD = 4;   // weight sets in flight; row-load ring (a load is finished 3 steps later)
-  // STAMP: diagnostic instantiation (conv_tuning(go=2, ablate=64)): s_memtime stamps of the block's FIRST item, 16 words per block
-  unsigned long long* const dbg = STAMP ? reinterpret_cast<unsigned long long*>(g.counters) : nullptr;
-  int n_stamp = 0;
-  bool stamp_on = STAMP;
-  if (STAMP && dbg) go_stamp(dbg, n_stamp++);                // 0: block start
-  extern __shared__ __attribute__((aligned(16))) unsigned char go3_smem[];
-  auto Us = [&](int b) { return reinterpret_cast<__bf16*>(go3_smem + (size_t)b * GO3_IMG); };
-  auto Ls = [&](int b) { return reinterpret_cast<uint16_t*>(go3_smem + 2 * GO3_IMG + (size_t)b * (GO_BM * 27 * 2)); };
-  auto Rs = [&](int b) { return reinterpret_cast<int32_t*>(go3_smem + 2 * GO3_IMG + 2 * (GO_BM * 27 * 2) + (size_t)b * (GO3_RS * 4)); };
-  const int64_t n_live = live_rows(p.no_cap, p.no_dev);
-  const int Cin = p.Cin, Cout = p.Cout;
-  const int Cout_p = conv_cout_padded(Cout), nt = Cout_p / 32, ns = Cin / BK;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wid / WAVES_N, wc = wid % WAVES_N;
-  const int fhalf = lane >> 5;
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const float a_scale = f16_scale_for(read_amax(p.in_amax));
-  const float out_scale = 1.0f / (a_scale * f16_scale_for(*p.w_amax));
-  // ---- this block's items
-  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-  const int it_end = min(mp.n_items, (xcd + 1) * mp.per_xcd);
-  int it = xcd * mp.per_xcd + jb;
-  auto live_item = [&](int i) { return i < it_end && (int64_t)(i / mp.ng) * GO_BM < n_live; };
-  if (!live_item(it)) return;                                // items are in tile order: behind a dead tile nothing is alive
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-    if (tid < 16) {                                          // the zero row of both planes of both images
-      reinterpret_cast<uint32_t*>(Us(b) + GO_UMAX * LDK)[tid] = 0u;
-      reinterpret_cast<uint32_t*>(Us(b) + GO2_US + GO_UMAX * LDK)[tid] = 0u;
-    }
-  // ---- metadata of the first item, waited for (every later item's arrives under the stages of the item before it)
-  int buf = 0;                                               // Ls / Rs buffer of the current item
-  int4 h0;
-  {
-    const int64_t tile = it / mp.ng;
-    h0 = *reinterpret_cast<const int4*>(g.hdr + tile * GO_HDR);
-    if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls(0))[tid] = reinterpret_cast<const uint4*>(g.lidx + tile * (GO_BM * 27))[tid];
-    const int32_t* tr = g.rows + tile * GO_ROWS;
-    Rs(0)[tid] = tr[tid];
-    if (tid < GO3_RS - 256) Rs(0)[256 + tid] = tr[256 + tid];
-  }
-  int img = 0;                                               // image of the next stage to run
-  bool have_img = false;                                     // ... already gathered by the stage before it
-  float mx = 0.0f;
-
-  auto load_b = [&](u32x4_t (&bf)[2][2], int k, int slice, int cout0) {
-    const uint64_t ba = reinterpret_cast<uint64_t>(wfrag + (((int64_t)k * ns + slice) * nt + (cout0 >> 5) + wc) * 2048);
-    const uint16_t* base = reinterpret_cast<const uint16_t*>(
-        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ba >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ba));
-    go_load_frag(bf, base, lane16);
-  };
-  // a gather that is waited for: union rows [q0 * 256 / 8 ..) of `un` (row numbers from `rows`, LDS or memory) into image `dst`
-  auto gather_now = [&](__bf16* dst, const int32_t* rows, int un, int cin0, int q0) {
-    const int tasks = un * 8;
-    for (int t0 = q0 * 256; t0 < tasks; t0 += 256 * 4) {
-      float4 v[4];
-      int32_t src[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int tk = t0 + i * 256 + tid;
-        src[i] = rows[tk < tasks ? (tk >> 3) : 0];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(p.in + (int64_t)src[i] * Cin + cin0 + (tid & 7) * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int tk = t0 + i * 256 + tid;
-        const int u = tk < tasks ? (tk >> 3) : GO_UMAX + 1, kc = tid & 7;
-        uint2 h, m;
-        split2(v[i], a_scale, h, m);
-        __bf16* d = dst + lds_slot(u, kc >> 1) + (kc & 1) * 4;
-        *reinterpret_cast<uint2*>(d) = h;
-        *reinterpret_cast<uint2*>(d + GO2_US) = m;
-      }
-    }
-  };
-
-  for (;;) {                                                 // ---- items
-    const int64_t tile = it / mp.ng, tile0 = tile * GO_BM;
-    const int grp = it % mp.ng;
-    const int cout0 = (grp % mp.ncol) * BN, zs = grp / mp.ncol;
-    const int32_t* th = g.hdr + tile * GO_HDR;
-    const int32_t* tr = g.rows + tile * GO_ROWS;
-    const int n_groups = __builtin_amdgcn_readfirstlane(h0.x);
-    int s_lo = 0, s_hi = ns;
-    if (p.splits > 1) { s_lo = zs * g.slices_per_split; s_hi = min(ns, s_lo + g.slices_per_split); }
-    const int n_stages = (s_hi - s_lo) * n_groups;
-    const int col = cout0 + wc * 32 + (lane & 31);
-    const bool col_ok = col < Cout;
-    const int colc = col_ok ? col : 0;
-    const bool use_scale = p.scale != nullptr && p.splits == 1, use_shift = p.shift != nullptr && p.splits == 1;
-    const float sc = use_scale ? p.scale[colc] : 1.0f;
-    const float sh = use_shift ? p.shift[colc] : 0.0f;
-    const uint16_t* ls0 = Ls(buf) + (lane & 31) * 27;
-    // the next item; its metadata is requested in this item's first stage and parked in the other Ls / Rs buffer behind it
-    const int it2 = it + mp.bpx;
-    const bool more = live_item(it2);
-    const int64_t tile2 = more ? it2 / mp.ng : tile;
-    int s_lo2 = 0;
-    if (p.splits > 1) s_lo2 = ((it2 % mp.ng) / mp.ncol) * g.slices_per_split;
-    int4 h0n = h0;
-    uint4 lvn = make_uint4(0u, 0u, 0u, 0u);
-    int32_t rn0 = 0, rn1 = 0;
-    bool meta_parked = !more;
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
-
-    int stage = 0;
-    int n_off_dbg = 0;
-    for (int slice = s_lo; slice < s_hi; ++slice) {
-      const int cin0 = slice * BK;
-      for (int grpi = 0; grpi < n_groups; ++grpi, ++stage) {
-        const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane(grpi == 0 ? h0.y : th[1 + 3 * grpi]);
-        const int ub = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.z : th[2 + 3 * grpi]);
-        const int un = __builtin_amdgcn_readfirstlane(grpi == 0 ? h0.w : th[3 + 3 * grpi]);
-        unsigned mymask = mask;
-        if constexpr (KS == 2) {                             // every second offset of the group
-          mymask = 0;
-          unsigned m = mask;
-          int r = 0;
-          while (m) {
-            const unsigned low = m & (0u - m);
-            if ((r & 1) == kg) mymask |= low;
-            m ^= low;
-            ++r;
-          }
-        }
-        u32x4_t bf[NB][2][2];
-        int kk[NB];
-        unsigned rest = mymask;
-        const int n_off = __popc(mymask);
-        n_off_dbg += n_off;
-        int k_last = 0;
-        auto pop = [&]() { if (rest) { k_last = __ffs(rest) - 1; rest &= rest - 1u; } return k_last; };
-        // prime the issue pattern of the steps -- four weight loads, one row load -- so that their counted waits hold from the
-        // first step on (the two row loads are dummies into ring slots that are waited for before they are reused)
-        f32x4_t ring[RD];
-        static_assert(NB == 2 && RD == 4, "priming order below");
-        kk[0] = pop(); load_b(bf[0], kk[0], slice, cout0);
-        go_load_row(ring[2], p.in, (unsigned)(tid & 7) * 16u);
-        kk[1] = pop(); load_b(bf[1], kk[1], slice, cout0);
-        go_load_row(ring[3], p.in, (unsigned)(tid & 7) * 16u);
-        __bf16* const U = Us(img);
-        if (!have_img) {                                     // nobody gathered this stage's image ahead of time
-          __syncthreads();                                   // (the image's previous readers are done)
-          if (grpi == 0) gather_now(U, Rs(buf), un, cin0, 0);
-          else gather_now(U, tr + ub, un, cin0, 0);
-        }
-        __syncthreads();
-        if (STAMP && dbg && stamp_on) go_stamp(dbg, n_stamp++);          // 1 + 3 i: barrier passed (image ready)
-        const bool park_here = !meta_parked;                 // this item's first stage: ask for the next item's metadata now
-        if (park_here) {
-          h0n = *reinterpret_cast<const int4*>(g.hdr + tile2 * GO_HDR);
-          if (tid < GO_BM * 27 / 8) lvn = reinterpret_cast<const uint4*>(g.lidx + tile2 * (GO_BM * 27))[tid];
-          const int32_t* tr2 = g.rows + tile2 * GO_ROWS;
-          rn0 = tr2[tid];
-          if (tid < GO3_RS - 256) rn1 = tr2[256 + tid];
-        }
-        // ---- what this stage gathers for its successor: the next slice's first group of this item, or -- on the item's last
-        // stage, with the next item's metadata parked -- the next item's first stage
-        const bool last_stage = stage == n_stages - 1;
-        bool ahead = false;
-        const int32_t* rows_n = Rs(buf);
-        int un_n = 0, cin0_n = 0;
-        if (!last_stage) {
-          if (grpi == n_groups - 1) { ahead = true; un_n = __builtin_amdgcn_readfirstlane(h0.w); cin0_n = (slice + 1) * BK; }
-        } else if (more && meta_parked) {
-          ahead = true; rows_n = Rs(buf ^ 1); un_n = __builtin_amdgcn_readfirstlane(h0n.w); cin0_n = s_lo2 * BK;
-        }
-        if (mp.flags & 1) ahead = false;
-        __bf16* const Un = Us(img ^ 1);
-        const int tasks_n = ahead ? un_n * 8 : 0;
-        const int nq = (tasks_n + 255) >> 8;                 // row loads per thread of the successor's gather
-        const unsigned kc16 = (unsigned)(tid & 7) * 16u + (unsigned)cin0_n * 4u;
-        // the row number of task q is read from LDS at the TOP of a step (g_row) and used at its end (g_issue): read where it is
-        // used, behind a condition, hipcc waited lgkmcnt(0) there -- draining the eight fragment reads of the next offset issued
-        // just before -- once per step
-        auto g_row = [&](int q) -> int32_t {
-          const int tk = q * 256 + tid;
-          return rows_n[min(tk >> 3, GO3_RS - 1)];              // always a valid LDS address; selected in g_issue
-        };
-        auto g_issue = [&](f32x4_t& dreg, int q, int32_t row_q) {   // task q of this thread (a dummy behind the last: row 0, dump row)
-          const int tk = q * 256 + tid;
-          const bool real = q < nq && tk < tasks_n;
-          const int32_t srow = real ? row_q : 0;
-          go_load_row(dreg, p.in, (unsigned)srow * (unsigned)(Cin * 4) + kc16);
-        };
-        auto g_finish = [&](const f32x4_t& dreg, int q) {
-          const int tk = q * 256 + tid;
-          const int u = (q >= 0 && q < nq && tk < tasks_n) ? (tk >> 3) : GO_UMAX + 1, kc = tid & 7;
-          uint2 h, m;
-          split2(make_float4(dreg[0], dreg[1], dreg[2], dreg[3]), a_scale, h, m);
-          __bf16* d = Un + lds_slot(u, kc >> 1) + (kc & 1) * 4;
-          *reinterpret_cast<uint2*>(d) = h;
-          *reinterpret_cast<uint2*>(d + GO2_US) = m;
-        };
-        // ---- the offsets: A fragments of offset j + 1 are read while offset j multiplies
-        auto load_li = [&](int (&li)[TM], int k) {
-#pragma unroll
-          for (int a = 0; a < TM; ++a) li[a] = ls0[a * (32 * 27) + k];
-        };
-        f16x8_t A[2][TM][2][2];                                // [set][row tile][plane][k-step]
-        auto read_a = [&](f16x8_t (&dst)[TM][2][2], const int (&li)[TM]) {
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-              for (int ks = 0; ks < 2; ++ks)
-                dst[a][pl][ks] = *reinterpret_cast<const f16x8_t*>(U + pl * GO2_US + lds_slot(li[a], ks * 2 + fhalf));
-        };
-        auto mfma_k = [&](const u32x4_t (&b)[2][2], const f16x8_t (&fa)[TM][2][2]) {
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const f16x8_t bh = __builtin_bit_cast(f16x8_t, b[0][ks]), bm = __builtin_bit_cast(f16x8_t, b[1][ks]);
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-              acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a][1][ks], bh, acc[a], 0, 0, 0);       // m*h
-              acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a][0][ks], bm, acc[a], 0, 0, 0);       // h*m
-              acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a][0][ks], bh, acc[a], 0, 0, 0);       // h*h
-            }
-          }
-        };
-        int li[TM];
-        load_li(li, kk[0]);
-        read_a(A[0], li);
-        load_li(li, kk[1]);                                  // the second offset (the first again when there is only one)
-        // one step = one offset.  t: index of the step inside the stage (ring / set indices are t % 4, t % 2: the steps run in
-        // turns of RD so that they are compile-time constants)
-        auto step = [&](int j, int t) {
-          const int32_t row_t = g_row(t);
-          go_waitn<(NB - 1) * 5 + 1>(bf[j % NB]);            // this step's weights have landed; newer: 1 row load + the step before's 5
-          read_a(A[(j + 1) & 1], li);                        // fragments of the next offset
-          mfma_k(bf[j % NB], A[j & 1]);
-          kk[j % NB] = pop();                                // two offsets ahead (behind the last offset: the last one again)
-          load_li(li, kk[j % NB]);                           // ... its local indices are turned into fragment reads one step later
-          load_b(bf[j % NB], kk[j % NB], slice, cout0);
-          g_issue(ring[j], t, row_t);
-          asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring[(j + 1) % RD]) : "n"((RD - 1) * 5));   // the row load RD - 1 steps old
-          g_finish(ring[(j + 1) % RD], t - (RD - 1));
-        };
-        int i = 0;
-        for (; i + RD <= n_off; i += RD) {
-#pragma unroll
-          for (int j = 0; j < RD; ++j) step(j, i + j);
-        }
-#pragma unroll
-        for (int j = 0; j < RD - 1; ++j)
-          if (i + j < n_off) step(j, i + j);
-        if (STAMP && dbg && stamp_on) go_stamp(dbg, n_stamp++);          // 2 + 3 i: this wave's offsets issued
-        // ---- nothing may stay in flight (the asm loads are invisible to the compiler); then the row loads not yet finished
-        // (the last RD - 1 issued) and the ones never issued (more tasks than offsets), without overlap
-#pragma unroll
-        for (int j = 0; j < NB; ++j) go_drain(bf[j]);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring[0]), "+v"(ring[1]), "+v"(ring[2]), "+v"(ring[3]));
-#pragma unroll
-        for (int jj = 0; jj < RD; ++jj) {
-          const int q = (n_off - 1) - (((n_off - 1 - jj) % RD + RD) % RD);      // the newest issued task that sits in ring[jj]
-          if (n_off > 0 && q >= 0 && q >= n_off - (RD - 1)) g_finish(ring[jj], q);
-        }
-        if (ahead && n_off < nq) gather_now(Un, rows_n, un_n, cin0_n, n_off);
-        if (park_here) {                                     // the next item's metadata has landed: park it
-          if (tid < GO_BM * 27 / 8) reinterpret_cast<uint4*>(Ls(buf ^ 1))[tid] = lvn;
-          Rs(buf ^ 1)[tid] = rn0;
-          if (tid < GO3_RS - 256) Rs(buf ^ 1)[256 + tid] = rn1;
-          meta_parked = true;
-        }
-        if (STAMP && dbg && stamp_on) go_stamp(dbg, n_stamp++);          // 3 + 3 i: drained, leftovers finished, metadata parked
-        have_img = ahead;
-        img ^= 1;
-      }
-    }
-
-    // ---- the item's tile is complete: merge (KS = 2), epilogue.  The image just used is free; the other one may already
-    // hold the next item's first stage.
-    unsigned char* const scratch = reinterpret_cast<unsigned char*>(Us(img ^ 1));
-    if constexpr (KS == 2) {
-      __syncthreads();
-      float* X = reinterpret_cast<float*>(scratch);          // 4 x 4 KB
-      float* mine = X + (wc * 2 + kg) * 1024;
-      const float* theirs = X + (wc * 2 + (kg ^ 1)) * 1024;
-      if (kg == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[1][i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mine[i * 64 + lane] = acc[0][i];
-      }
-      __syncthreads();
-      if (kg == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] += theirs[i * 64 + lane];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[1][i] += theirs[i * 64 + lane];
-      }
-    }
-    if (p.splits > 1) {                                      // partial tile into this split's slab; conv_reduce_kernel follows
-      float* slab = p.slab + (int64_t)zs * p.no_cap * Cout;
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        if (KS == 2 && a != kg) continue;
-        const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t row = row0 + (i & 3) + 8 * (i >> 2);
-          if (col_ok && row < n_live) slab[row * Cout + col] = acc[a][i] * out_scale;
-        }
-      }
-    } else {
-      const int act = p.act;
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        if (KS == 2 && a != kg) continue;
-        const int64_t row0 = tile0 + a * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          float res[4];
-          if (HAS_RES) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int64_t row = row0 + q + 8 * rg;
-              const int64_t rc = row < n_live ? row : n_live - 1;
-              res[q] = p.residual[rc * Cout + colc];
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int64_t row = row0 + q + 8 * rg;
-            float v = acc[a][rg * 4 + q];
-            v = v * out_scale;
-            v = v * sc;
-            v = v + sh;
-            if (HAS_RES) v = v + res[q];
-            v = apply_act(v, act);
-            if (col_ok && row < n_live) {
-              p.out[row * Cout + col] = v;
-              mx = fmaxf(mx, fabsf(v));
-            }
-          }
-        }
-      }
-    }
-    if (STAMP && dbg && stamp_on) { go_stamp(dbg, 15); stamp_on = false; if (threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + 14] = (unsigned long long)n_off_dbg; }
-    if (!more) break;
-    it = it2;
-    h0 = h0n;
-    buf ^= 1;
-  }
-  if (p.out_amax != nullptr && p.splits == 1) {
-    __syncthreads();
-    block_amax_publish(p.out_amax, mx, reinterpret_cast<float*>(go3_smem));
-  }
-}
+#ifdef CNRMA_EXPERIMENTS
+#include "sparse_exp_go3.inc"
+#endif
 
 // children coordinates of the generative transposed conv: child k (x fastest) of parent i is row 8 * i + morton_child(k)
 __global__ __launch_bounds__(256) void convtr_coords_kernel(const int32_t* __restrict__ in_coords, int64_t n_cap,
@@ -4667,6 +3696,7 @@ extern "C" size_t cnrma_sparse_conv_workspace_bytes(int64_t no_cap, int Cout, in
   return (size_t)K * (size_t)no_cap * (size_t)Cout * sizeof(float);
 }
 
+#ifdef CNRMA_EXPERIMENTS
 extern "C" int cnrma_debug_conv_tuning(const int* v, int n) {
   // v = {tile shape (0 128x128, 1 128x64, 2 64x64, 3 128x32, 4 64x128), splits over the kernel offsets, prefetch depth}; -1 or
   // missing = the launcher's own choice; n == 0 restores the product configuration.  Host-side global state: A/B runs only.
@@ -4679,6 +3709,7 @@ extern "C" int cnrma_debug_conv_tuning(const int* v, int n) {
   g_conv_tune = t;
   return 0;
 }
+#endif
 
 extern "C" int cnrma_sparse_conv_plan(int64_t no_cap, int Cin, int Cout, int K, int mode, int slices, size_t workspace_bytes,
                                       int* out6) {
@@ -5041,7 +4072,7 @@ static_assert(GO2_LDS <= 48 * 1024 && 4 * GO2_LDS <= 160 * 1024, "four blocks pe
 // (a captured launch sequence replays the same kernels; cnrma_sparse_conv_go_plan exposes it to the tests)
 struct Go2Plan { int form, bn, ks, splits, slices_per_split, mode, nb; int64_t tiles; unsigned blocks; Go2Map mp; };
 static Go2Plan go2_plan(int64_t no_cap, int Cin, int Cout, bool has_ws, size_t workspace_bytes) {
-  const ConvTune tune = g_conv_tune;
+  const ConvTune tune = CNRMA_CONV_TUNE;
   Go2Plan pl{};
   pl.form = tune.go >= 0 ? tune.go : go_form_default(no_cap, Cin, Cout);
   pl.bn = Cout >= 128 ? 128 : 64;
@@ -5101,6 +4132,7 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
     CNRMA_LAUNCH_CHECK();
     return 0;
   }
+#ifdef CNRMA_EXPERIMENTS            // + the s_memtime-stamped instantiation and four weight offsets in flight (measured 0-5 % slower)
 #define CNRMA_GO2(WN, KS_, NB_)                                                                              \
   rc = stamps != nullptr && !has_res ? launch_go2_one<WN, KS_, false, NB_, true>(blocks, p, g, wfrag, mp, st) \
        : has_res ? launch_go2_one<WN, KS_, true, NB_>(blocks, p, g, wfrag, mp, st)                           \
@@ -5112,6 +4144,14 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
     if (pl.nb == 2) CNRMA_GO2(2, 2, 2);
     else CNRMA_GO2(2, 2, 4);
   }
+#else
+#define CNRMA_GO2(WN, KS_, NB_)                                                                              \
+  rc = has_res ? launch_go2_one<WN, KS_, true, NB_>(blocks, p, g, wfrag, mp, st)                             \
+               : launch_go2_one<WN, KS_, false, NB_>(blocks, p, g, wfrag, mp, st)
+  if (stamps != nullptr) return CNRMA_EINVAL;
+  if (pl.bn == 128) CNRMA_GO2(4, 1, 2);
+  else CNRMA_GO2(2, 2, 2);
+#endif
 #undef CNRMA_GO2
   if (rc != 0) return rc;
   if (pl.splits > 1) {
@@ -5123,51 +4163,9 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
   return 0;
 }
 
-// third form (experimental until measured everywhere): persistent grid, two blocks per CU
-template <int WAVES_N, int KS, bool HAS_RES, bool STAMP = false>
-static int launch_go3_one(unsigned blocks, const ConvArgs& p, const GoArgs& g, const uint16_t* wfrag, const Go3Map& mp, hipStream_t st) {
-  auto kernel = sparse_conv_go3_kernel<WAVES_N, KS, HAS_RES, STAMP>;
-  static bool raised = false;               // per instantiation: dynamic LDS above the 64-KB default
-  if (!raised) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GO3_LDS);
-    if (e != hipSuccess) return -(int)e;
-    raised = true;
-  }
-  if (g_conv_tune.pf == 8) {                               // A/B aid: how many of these blocks a CU holds
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 256, GO3_LDS);
-    fprintf(stderr, "sparse_conv_go3_kernel<%d, %d, %d>: %d blocks per CU at %d bytes of LDS\n", WAVES_N, KS, (int)HAS_RES, nb, GO3_LDS);
-  }
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), GO3_LDS, st, p, g, wfrag, mp);
-  return 0;
-}
-
-static int launch_go3(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* wfrag, bool residual, void* stamps, hipStream_t st) {
-  Go3Map mp;
-  mp.tiles = pl.mp.tiles; mp.ncol = pl.mp.ncol; mp.ng = pl.mp.ng;
-  mp.n_items = mp.tiles * mp.ng;
-  mp.per_xcd = (int)ceil_div(mp.n_items, 8);
-  mp.bpx = mp.per_xcd < 64 ? mp.per_xcd : 64;               // 2 blocks x 32 CUs per XCD
-  mp.flags = g_conv_tune.pf == 7 ? 1 : 0;
-  g.slices_per_split = pl.slices_per_split;
-  p.splits = pl.splits;
-  g.counters = reinterpret_cast<unsigned*>(stamps);
-  const unsigned blocks = 8u * (unsigned)mp.bpx;
-  const bool has_res = residual && pl.splits == 1;
-  int rc;
-  if (stamps != nullptr && !has_res)
-    rc = pl.bn == 128 ? launch_go3_one<4, 1, false, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<2, 2, false, true>(blocks, p, g, wfrag, mp, st);
-  else if (pl.bn == 128) rc = has_res ? launch_go3_one<4, 1, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<4, 1, false>(blocks, p, g, wfrag, mp, st);
-  else rc = has_res ? launch_go3_one<2, 2, true>(blocks, p, g, wfrag, mp, st) : launch_go3_one<2, 2, false>(blocks, p, g, wfrag, mp, st);
-  if (rc != 0) return rc;
-  if (pl.splits > 1) {
-    int64_t rb = ceil_div(p.no_cap * p.Cout / 4 + 1, 256);
-    if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(conv_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, st, p);
-  }
-  CNRMA_LAUNCH_CHECK();
-  return 0;
-}
+#ifdef CNRMA_EXPERIMENTS
+#include "sparse_exp_go3_launch.inc"
+#endif
 
 extern "C" int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size_t workspace_bytes, int has_residual, int* out8) {
   // what cnrma_sparse_conv_go_f16x3 launches for these sizes: out8 = {form (0 first, 1 second), tile columns (64: the four waves
@@ -5254,7 +4252,7 @@ extern "C" int cnrma_sparse_tile_union_build(const int32_t* nbr, int64_t no_cap,
   int32_t* rows = reinterpret_cast<int32_t*>(w);     w += go_align(tiles * GO_ROWS * 4);
   uint16_t* lidx = reinterpret_cast<uint16_t*>(w);
   hipLaunchKernelGGL(tile_union_kernel, dim3((unsigned)ceil_div((int64_t)tiles, 4)), dim3(256), 0, as_stream(stream), nbr, no_cap,
-                     no_dev, K, hdr, rows, lidx, g_conv_tune.ablate);
+                     no_dev, K, hdr, rows, lidx, CNRMA_CONV_TUNE.ablate);
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
@@ -5276,7 +4274,7 @@ extern "C" int cnrma_sparse_conv_wgrad_go_bf16(const float* in_feats, int Cin, c
   map.n_ci = (int)ceil_div(Cin, 64);
   map.n_co = (int)ceil_div(Cout, 64);
   map.by_part = parts >= 16;
-  map.ablate = g_conv_tune.ablate;
+  map.ablate = CNRMA_CONV_TUNE.ablate;
   const int64_t per = (int64_t)WGO_KG * map.n_ci * map.n_co;
   const int64_t blocks = (map.by_part ? ceil_div(parts, 8) * 8 : (int64_t)parts) * per;
   if (blocks > 0x7fffffffLL) return CNRMA_EINVAL;
@@ -5420,24 +4418,30 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   g.lidx = reinterpret_cast<const uint16_t*>(w);
   ConvArgs p{in_feats, Cin, nullptr, K, nullptr, Cout, scale, shift, residual, act, out_feats, no_cap, no_dev, 1, 1, K,
              reinterpret_cast<float*>(workspace), nullptr, 0, nullptr, 0, in_amax, nullptr, out_amax, nullptr, 0};
-  p.ablate = g_conv_tune.ablate;
+  p.ablate = CNRMA_CONV_TUNE.ablate;
   const uint16_t* wfrag = reinterpret_cast<const uint16_t*>(weight_frag);
   p.w_amax = reinterpret_cast<const float*>(wfrag + 2 * (int64_t)K * Cin * conv_cout_padded(Cout));
   const int bn = Cout >= 128 ? 128 : 64;
   const int ns = Cin / BK;
   {
     const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace != nullptr, workspace_bytes);
+#ifndef CNRMA_EXPERIMENTS
+    (void)ns; (void)bn; (void)tiles;
+    return launch_go2(pl, p, g, wfrag, residual != nullptr, nullptr, st);       // the product library: the second form, nothing else
+  }
+}
+#else
     // the other ablation masks (diagnostic kernels with phases switched off) exist in the first form only
-    if (pl.form >= 2 && (g_conv_tune.ablate & ~64) == 0 && (uint64_t)no_cap * (uint64_t)Cin * 4u < (1ull << 32))
-      return launch_go3(pl, p, g, wfrag, residual != nullptr, (g_conv_tune.ablate & 64) ? tile_counters : nullptr, st);
-    if (pl.form >= 1 && (g_conv_tune.ablate & ~64) == 0)
-      return launch_go2(pl, p, g, wfrag, residual != nullptr, (g_conv_tune.ablate & 64) ? tile_counters : nullptr, st);
+    if (pl.form >= 2 && (CNRMA_CONV_TUNE.ablate & ~64) == 0 && (uint64_t)no_cap * (uint64_t)Cin * 4u < (1ull << 32))
+      return launch_go3(pl, p, g, wfrag, residual != nullptr, (CNRMA_CONV_TUNE.ablate & 64) ? tile_counters : nullptr, st);
+    if (pl.form >= 1 && (CNRMA_CONV_TUNE.ablate & ~64) == 0)
+      return launch_go2(pl, p, g, wfrag, residual != nullptr, (CNRMA_CONV_TUNE.ablate & 64) ? tile_counters : nullptr, st);
   }
   // short layers: split over the 32-channel slices (every block still runs all 27 offsets of its slices); partial slabs are
   // reduced by conv_reduce_kernel in a fixed order
   int splits = 1;
   const int64_t blocks = (int64_t)tiles * ceil_div(Cout, bn);
-  const int force = g_conv_tune.splits;
+  const int force = CNRMA_CONV_TUNE.splits;
   if (workspace != nullptr && ns > 1 && (blocks < 384 || force > 0)) {
     splits = force > 0 ? force : (int)ceil_div(768, blocks);
     if (splits > ns) splits = ns;
@@ -5458,7 +4462,7 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
     if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
     else hipLaunchKernelGGL((sparse_conv_go_kernel<1, 4, 2, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
   } else {
-    if (g_conv_tune.pf == 3) {                             // A/B aid: the 2 x 2 waves-over-rows-x-columns form
+    if (CNRMA_CONV_TUNE.pf == 3) {                             // A/B aid: the 2 x 2 waves-over-rows-x-columns form
       if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, true>), grid, dim3(256), 0, st, p, g, wfrag);
       else hipLaunchKernelGGL((sparse_conv_go_kernel<2, 2, 1, 1, false>), grid, dim3(256), 0, st, p, g, wfrag);
     } else if (has_res) hipLaunchKernelGGL((sparse_conv_go_kernel<1, 2, 2, 1, true, 2>), grid, dim3(256), 0, st, p, g, wfrag);
@@ -5472,6 +4476,7 @@ extern "C" int cnrma_sparse_conv_go_f16x3(const float* in_feats, const float* in
   CNRMA_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
 extern "C" int cnrma_sparse_conv_f16x3(const float* in_feats, const float* in_amax, int Cin, const int32_t* nbr, int K,
                                        const void* weight_split, int Cout, const float* scale, const float* shift,

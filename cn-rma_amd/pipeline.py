@@ -503,6 +503,9 @@ class StaticScene:
                 with torch.cuda.graph(self.graph, stream=self.stream):
                     self.out = self._trace()
                 self.n_nodes = graph_node_count(self.graph) if kept else None   # launches per scene (bench: graph_nodes_per_scene)
+                # tables of the CAPTURED trace that did not fit the 0xFF arena its sizing run measured (each clears itself: one
+                # launch more; 0 unless the two runs took different table sequences -- ADVICE round 5)
+                self.arena_fallbacks = self.plan.arena_fallbacks
                 if kept:
                     self.graph.instantiate()
                 self.stream.synchronize()

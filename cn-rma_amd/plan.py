@@ -74,6 +74,7 @@ class Plan:
             self._arena = torch.empty(self._arena_need, dtype=torch.uint8, device=self._arena_dev)
         self._arena_off = 0
         self._arena_filled = False
+        self.arena_fallbacks = 0   # tables of this trace that did not fit the arena sized by the plan's first static run
 
     # ---- recording (eager calibration run) --------------------------------------------------------------------------
     def record(self, n):
@@ -177,8 +178,10 @@ class Plan:
             self._arena_need = getattr(self, "_arena_need", 0) + nbytes
             self._arena_dev = device
             return None
-        if self._arena_off + nbytes > self._arena.numel():          # a trace that asks for more than it did when it was sized
-            return None
+        if self._arena_off + nbytes > self._arena.numel():          # a trace that asks for more than it did when it was sized:
+            self.arena_fallbacks += 1                                # the caller clears its own table (correct, one launch more);
+            return None                                              # counted, so that a drift between the sizing run and the
+                                                                     # captured run shows (StaticScene info / test_static_gpu)
         if not self._arena_filled:
             from . import _lib
             _lib.call("cnrma_fill_bytes_u8", _lib.ptr(self._arena), 0xFF, self._arena.numel(), _lib.stream())

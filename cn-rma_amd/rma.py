@@ -121,8 +121,12 @@ def dense_tuning(**kw):
     no arguments = the product configuration.  Never called by product code."""
     import ctypes
     if not kw:
-        call("cnrma_debug_dense_tuning", None, 0)
+        # back to the product library (libcnrma_hip.so has no tuning state, nothing to reset there)
+        if _lib.experiments_active():
+            call("cnrma_debug_dense_tuning", None, 0)
+            _lib.experiments(False, "dense")
         return
+    _lib.experiments(True, "dense")       # the alternative schedules exist in libcnrma_hip_exp.so only
     base = dict(variant=1, slab=1, st=16, zt=32, tt=8, zi=32, chunk=-1, persist=0, lpv=0, pipe=1, epi=0, lockstep=0, lattice=0, nt=0, own=0, stagger=0, groups=8, ldspad=0)
     base.update(DENSE_DEFAULTS)
     unknown = set(kw) - set(base)

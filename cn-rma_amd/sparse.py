@@ -728,8 +728,12 @@ def conv_tuning(shape=None, splits=-1, pf=-1, ablate=0, ws=-1, xcd=-1, go=-1, nb
     and the prefetch depth of every later convolution launch; no arguments = the product configuration"""
     import ctypes
     if shape is None and splits < 0 and pf < 0 and not ablate and ws < 0 and xcd < 0 and go < 0 and nb < 0:
-        call("cnrma_debug_conv_tuning", None, 0)
+        # back to the product library (libcnrma_hip.so has no tuning state, nothing to reset there)
+        if _lib.experiments_active():
+            call("cnrma_debug_conv_tuning", None, 0)
+            _lib.experiments(False, "conv")
         return
+    _lib.experiments(True, "conv")       # the forced variants / alternative kernel forms exist in libcnrma_hip_exp.so only
     # ablate (diagnostic kernels, timing only -- results are wrong): bit 0 no MFMAs, 1 no A loads, 2 no B loads, 3 no LDS
     # stores, 4 no barriers after a block's first stage; the gather-once weight gradient reads 256 no consumer phase, 512 no
     # LDS stores, 1024 no row loads, 2048 LDS reads without MFMAs (scripts/wgrad_go_ablate.py)
@@ -764,7 +768,20 @@ def _gather_once(in_cs, out_cs):
     """3x3x3 stride-1 convolution: the gather-once kernel where the rows are compact (a 64-row tile reads ~250 distinct
     input rows instead of 64 x ~20) and there are enough of them to fill the chip; GO_CONV True / False force the choice"""
     if GO_CONV == "auto":
-        return in_cs.compact and out_cs.n >= GO_MIN_ROWS
+        if not in_cs.compact:
+            return False
+        # the row threshold is a recorded branch of the size plan (ADVICE round 5): out_cs.n is a live count in the eager /
+        # calibration run and a CAPACITY (recorded size x 1.2 + 256, i.e. always >= GO_MIN_ROWS) in the static trace -- decided on
+        # `n` alone a 9-56-row level ran the 64-row-tile gather-once kernel in the replay and the stage kernel in the eager
+        # fallback of the same scene (another summation order between the two)
+        p = P.current()
+        if p is not None and p.static:
+            f = p.next_flag()
+            return out_cs.n >= GO_MIN_ROWS if f is None else bool(f)      # calibration scenes disagreed: by capacity
+        f = out_cs.n >= GO_MIN_ROWS
+        if p is not None:
+            p.record_flag(f)
+        return f
     return bool(GO_CONV)
 
 

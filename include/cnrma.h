@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define CNRMA_EINVAL (-22)
-#define CNRMA_ABI_VERSION 5   /* 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16, cnrma_sparse_conv_go_bf16 (+ its weight images), cnrma_bn_train_forward_f32 / _backward_f32; 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
+#define CNRMA_ABI_VERSION 6   /* 6: the cnrma_debug_* entry points (and the experimental kernels behind them) left the product library: they exist in libcnrma_hip_exp.so (-DCNRMA_EXPERIMENTS) only; no signature changed; 5: + cnrma_sparse_conv_prepare_weights_bf16_t, cnrma_sparse_conv_wgrad_go_bf16, cnrma_sparse_conv_go_bf16 (+ its weight images), cnrma_bn_train_forward_f32 / _backward_f32; 4: gather-once convolution family, records-based point selection (SampleWs layout), *_ref_f32 hand-off */
 
 int cnrma_abi_version(void);
 
@@ -69,10 +69,13 @@ int cnrma_backproject_accum_ref_f32(const float* const* feat_nhwc_ref, const flo
                                     int X, int Y, int Z, float voxel_size, float ox, float oy, float oz,
                                     float* volume, int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Debug / A-B aid (scripts/dense_ab.py, tests of the alternative voxel orders): overrides the dense kernel's schedule
- * switches {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger, groups, ldspad} (host-side global state; n = 0
- * restores the product configuration).  Product code never calls it and nothing reads the environment. */
+#ifdef CNRMA_EXPERIMENTS
+/* libcnrma_hip_exp.so ONLY (built with -DCNRMA_EXPERIMENTS; the product library libcnrma_hip.so exports no cnrma_debug_* symbol
+ * and holds no tuning state).  Debug / A-B aid (scripts/dense_ab.py, tests of the alternative voxel orders): overrides the dense
+ * kernel's schedule switches {variant, slab, st, zt, tt, zi, chunk, persist, lpv, pipe, epi, lockstep, lattice, nt, own, stagger,
+ * groups, ldspad} (host-side global state of that library; n = 0 restores the product configuration). */
 int cnrma_debug_dense_tuning(const int* values, int n);
+#endif
 
 /* Backward of cnrma_backproject_accum_f32 w.r.t. the feature maps (training):
  * grad_feat_nhwc[v][pix_v(g)][c] += grad_volume[c][g] / count[g] for every valid (voxel g, view v) pair; the output is
@@ -145,8 +148,11 @@ int cnrma_rma_sigmoid_table_f32(const float* tsdf, int64_t n, float* table, void
  * most of their steps in free space).  skip_table: cnrma_rma_skip_table_bytes(X, Y, Z) bytes (radii + scratch of the build). */
 size_t cnrma_rma_skip_table_bytes(int X, int Y, int Z);
 int cnrma_rma_march_tables_f32(const float* tsdf, int X, int Y, int Z, float* table, void* skip_table, void* stream);
-/* parity aid: the march's division by the voxel size (reciprocal + two quotient refinements) next to the IEEE division */
+#ifdef CNRMA_EXPERIMENTS
+/* libcnrma_hip_exp.so only.  Parity aid: the march's division by the voxel size (reciprocal + two quotient refinements) next to
+ * the IEEE division */
 int cnrma_debug_div_by_voxel_size_f32(const float* a, int64_t n, float voxel_size, float* q_fast, float* q_ref, void* stream);
+#endif
 int cnrma_rma_neus_march_f32(const float* proj_inv, const float* tsdf, const float* sig_table, int V, int H, int W, int X,
                              int Y, int Z, float voxel_size, float ox, float oy, float oz, int n_steps, float t_one,
                              float thr, int32_t* count, double* wsum, void* kept, int cap, int32_t* overflow,
@@ -352,7 +358,11 @@ int cnrma_sparse_conv_f32(const float* in_feats, int Cin, const int32_t* nbr, in
  * mode: 0 = fp32 MFMA kernel (cnrma_sparse_conv_f32), 1 = f16x3, 2 = bf16, 3 = bf16x6.  Tests use it to prove which
  * variants a parity case covered (fcaf3d_backbone.py:59-107 / fcaf3d_head.py:61-139 run through all of them). */
 int cnrma_sparse_conv_plan(int64_t no_cap, int Cin, int Cout, int K, int mode, int slices, size_t workspace_bytes, int* out6);
-/* Debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): overrides {tile shape id, splits, load stages in flight,
+#ifdef CNRMA_EXPERIMENTS
+/* libcnrma_hip_exp.so ONLY (-DCNRMA_EXPERIMENTS): that library additionally carries the measured-and-rejected kernel forms (the
+ * warp-specialised stage kernel, the first and third form of the gather-once convolution, ablation / s_memtime-stamped
+ * instantiations); the product library has none of them and no tuning state.
+ * Debug / A-B aid (scripts/conv_sweep.py, variant-forcing tests): overrides {tile shape id, splits, load stages in flight,
  * ablation mask} of every later convolution launch (-1 = the launcher's choice; n = 0 restores the product configuration).
  * A non-zero ablation mask routes f16x3 launches to a DIAGNOSTIC kernel that leaves stage components out (timing
  * experiments: its results are meaningless; stage kernel bits: 1 MFMAs, 2 A loads, 4 B loads, 8 LDS stores, 16 barriers;
@@ -360,6 +370,7 @@ int cnrma_sparse_conv_plan(int64_t no_cap, int Cin, int Cout, int K, int mode, i
  * 32 local-index load; tile-union builder: 32 / 64 insertion / numbering).  Host-side global state; product code never calls it and nothing reads the
  * environment. */
 int cnrma_debug_conv_tuning(const int* values, int n);
+#endif
 
 /* fp32-grade convolution on the bf16 matrix cores ("bf16x6": each fp32 operand split exactly into 3 bf16 pieces, the 6
  * significant partial products accumulated in fp32; relative error ~2^-23 per product, i.e. that of an fp32 fma chain;

@@ -123,9 +123,12 @@ def test_synth_scene_is_deterministic():
 # ---------------------------------------------------------------------------------------------------------------
 # C-ABI surface: the library loads, exports every symbol of include/cnrma.h, and the ctypes table agrees in arity
 # ---------------------------------------------------------------------------------------------------------------
-def _header_functions():
+def _header_functions(experiments=False):
+    """prototypes of include/cnrma.h: the product surface, or (experiments=True) only those under #ifdef CNRMA_EXPERIMENTS"""
     src = open(os.path.join(ROOT, "include", "cnrma.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    exp = "\n".join(re.findall(r"#ifdef CNRMA_EXPERIMENTS\n(.*?)#endif", src, flags=re.S))
+    src = exp if experiments else re.sub(r"#ifdef CNRMA_EXPERIMENTS\n.*?#endif", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(?:int|size_t)\s+(cnrma_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
@@ -134,25 +137,41 @@ def _header_functions():
     return out
 
 
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("cnrma_")}
+
+
 def test_library_exports_every_declared_symbol():
     from cnrma_amd import _lib
-    if not os.path.exists(_lib.LIB_PATH):                  # fresh checkout: hipcc cross-compiles without a GPU (~1-2 min)
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(_lib.EXP_LIB_PATH):   # fresh checkout: hipcc cross-compiles without a GPU
         import subprocess
-        subprocess.run(["make", "-C", os.path.dirname(_lib.LIB_PATH), "-j8", "libcnrma_hip.so"], check=True)
+        subprocess.run(["make", "-C", os.path.dirname(_lib.LIB_PATH), "-j8"], check=True)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     decl = _header_functions()
     assert len(decl) >= 30
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/cnrma.h but not exported"
     assert lib.cnrma_abi_version() == _lib.ABI_VERSION
+    # the product library exports exactly the product surface: no cnrma_debug_* hook, nothing undeclared
+    product = _exported(_lib.LIB_PATH)
+    assert product == set(decl), product ^ set(decl)
+    assert not [n for n in product if n.startswith("cnrma_debug")]
+    # the experiments library = the same surface + the prototypes under #ifdef CNRMA_EXPERIMENTS
+    extra = _header_functions(experiments=True)
+    assert extra and all(n.startswith("cnrma_debug_") for n in extra)
+    assert _exported(_lib.EXP_LIB_PATH) == set(decl) | set(extra)
+    assert ctypes.CDLL(_lib.EXP_LIB_PATH).cnrma_abi_version() == _lib.ABI_VERSION
 
 
 def test_ctypes_table_matches_header():
     from cnrma_amd import _lib
-    decl = _header_functions()
-    assert set(decl) == set(_lib.SIGNATURES), set(decl) ^ set(_lib.SIGNATURES)
-    for name, n in decl.items():
-        assert len(_lib.SIGNATURES[name][1]) == n, (name, n, len(_lib.SIGNATURES[name][1]))
+    for decl, table in ((_header_functions(), _lib.SIGNATURES), (_header_functions(experiments=True), _lib.EXPERIMENT_SIGNATURES)):
+        assert set(decl) == set(table), set(decl) ^ set(table)
+        for name, n in decl.items():
+            assert len(table[name][1]) == n, (name, n, len(table[name][1]))
+    assert not set(_lib.SIGNATURES) & set(_lib.EXPERIMENT_SIGNATURES)
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -334,7 +334,11 @@ def test_division_by_voxel_size_is_exact(device, vs):
              (torch.randint(-4000, 4000, (n // 4,), generator=g, device=device).float() + 0.5) * vs]   # near rounding ties
     a = torch.cat(parts).contiguous()
     qf, qr = torch.empty_like(a), torch.empty_like(a)
-    call("cnrma_debug_div_by_voxel_size_f32", ptr(a), a.numel(), float(vs), ptr(qf), ptr(qr), stream())
+    _lib.experiments(True)                 # the parity aid lives in libcnrma_hip_exp.so (same rma.hip, -DCNRMA_EXPERIMENTS)
+    try:
+        call("cnrma_debug_div_by_voxel_size_f32", ptr(a), a.numel(), float(vs), ptr(qf), ptr(qr), stream())
+    finally:
+        _lib.experiments(False)
     assert torch.equal(qf.view(torch.int32), qr.view(torch.int32))
 
 
