@@ -98,6 +98,23 @@ def pmc_sq(workload, tag=None, profiles=None):
     return out
 
 
+def pmc_provenance(tag=None, profiles=None):
+    """where the counter-derived numbers of the line come from, and whether they describe THIS build: the PMC
+    passes are separate rocprofv3 runs committed under profiles/, not part of a bench run; scripts/profile_round.sh /
+    profile_sq.sh record the sha256 of the library they profiled in profiles/<tag>_pmc_meta.json.  Returns
+    dict(src="profiles/<tag>@<sha12>", matches_build=bool | None)."""
+    import hashlib
+    tag = tag or PMC_TAG
+    path = os.path.join(profiles or os.path.join(ROOT, "profiles"), f"{tag}_pmc_meta.json")
+    if not os.path.exists(path):
+        return dict(src=f"profiles/{tag}@unrecorded", matches_build=None)
+    with open(path) as f:
+        meta = json.load(f)
+    lib = os.path.join(ROOT, "cn-rma_amd", "csrc", "libcnrma_hip.so")
+    sha = hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None
+    return dict(src=f"profiles/{tag}@{str(meta.get('so_sha256', ''))[:12]}", matches_build=(sha == meta.get("so_sha256")) if sha else None)
+
+
 PASS_DEFAULT = {}             # workload -> scenes per sparse-network pass (measured: see DESIGN.md "Scenes per pass")
 
 _T0 = time.perf_counter()
@@ -701,8 +718,14 @@ def profile_block(wl, block, name):
     block["stage_ms"] = stage
     block["conv"] = conv
     block["pmc_sq"] = pmc_sq(name)
+    block["pmc_provenance"] = pmc_provenance()
     if block["pmc_sq"] and "gather_once_conv" in block["pmc_sq"]:
-        conv["mfma_busy_gather_once"] = block["pmc_sq"]["gather_once_conv"]["mfma_busy"]
+        # a counter pass of ANOTHER build (or of the exact-fp32 kernels) says nothing about these launches: null, not a stale number
+        from cnrma_amd import sparse as _S
+        f16x3 = _S.CONV_PRECISION == "f16x3"
+        ok = block["pmc_provenance"]["matches_build"] is not False and f16x3
+        conv["mfma_busy_gather_once"] = block["pmc_sq"]["gather_once_conv"]["mfma_busy"] if ok else None
+        conv["mfma_busy_src"] = block["pmc_provenance"]["src"] + ("" if ok else " (another build: not reported)")
     block["conv_layers"] = [dict(K=L["K"], Cin=L["Cin"], Cout=L["Cout"], rows=L["n_out"], pairs=L["pairs"], ms=round(L["ms"], 4))
                             for L in layers]
     ms_scene = block["ms_per_scene"]
@@ -845,6 +868,7 @@ def compact_line(result):
     if result.get("conv"):
         line["conv_ms_per_scene"] = result["conv"].get("ms_per_scene")
         line["conv_mfma_busy"] = result["conv"].get("mfma_busy_gather_once")
+        line["pmc_src"] = result["conv"].get("mfma_busy_src")            # roofline.traffic and conv_mfma_busy: committed counter passes
     if result.get("whole_path_hbm"):
         line["whole_path_hbm_frac"] = result["whole_path_hbm"].get("frac_of_8TBps")
     line["roofline"] = _roof(result.get("roofline"))

@@ -4,6 +4,10 @@ WL=$1; TAG=$2
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python3 - > $OUT/pmc_meta.json <<PYEOF
+import hashlib, json, time
+print(json.dumps(dict(so_sha256=hashlib.sha256(open("$ROOT/cn-rma_amd/csrc/libcnrma_hip.so","rb").read()).hexdigest(), workload="$WL", taken=time.strftime("%Y-%m-%d %H:%M:%S"))))
+PYEOF
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --workload $WL --no-secondary --no-cpu-baseline --no-profile --steps 4 --warmup 2 --scenes-per-step 3 --windows 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err

@@ -22,6 +22,8 @@ def _canned():
     r["kernels"]["x" * 300] = dict(ms_per_scene=1.0)
     r["conv_layers"] = r["conv_layers"] * 4
     r["train_S"] = dict(value=40.0, ms_per_step=25.0, note="n" * 5000)
+    r["A"] = dict(value=240.0, ms_per_step=100.0, graph_nodes_per_scene=290, n_classes=17, n_reg_outs=8, workload="A" * 400,
+                  windows_scenes_per_s=[240.0, 241.0, 239.0])
     r["dist"] = dict(world_size=8, backend="nccl", rank=0, per_rank_window_s=[[2.0] * 8] * 3)
     return r
 
@@ -47,6 +49,7 @@ def test_line_is_short_strict_json_with_the_contract_keys():
     for k in ("kernels", "conv_layers", "stage_ms"):
         assert k not in line and k not in line["S"]
     assert line["through_plugin"]["value"] and line["nchw_input"]["value"] and line["value_f32_conv"]
+    assert line["A"] == dict(value=240.0, ms_per_step=100.0, graph_nodes_per_scene=290, n_reg_outs=8)      # BASELINE configs[2]
     assert line["detail"] == bench.DETAIL_NAME
 
 
