@@ -23,6 +23,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "cnrma_fill_bytes_u8": (c_int, [P, I, c_size_t, P]),
     "cnrma_abi_version": (c_int, []),
+    "cnrma_range_violations_i32": (c_int, [P, P, P, I, P, P]),
     "cnrma_nchw_to_nhwc_f32": (c_int, [P, P, I, I, I, I, P]),
     "cnrma_backproject_accum_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),
     "cnrma_backproject_accum_ref_f32": (c_int, [P, P, I, I, I, I, I, I, I, F, F, F, F, P, P, P, L, P]),

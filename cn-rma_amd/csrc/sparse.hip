@@ -3601,12 +3601,57 @@ __global__ __launch_bounds__(256) void stride_sorted_write_kernel(const int32_t*
   reinterpret_cast<int4*>(out_coords)[j] = make_int4(b, x, y, z);
 }
 
+// the same for short sets (n_cap <= STRIDE_SMALL_MAX: the coarse levels) as ONE block and ONE launch instead of four (flag,
+// two scan launches, write): a thread owns a contiguous run of rows, flags them against their predecessors, the block scans
+// the counts, the run's first-of-parent rows are written in order.  Same rows, same order, same n_out.
+constexpr int STRIDE_SMALL_MAX = 16384;
+__global__ __launch_bounds__(1024) void stride_sorted_small_kernel(const int32_t* __restrict__ in_coords, int n_cap,
+                                                                   const int32_t* __restrict__ n_dev, int new_stride,
+                                                                   int32_t* __restrict__ out_coords, int out_cap,
+                                                                   int32_t* __restrict__ n_out) {
+  __shared__ int smem[1024 / 64 + 1];
+  const int n = (int)live_rows(n_cap, n_dev);
+  const int per = (n_cap + 1023) / 1024;                   // <= 16
+  const int lo = threadIdx.x * per, hi = min(lo + per, n);
+  unsigned flags = 0;
+  int pb = 0, px = 0, py = 0, pz = 0;
+  if (lo < hi && lo > 0) quantise<1>(in_coords, lo - 1, 1.0f, new_stride, 0, &pb, &px, &py, &pz);
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) {
+    int b, x, y, z;
+    quantise<1>(in_coords, i, 1.0f, new_stride, 0, &b, &x, &y, &z);
+    const bool f = i == 0 || b != pb || x != px || y != py || z != pz;
+    flags |= (f ? 1u : 0u) << (i - lo);
+    cnt += f ? 1 : 0;
+    pb = b; px = x; py = y; pz = z;
+  }
+  int total;
+  int run = block_excl_scan<1024>(cnt, smem, &total);
+  for (int i = lo; i < hi; ++i) {
+    if ((flags >> (i - lo)) & 1u) {
+      if (run < out_cap) {                                 // beyond the planned capacity: dropped (n_out says so)
+        int b, x, y, z;
+        quantise<1>(in_coords, i, 1.0f, new_stride, 0, &b, &x, &y, &z);
+        reinterpret_cast<int4*>(out_coords)[run] = make_int4(b, x, y, z);
+      }
+      ++run;
+    }
+  }
+  if (threadIdx.x == 0) n_out[0] = total;
+}
+
 extern "C" int cnrma_sparse_stride_coords_sorted(const int32_t* in_coords, int64_t n_cap, const int32_t* n_dev, int new_stride,
                                                  int32_t* out_coords, int64_t out_cap, int32_t* n_out, void* workspace,
                                                  void* stream) {
   if (new_stride <= 0 || n_cap <= 0 || in_coords == nullptr || out_coords == nullptr || n_out == nullptr) return CNRMA_EINVAL;
   if (out_cap <= 0 || out_cap > n_cap) out_cap = n_cap;
   hipStream_t st = as_stream(stream);
+  if (n_cap <= STRIDE_SMALL_MAX) {
+    hipLaunchKernelGGL(stride_sorted_small_kernel, dim3(1), dim3(1024), 0, st, in_coords, (int)n_cap, n_dev, new_stride, out_coords,
+                       (int)out_cap, n_out);
+    CNRMA_LAUNCH_CHECK();
+    return 0;
+  }
   UniqueWs w = carve_unique_ws(workspace, n_cap);
   const unsigned nb = (unsigned)ceil_div(n_cap, 256);
   hipLaunchKernelGGL(stride_sorted_flag_kernel, dim3(nb), dim3(256), 0, st, in_coords, n_cap, n_dev, new_stride, w.flag);

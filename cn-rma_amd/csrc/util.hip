@@ -11,6 +11,25 @@ extern "C" int cnrma_fill_bytes_u8(void* dst, int byte, size_t n_bytes, void* st
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+__global__ __launch_bounds__(256) void range_violations_kernel(const int32_t* __restrict__ v, const int32_t* __restrict__ lo,
+                                                               const int32_t* __restrict__ hi, int n, int32_t* __restrict__ out) {
+  __shared__ int sm[4];
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) c += (v[i] < lo[i] || v[i] > hi[i]) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+extern "C" int cnrma_range_violations_i32(const int32_t* values, const int32_t* lo, const int32_t* hi, int n, int32_t* out,
+                                          void* stream) {
+  if (values == nullptr || lo == nullptr || hi == nullptr || out == nullptr || n <= 0 || n > 4096) return CNRMA_EINVAL;
+  hipLaunchKernelGGL(range_violations_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), values, lo, hi, n, out);
+  CNRMA_LAUNCH_CHECK();
+  return 0;
+}
+
 namespace {
 
 constexpr int SCAN_BLOCK = 256;
@@ -100,9 +119,38 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const T* __restrict__ i
   }
 }
 
+// short inputs (n <= SCAN_SINGLE_MAX: the coarse levels' strided sets, the neck's unions): ONE block, ONE launch -- every thread
+// owns a contiguous run of ceil(n / 1024) items (round 6: a scene spends ~300 launches, two thirds of them this small)
+constexpr int SCAN_SINGLE_MAX = 32768;
+template <typename T, int MODE>
+__global__ __launch_bounds__(1024) void scan_single_kernel(const T* __restrict__ in, int32_t* __restrict__ out,
+                                                           int32_t* __restrict__ total_out, int n) {
+  __shared__ int smem[1024 / 64 + 1];
+  const int per = (n + 1023) / 1024;                       // <= 32
+  const int lo = threadIdx.x * per, hi = min(lo + per, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += (int)in[i];
+  int total;
+  int run = block_excl_scan<1024>(s, smem, &total);
+  for (int i = lo; i < hi; ++i) {
+    const int v = (int)in[i];
+    out[i] = (MODE == 0) ? run : (v ? run : -1);
+    run += v;
+  }
+  if (threadIdx.x == 0) {
+    if (MODE == 0) out[n] = total;
+    if (total_out) total_out[0] = total;
+  }
+}
+
 template <typename T, int MODE>
 int run_scan(const T* in, int32_t* out, int32_t* total_out, int64_t n, void* workspace, hipStream_t st) {
   if (n < 0) return CNRMA_EINVAL;
+  if (n <= SCAN_SINGLE_MAX) {
+    hipLaunchKernelGGL((scan_single_kernel<T, MODE>), dim3(1), dim3(1024), 0, st, in, out, total_out, (int)n);
+    CNRMA_LAUNCH_CHECK();
+    return 0;
+  }
   int64_t n_tiles = ceil_div(n > 0 ? n : 1, SCAN_TILE);
   int32_t* tile = reinterpret_cast<int32_t*>(workspace);
   hipLaunchKernelGGL((scan_tile_sums<T>), dim3((unsigned)n_tiles), dim3(SCAN_BLOCK), 0, st, in, tile, n);

@@ -213,4 +213,9 @@ class Plan:
         vals = torch.cat([w[0].to(torch.int32) for w in self._watch])
         lo = self.const(lambda: torch.tensor([w[1] for w in self._watch], dtype=torch.int32, device=device))
         hi = self.const(lambda: torch.tensor([w[2] for w in self._watch], dtype=torch.int32, device=device))
-        return ((vals < lo) | (vals > hi)).sum().to(torch.int32).view(1)
+        if vals.numel() > 4096:
+            return ((vals < lo) | (vals > hi)).sum().to(torch.int32).view(1)
+        from . import _lib
+        out = torch.empty(1, dtype=torch.int32, device=device)
+        _lib.call("cnrma_range_violations_i32", _lib.ptr(vals), _lib.ptr(lo), _lib.ptr(hi), vals.numel(), _lib.ptr(out), _lib.stream())
+        return out

@@ -36,6 +36,12 @@ int cnrma_abi_version(void);
  * then skip their own clearing launch (27 launches per scene). */
 int cnrma_fill_bytes_u8(void* dst, int byte, size_t n_bytes, void* stream);
 
+/* out[0] = number of i < n with values[i] < lo[i] or values[i] > hi[i] (n <= 4096).  The static trace registers every capacity /
+ * branch assumption of its size plan as such a range on a device word (the live row counts the reference reads back with
+ * nonzero() / ME's coordinate manager: ray_marching.py:781, :328-330); this folds them into the scene's status word in ONE launch
+ * (it was two compares, an or, a sum and a cast: five). */
+int cnrma_range_violations_i32(const int32_t* values, const int32_t* lo, const int32_t* hi, int n, int32_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * layout helper: feat_nchw[V][C][H][W] -> feat_nhwc[V][H][W][C]
  * (the reference keeps NCHW: projects/mvsdetection/models/ray_marching.py:64 and :799 gather [b,:,py,px])
