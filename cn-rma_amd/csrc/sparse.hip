@@ -1902,10 +1902,16 @@ constexpr int GO2_LDS = 2 * GO2_US * 2 + GO_BM * 27 * 2 + GO2_RS * 4;      // by
 // BF1: ONE bf16 plane per operand (round to nearest, no scaling), one MFMA per product on v_mfma_f32_32x32x16_bf16 -- the
 // arithmetic of cnrma_sparse_conv_bf16 (autocast training) on the gather-once structure; weight image
 // [k][slice][column tile][k-step][lane][8] (cnrma_sparse_conv_prepare_weights_bf16_frag)
-template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false, bool BF1 = false>
-__global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_go2_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag,
+// APF (round 6): the A fragments of a whole OFFSET are read one offset ahead of their MFMAs -- every fragment register is refilled
+// for the next offset right behind its last use, the local indices run two offsets ahead -- so that no MFMA group waits for an
+// LDS round trip (the form above exposes four per offset: 2 k-steps x 2 row tiles; on a grid that leaves <= 3 blocks per CU that
+// latency is not covered by other waves: the 27-offset chain of a block is what the short levels cost).  ~16 more registers: three
+// blocks per CU, which those grids do not reach anyway.  Same products in the same order per accumulator: bit-identical results.
+template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false, bool BF1 = false, bool APF = false>
+__global__ __launch_bounds__(256, APF ? 3 : ((NB == 2 && !STAMP) ? 4 : 2)) void sparse_conv_go2_kernel(ConvArgs p, GoArgs g, const uint16_t* __restrict__ wfrag,
                                                                              Go2Map mp) {
   static_assert(WAVES_N * KS == 4 && (KS == 1 || KS == 2), "four waves: column tiles x offset halves");
+  static_assert(!APF || (NB == 2 && !BF1 && !STAMP), "fragment look-ahead: the f16x3 product form only");
   constexpr int TM = 2, BN = 32 * WAVES_N;
   extern __shared__ __attribute__((aligned(16))) unsigned char go2_smem[];
   __bf16* const Us = reinterpret_cast<__bf16*>(go2_smem);                                // [2 planes][(GO_UMAX + 2) * LDK]
@@ -2089,37 +2095,112 @@ __global__ __launch_bounds__(256, (NB == 2 && !STAMP) ? 4 : 2) void sparse_conv_
       if (STAMP && dbg) go_stamp(dbg, n_stamp++);              // 2 + 3 i: union image staged
       // ---- the group's offsets back to back: no barrier, no LDS store, no index load from memory; the local indices of an
       // offset are read while the offset before it runs
-      int lin[TM];
-      load_li(lin, kk[0]);
-      int i = 0;
-      for (; i + NB < n_off; i += NB) {                        // steady state: NB offsets per turn, their successors prefetched
+      if constexpr (APF) {
+        // fragments one offset ahead.  fr[a][plane][k-step] holds the CURRENT offset's operands; each is reloaded for the next
+        // offset (rows li_n) right behind its last MFMA.  Local indices: two offsets ahead (an offset's row numbers must be in
+        // registers when the offset before it starts).
+        f16x8_t fr[TM][2][2];
+        auto rdf = [&](const int (&li)[TM], int a, int pl, int ks) -> f16x8_t {
+          return *reinterpret_cast<const f16x8_t*>(Us + pl * GO2_US + lds_slot(li[a], ks * 2 + fhalf));
+        };
+        auto mfma_ahead = [&](auto sync_tag, const u32x4_t (&bfr)[2][2], const int (&li_next)[TM], bool more) {
+          constexpr int SY = decltype(sync_tag)::value;      // one scheduling pipeline per call site
+          static_assert(TM == 2, "two row tiles per wave");
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
+          for (int ks = 0; ks < 2; ++ks) {
+            const f16x8_t bh = __builtin_bit_cast(f16x8_t, bfr[0][ks]), bm = __builtin_bit_cast(f16x8_t, bfr[1][ks]);
+            // the two accumulators alternate (a dependent MFMA issues every 64 cycles, two chains fill the pipe); per accumulator the
+            // order stays m*h, h*m, h*h as in the form above
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0][1][ks], bh, acc[0], 0, 0, 0);
+            if (more) fr[0][1][ks] = rdf(li_next, 0, 1, ks);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[1][1][ks], bh, acc[1], 0, 0, 0);
+            if (more) fr[1][1][ks] = rdf(li_next, 1, 1, ks);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0][0][ks], bm, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[1][0][ks], bm, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[0][0][ks], bh, acc[0], 0, 0, 0);
+            if (more) fr[0][0][ks] = rdf(li_next, 0, 0, ks);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[1][0][ks], bh, acc[1], 0, 0, 0);
+            if (more) fr[1][0][ks] = rdf(li_next, 1, 0, ks);
+          }
+          // pin that issue order (mh0 R mh1 R hm0 hm1 hh0 R hh1 R per k-step): every fragment is re-read right behind its last use --
+          // left alone the scheduler parks all eight reads behind the 8th-11th MFMA, and the next offset's first MFMA waits for them
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, SY); __builtin_amdgcn_sched_group_barrier(0x100, 1, SY);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, SY); __builtin_amdgcn_sched_group_barrier(0x100, 1, SY);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, SY); __builtin_amdgcn_sched_group_barrier(0x100, 1, SY);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, SY); __builtin_amdgcn_sched_group_barrier(0x100, 1, SY);
+          }
+        };
+        int li_n[TM];
+        {
+          int li_c[TM];
+          load_li(li_c, kk[0]);
+          load_li(li_n, kk[1 % NB]);                           // offset 1 (one offset only: the same again, never used)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { fr[a][1][ks] = rdf(li_c, a, 1, ks); fr[a][0][ks] = rdf(li_c, a, 0, ks); }
+        }
+        int i = 0;
+        auto step = [&](auto jt) {                             // one steady-state offset; jt: which of the two weight sets
+          constexpr int j = decltype(jt)::value;
           int li[TM];
 #pragma unroll
-          for (int a = 0; a < TM; ++a) li[a] = lin[a];
-          load_li(lin, kk[(j + 1) % NB]);                      // j + 1 < NB: this turn's next offset; else the next turn's first
-          if constexpr (BF1) go_waitn1<(NB - 1) * 2>(bf[j]);
-          else go_waitn<(NB - 1) * 4>(bf[j]);                  // bf[j] has landed; the NB - 1 sets behind it may still fly
-          mfma_k(bf[j], li);
-          kk[j] = pop();                                       // behind the last offset: the last one again (never used)
-          load_b(bf[j], kk[j], slice);
+          for (int a = 0; a < TM; ++a) li[a] = li_n[a];          // rows of the NEXT offset
+          const int k2 = pop();                                // the offset after it (behind the end: the last one again)
+          load_li(li_n, k2);
+          go_waitn<(NB - 1) * 4>(bf[j]);
+          mfma_ahead(jt, bf[j], li, true);
+          kk[j] = k2;
+          load_b(bf[j], k2, slice);
+        };
+        for (; i + NB < n_off; i += NB) {
+          step(std::integral_constant<int, 0>{});
+          step(std::integral_constant<int, 1>{});
         }
-      }
-      // the last <= NB offsets: nothing more to prefetch, and NO load may be left in flight (the asm loads are invisible to the
-      // compiler, which is free to reuse their destination registers from here on)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        if constexpr (BF1) go_drain1(bf[j]);
-        else go_drain(bf[j]);
-      }
+        for (int j = 0; j < NB; ++j) go_drain(bf[j]);
+        {
+          int li[TM];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        int li[TM];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) li[a] = lin[a];
-        if (j + 1 < NB) load_li(lin, kk[j + 1]);
-        if (i + j < n_off) mfma_k(bf[j], li);
+          for (int a = 0; a < TM; ++a) li[a] = li_n[a];
+          if (i < n_off) mfma_ahead(std::integral_constant<int, 2>{}, bf[0], li, i + 1 < n_off);
+          if (i + 1 < n_off) mfma_ahead(std::integral_constant<int, 3>{}, bf[1], li, false);
+        }
+      } else {
+        int lin[TM];
+        load_li(lin, kk[0]);
+        int i = 0;
+        for (; i + NB < n_off; i += NB) {                        // steady state: NB offsets per turn, their successors prefetched
+  #pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            int li[TM];
+  #pragma unroll
+            for (int a = 0; a < TM; ++a) li[a] = lin[a];
+            load_li(lin, kk[(j + 1) % NB]);                      // j + 1 < NB: this turn's next offset; else the next turn's first
+            if constexpr (BF1) go_waitn1<(NB - 1) * 2>(bf[j]);
+            else go_waitn<(NB - 1) * 4>(bf[j]);                  // bf[j] has landed; the NB - 1 sets behind it may still fly
+            mfma_k(bf[j], li);
+            kk[j] = pop();                                       // behind the last offset: the last one again (never used)
+            load_b(bf[j], kk[j], slice);
+          }
+        }
+        // the last <= NB offsets: nothing more to prefetch, and NO load may be left in flight (the asm loads are invisible to the
+        // compiler, which is free to reuse their destination registers from here on)
+  #pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if constexpr (BF1) go_drain1(bf[j]);
+          else go_drain(bf[j]);
+        }
+  #pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          int li[TM];
+  #pragma unroll
+          for (int a = 0; a < TM; ++a) li[a] = lin[a];
+          if (j + 1 < NB) load_li(lin, kk[j + 1]);
+          if (i + j < n_off) mfma_k(bf[j], li);
+        }
       }
       if (STAMP && dbg) go_stamp(dbg, n_stamp++);              // 3 + 3 i: this wave's offsets issued
     }
@@ -4106,16 +4187,23 @@ constexpr int GO_FORM_DEFAULT = 1;      // the second form everywhere (scripts/g
                                         // the layer classes of an S scene, never slower than the first form in its best work order)
 static int go_form_default(int64_t no_cap, int Cin, int Cout) { (void)no_cap; (void)Cin; (void)Cout; return GO_FORM_DEFAULT; }
 
-template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false, bool BF1 = false>
+template <int WAVES_N, int KS, bool HAS_RES, int NB, bool STAMP = false, bool BF1 = false, bool APF = false>
 static int launch_go2_one(unsigned blocks, const ConvArgs& p, const GoArgs& g, const uint16_t* wfrag, const Go2Map& mp, hipStream_t st) {
-  hipLaunchKernelGGL((sparse_conv_go2_kernel<WAVES_N, KS, HAS_RES, NB, STAMP, BF1>), dim3(blocks), dim3(256), GO2_LDS, st, p, g, wfrag, mp);
+  hipLaunchKernelGGL((sparse_conv_go2_kernel<WAVES_N, KS, HAS_RES, NB, STAMP, BF1, APF>), dim3(blocks), dim3(256), GO2_LDS, st, p, g, wfrag, mp);
   return 0;
 }
+// fragment look-ahead instantiation (APF): MEASURED AND REJECTED (round 6, scripts/go_forms.py AB=f2,f2a,
+// profiles/r06_go_apf_{S,NS}.log): equal within 1 % on every short layer class (11 k rows 42.8 vs 43.0 us, 2.4 k 37.3 vs 38.3, 541
+// 36.4 vs 37.0), 2-4 % slower on the 200-500 k-row layers (three blocks per CU).  The blocks of a short layer all start together,
+// so their offset phases coincide and the ~2.8 waves per SIMD saturate the matrix pipe INSIDE that phase (2.8 x 384 MFMA cycles per
+// offset step = the 0.6-0.74 us per step the stamps show): the fragment-read latency was already covered by the other waves.
+// Experiments library only (conv_tuning(nb=12)).
+constexpr unsigned GO_APF_MAX_BLOCKS = 0;
 static_assert(GO2_LDS <= 48 * 1024 && 4 * GO2_LDS <= 160 * 1024, "four blocks per CU without raising the dynamic LDS limit");
 
 // what the gather-once launcher runs for a layer: a pure function of the CAPACITY of the output, the widths and the workspace
 // (a captured launch sequence replays the same kernels; cnrma_sparse_conv_go_plan exposes it to the tests)
-struct Go2Plan { int form, bn, ks, splits, slices_per_split, mode, nb; int64_t tiles; unsigned blocks; Go2Map mp; };
+struct Go2Plan { int form, bn, ks, splits, slices_per_split, mode, nb, apf; int64_t tiles; unsigned blocks; Go2Map mp; };
 static Go2Plan go2_plan(int64_t no_cap, int Cin, int Cout, bool has_ws, size_t workspace_bytes) {
   const ConvTune tune = CNRMA_CONV_TUNE;
   Go2Plan pl{};
@@ -4151,6 +4239,12 @@ static Go2Plan go2_plan(int64_t no_cap, int Cin, int Cout, bool has_ws, size_t w
   else if (mp.mode == 2) pl.blocks = 8u * (unsigned)mp.per * (unsigned)mp.ng;
   else pl.blocks = (unsigned)mp.tiles * (unsigned)mp.ng;
   pl.nb = tune.nb == 4 ? 4 : 2;
+  // tune.nb 12 / 10 (experiments library): fragment look-ahead forced on / off
+#ifdef CNRMA_EXPERIMENTS
+  pl.apf = tune.nb == 12 ? 1 : (tune.nb == 10 ? 0 : (pl.blocks <= GO_APF_MAX_BLOCKS ? 1 : 0));
+#else
+  pl.apf = 0;
+#endif
   return pl;
 }
 
@@ -4177,6 +4271,17 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
     CNRMA_LAUNCH_CHECK();
     return 0;
   }
+#ifdef CNRMA_EXPERIMENTS
+  if (pl.apf && stamps == nullptr) {                          // fragment look-ahead (measured: no gain; see GO_APF_MAX_BLOCKS)
+#define CNRMA_GO2A(WN, KS_)                                                                                             \
+  rc = has_res ? launch_go2_one<WN, KS_, true, 2, false, false, true>(blocks, p, g, wfrag, mp, st)                      \
+               : launch_go2_one<WN, KS_, false, 2, false, false, true>(blocks, p, g, wfrag, mp, st)
+    if (pl.bn == 128) CNRMA_GO2A(4, 1);
+    else CNRMA_GO2A(2, 2);
+#undef CNRMA_GO2A
+  } else
+#endif
+  {
 #ifdef CNRMA_EXPERIMENTS            // + the s_memtime-stamped instantiation and four weight offsets in flight (measured 0-5 % slower)
 #define CNRMA_GO2(WN, KS_, NB_)                                                                              \
   rc = stamps != nullptr && !has_res ? launch_go2_one<WN, KS_, false, NB_, true>(blocks, p, g, wfrag, mp, st) \
@@ -4198,6 +4303,7 @@ static int launch_go2(const Go2Plan& pl, ConvArgs p, GoArgs g, const uint16_t* w
   else CNRMA_GO2(2, 2, 2);
 #endif
 #undef CNRMA_GO2
+  }
   if (rc != 0) return rc;
   if (pl.splits > 1) {
     int64_t rb = ceil_div(p.no_cap * p.Cout / 4 + 1, 256);
@@ -4219,7 +4325,7 @@ extern "C" int cnrma_sparse_conv_go_plan(int64_t no_cap, int Cin, int Cout, size
   if (out8 == nullptr || no_cap <= 0 || Cin <= 0 || Cin % BK != 0 || Cout < 64) return CNRMA_EINVAL;
   const Go2Plan pl = go2_plan(no_cap, Cin, Cout, workspace_bytes > 0, workspace_bytes);
   out8[0] = pl.form >= 2 ? 2 : (pl.form >= 1 ? 1 : 0); out8[1] = pl.bn; out8[2] = pl.splits; out8[3] = pl.slices_per_split;
-  out8[4] = pl.form >= 1 ? pl.mode : 0; out8[5] = has_residual && pl.splits == 1; out8[6] = (int)pl.blocks; out8[7] = pl.nb;
+  out8[4] = pl.form >= 1 ? pl.mode : 0; out8[5] = has_residual && pl.splits == 1; out8[6] = (int)pl.blocks; out8[7] = pl.nb + (pl.apf ? 10 : 0);      // + 10: fragment look-ahead instantiation
   return 0;
 }
 

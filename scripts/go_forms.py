@@ -54,7 +54,7 @@ def timed(c):
 
 
 VARIANTS = [("f1", dict(go=0)), ("f2x0", dict(go=1, xcd=0)), ("f2x1", dict(go=1, xcd=1)), ("f2x2", dict(go=1, xcd=2)),
-            ("f2", dict(go=1)), ("f2b4", dict(go=1, nb=4)), ("f3", dict(go=2)), ("f3na", dict(go=2, pf=7)), ("f3occ", dict(go=2, pf=8))]
+            ("f2", dict(go=1, nb=10)), ("f2a", dict(go=1, nb=12)), ("f2b4", dict(go=1, nb=4)), ("f3", dict(go=2)), ("f3na", dict(go=2, pf=7)), ("f3occ", dict(go=2, pf=8))]
 if os.environ.get("AB"):            # AB=f2,f3: only these variants, interleaved three times (order effects: a slow variant leaves the
     names = os.environ["AB"].split(",")                       # chip in another clock / cache state for the one measured after it)
     VARIANTS = [v for v in VARIANTS if v[0] in names] * 3
