@@ -37,7 +37,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0
 # HBM-side traffic of the dominant kernel per launch: READ from the per-kernel sums of the PMC passes committed under
 # profiles/ (scripts/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs folded by scripts/pmc_sum.py;
 # counter unit KB; FETCH_SIZE x 2 -- gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM")
-PMC_TAG = "r05"
+PMC_TAG = "r06"
 PMC_KERNELS = {"dense": ("backproject_accum",), "conv": ("sparse_conv_",)}
 
 
