@@ -772,6 +772,10 @@ def train_block(device, steps=8, warm=3):
     import projects.mvsdetection  # noqa: F401
     from projects.mvsdetection.registry import build_model as build_registered
     from cnrma_amd import synth
+    import gc
+    gc.collect()                                 # graphs / plans of the inference blocks measured before (reference cycles)
+    torch.cuda.empty_cache()
+    resident = torch.cuda.memory_allocated()     # what other blocks of this process still hold: not this block's footprint
     sc = synth.make_scene("S", seed=0)
     C = sc["features"].shape[2]
     cfg = runpy.run_path(os.path.join(ROOT, "projects", "configs", "mvsdetection", "ray_marching_scannet.py"))
@@ -812,7 +816,8 @@ def train_block(device, steps=8, warm=3):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     return dict(value=1e3 / ms, unit="scenes/s", ms_per_step=ms, steps=steps, loss=float(loss), dtype="bf16 autocast (fp32 master weights)",
-                peak_memory_GiB=torch.cuda.max_memory_allocated() / 2 ** 30,
+                peak_memory_GiB=(torch.cuda.max_memory_allocated() - resident) / 2 ** 30,      # model + scene + the step's own peak
+                resident_before_GiB=resident / 2 ** 30,
                 note="BASELINE configs[4] on ONE GPU: forward + backward (aggregation, sparse convolutions dgrad + wgrad, losses) + SGD "
                      "step per scene at the ScanNet shape, eager path (~2 k launches per step)")
 
