@@ -484,6 +484,12 @@ def test_gather_once_bf16_forward_and_data_gradient_equal_the_stage_kernel(devic
     o1, o2 = np.lexsort(got_c.T[::-1]), np.lexsort(oc.T[::-1])
     assert np.array_equal(got_c[o1], oc[o2])
     np.testing.assert_allclose(res[True][0][o1], exp[o2], rtol=1e-5, atol=1e-5 * np.abs(exp).max())
+    # the DATA gradient of the gather-once path directly against the fp64 oracle (it was only compared with the stage
+    # kernel): grad_in = sum_k G[o] @ W[k]^T over the pairs, with the operands the kernel multiplies -- grad_out and W rounded to bf16
+    # (the rows of y follow the input rows here: stride 1, out set = in set)
+    assert np.array_equal(got_c, c)
+    gF, _ = SO.conv_backward(c, f, _bf16_round(W), _bf16_round(g), 3, 1, 1)
+    np.testing.assert_allclose(res[True][1], gF, rtol=2e-5, atol=2e-5 * np.abs(gF).max())
 
 
 @pytest.mark.parametrize("inplanes,planes,stride,prec", [(64, 64, 1, "bf16"), (64, 128, 2, "bf16"), (32, 64, 1, None)])
