@@ -36,7 +36,7 @@ def hook(self, out_set, k, off, method="auto"):
 S.CoordSet.neighbours = hook
 with torch.no_grad():
     pipeline.forward_scene(cfg, backbone, head, feat, proj, tsdf, dense=False)
-tot = {"pairs32": 0.0, 64: 0, 32: 0, 16: 0}
+tot = {"pairs32": 0.0, 64: 0, 32: 0, 16: 0, "perm32": 0, "side32": 0}
 for nbr, cs in seen:
     n = int(cs.n)
     nb = nbr[:n]
@@ -48,12 +48,28 @@ for nbr, cs in seen:
     for g in (64, 32, 16):
         act = v.view(-1, g, 27).any(dim=1)                 # [sub-tiles][27]
         row[g] = int(act.sum().item()) * (g // 16)         # in 16-row units
+    # what a permutation of the rows INSIDE each 64-row tile could buy (the tile's union is unchanged by it): rows sorted by how many
+    # neighbours they have, the 32 fullest in one half -- a cheap stand-in for the best 2-way partition
+    v64 = v.view(-1, 64, 27)
+    order = torch.argsort(v64.sum(dim=2), dim=1, descending=True)
+    vs = torch.gather(v64, 1, order.unsqueeze(-1).expand(-1, -1, 27))
+    row["perm32"] = int((vs[:, :32].any(dim=1).sum() + vs[:, 32:].any(dim=1).sum()).item()) * 2
+    # and by the direction they lack most neighbours in (sign of the mean missing offset along the axis of largest imbalance)
+    offs = torch.tensor([[dx, dy, dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=torch.float32, device=dev)
+    miss = (~v64).float() @ offs                               # [tiles, 64, 3]: where a row's missing neighbours point
+    axis = miss.abs().sum(dim=1).argmax(dim=1)                 # per tile: the axis along which the rows differ most
+    key = torch.gather(miss, 2, axis.view(-1, 1, 1).expand(-1, 64, 1)).squeeze(-1)
+    order = torch.argsort(key, dim=1)
+    vs = torch.gather(v64, 1, order.unsqueeze(-1).expand(-1, -1, 27))
+    row["side32"] = int((vs[:, :32].any(dim=1).sum() + vs[:, 32:].any(dim=1).sum()).item()) * 2
     u = uses[id(nbr)]
     print(f"rows={n:7d} stride={cs.stride:3d} used x{u}  pairs/16={pairs / 16:10.0f}  executed 16-row units: "
           f"mask64={row[64]:9d} ({row[64] * 16 / pairs:.2f}x)  mask32={row[32]:9d} ({row[32] * 16 / pairs:.2f}x)  "
-          f"mask16={row[16]:9d} ({row[16] * 16 / pairs:.2f}x)   density={pairs / (n * 27):.3f}")
+          f"mask16={row[16]:9d} ({row[16] * 16 / pairs:.2f}x)   rows permuted inside the tile, mask32: fullest-first {row['perm32'] * 16 / pairs:.2f}x  "
+          f"by side {row['side32'] * 16 / pairs:.2f}x   density={pairs / (n * 27):.3f}")
     tot["pairs32"] += u * pairs / 16
-    for g in (64, 32, 16):
+    for g in (64, 32, 16, "perm32", "side32"):
         tot[g] += u * row[g]
 print(f"{WL}: weighted by uses (not by channels): mask64 {tot[64] / tot['pairs32']:.3f}x  mask32 {tot[32] / tot['pairs32']:.3f}x  "
-      f"mask16 {tot[16] / tot['pairs32']:.3f}x of the pair count")
+      f"mask16 {tot[16] / tot['pairs32']:.3f}x of the pair count; mask32 with the rows permuted inside each tile: fullest-first "
+      f"{tot['perm32'] / tot['pairs32']:.3f}x, by side {tot['side32'] / tot['pairs32']:.3f}x")
