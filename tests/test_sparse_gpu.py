@@ -250,7 +250,8 @@ def test_gather_once_second_form_is_bit_identical_to_the_first(device, cin, cout
             ref = S.conv(x, W, 3, 1, residual=res, act="relu")
             ref_f, ref_amax = ref.F.clone(), float(ref.amax.max())
             plain = S.conv(x, W, 3, 1).F.clone()
-            for go, nb, xcd in [(1, nb_, x_) for nb_ in (2, 4) for x_ in (0, 1, 2)] + [(2, -1, -1)]:      # go = 2: the third form
+            # nb = 12: the fragment-look-ahead instantiation of the second form (round 6: A fragments one offset ahead); go = 2: the third form
+            for go, nb, xcd in [(1, nb_, x_) for nb_ in (2, 4, 12) for x_ in (0, 1, 2)] + [(2, -1, -1)]:
                 if True:
                     if True:
                         S.conv_tuning(splits=splits, go=go, nb=nb, xcd=xcd)
