@@ -463,3 +463,20 @@ def test_free_space_skipping_changes_nothing_in_the_march(device, shape, seed):
                 r += 1
         assert radii[i, j, k] == 4 * r, (i, j, k, radii[i, j, k], r)
     assert (radii > 0).mean() > 0.05                                  # furnished rooms still have free space to skip
+
+
+@pytest.mark.parametrize("n", [1, 63, 1023, 1024, 1025, 32767, 32768, 32769, 70001, 5_000_000])
+def test_device_scans_match_torch_on_both_sides_of_the_single_launch_threshold(device, n):
+    """cnrma_exclusive_scan_i32 / cnrma_mask_to_index: one block and one launch up to 32 768 items (round 6: the coarse levels'
+    strided sets, the neck's unions), tile sums + apply above -- both against torch.cumsum, at the sizes around the switch"""
+    from cnrma_amd import rma
+    g = torch.Generator(device=device).manual_seed(n)
+    cnt = torch.randint(0, 7, (n,), generator=g, device=device, dtype=torch.int32)
+    off = rma.exclusive_scan(cnt)
+    ref = torch.cat((torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(cnt.long(), 0)))
+    assert off.shape[0] == n + 1 and torch.equal(off.long(), ref)
+    mask = (torch.rand(n, generator=g, device=device) < 0.37).to(torch.uint8)
+    sel, n_sel = rma.mask_to_index(mask)
+    rank = torch.cumsum(mask.long(), 0) - mask.long()
+    assert int(n_sel) == int(mask.sum())
+    assert torch.equal(sel.long(), torch.where(mask.bool(), rank, torch.full_like(rank, -1)))
