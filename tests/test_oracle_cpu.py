@@ -174,6 +174,28 @@ def test_ctypes_table_matches_header():
     assert not set(_lib.SIGNATURES) & set(_lib.EXPERIMENT_SIGNATURES)
 
 
+def test_experiments_library_is_opt_in_and_reference_counted():
+    """product code binds libcnrma_hip.so only; `_lib.experiments(True, who)` routes the process's calls through
+    libcnrma_hip_exp.so until every `who` has let go (sparse.conv_tuning / rma.dense_tuning / tests are such users)"""
+    from cnrma_amd import _lib
+    assert not _lib.experiments_active()
+    prod = _lib.load()
+    assert not hasattr(prod, "cnrma_debug_conv_tuning") and not hasattr(prod, "cnrma_debug_dense_tuning")
+    try:
+        _lib.experiments(True, "a")
+        _lib.experiments(True, "b")
+        exp = _lib.load()
+        assert exp is not prod and hasattr(exp, "cnrma_debug_conv_tuning") and hasattr(exp, "cnrma_sparse_conv_go_f16x3")
+        assert _lib.load(experiments=False) is prod
+        _lib.experiments(False, "a")
+        assert _lib.experiments_active() and _lib.load() is exp          # "b" still holds it
+        _lib.experiments(False, "b")
+        assert not _lib.experiments_active() and _lib.load() is prod
+    finally:
+        _lib.experiments(False, "a")
+        _lib.experiments(False, "b")
+
+
 def test_product_path_fails_loudly_without_gpu():
     from cnrma_amd import _lib, rma
     if torch.cuda.is_available():
