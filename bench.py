@@ -98,6 +98,24 @@ def pmc_sq(workload, tag=None, profiles=None):
     return out
 
 
+def mfma_count(workload, precision="f16x3", tag=None, profiles=None):
+    """executed-over-algorithmic MFMA instructions of the gather-once convolutions of a scene, from the counter pass committed
+    under profiles/ (scripts/profile_mfma.sh -> <tag>_mfma_count_<workload>_<precision>.log, last line).  None when not there."""
+    import re
+    path = os.path.join(profiles or os.path.join(ROOT, "profiles"), f"{tag or PMC_TAG}_mfma_count_{workload}_{precision}.log")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        last = [l for l in f.read().splitlines() if l.startswith("sum:")]
+    m = last and re.search(r"executed / algorithmic ([\d.]+); executed / tile-mask ([\d.]+); busy / \(executed x (\d+)\) ([\d.]+); "
+                           r"busy / \(4 x CU-busy\) ([\d.]+)", last[-1])
+    if not m:
+        return None
+    return dict(executed_over_algorithmic=float(m.group(1)), executed_over_tile_mask_prediction=float(m.group(2)),
+                busy_cycles_over_executed_x_cycles=float(m.group(4)), mfma_busy_in_this_pass=float(m.group(5)),
+                source=os.path.relpath(path, ROOT))
+
+
 def pmc_provenance(tag=None, profiles=None):
     """where the counter-derived numbers of the line come from, and whether they describe THIS build: the PMC
     passes are separate rocprofv3 runs committed under profiles/, not part of a bench run; scripts/profile_round.sh /
@@ -726,6 +744,7 @@ def profile_block(wl, block, name):
         ok = block["pmc_provenance"]["matches_build"] is not False and f16x3
         conv["mfma_busy_gather_once"] = block["pmc_sq"]["gather_once_conv"]["mfma_busy"] if ok else None
         conv["mfma_busy_src"] = block["pmc_provenance"]["src"] + ("" if ok else " (another build: not reported)")
+    conv["mfma_count"] = mfma_count(name) if name in ("S", "NS") else None     # executed vs algorithmic MFMAs (counter pass)
     block["conv_layers"] = [dict(K=L["K"], Cin=L["Cin"], Cout=L["Cout"], rows=L["n_out"], pairs=L["pairs"], ms=round(L["ms"], 4))
                             for L in layers]
     ms_scene = block["ms_per_scene"]
@@ -874,6 +893,7 @@ def compact_line(result):
         line["conv_ms_per_scene"] = result["conv"].get("ms_per_scene")
         line["conv_mfma_busy"] = result["conv"].get("mfma_busy_gather_once")
         line["pmc_src"] = result["conv"].get("mfma_busy_src")            # roofline.traffic and conv_mfma_busy: committed counter passes
+        line["conv_mfma_executed_over_algorithmic"] = (result["conv"].get("mfma_count") or {}).get("executed_over_algorithmic")
     if result.get("whole_path_hbm"):
         line["whole_path_hbm_frac"] = result["whole_path_hbm"].get("frac_of_8TBps")
     line["roofline"] = _roof(result.get("roofline"))
@@ -884,6 +904,7 @@ def compact_line(result):
                          graph_nodes_per_scene=s.get("graph_nodes_per_scene"),
                          conv_ms_per_scene=(s.get("conv") or {}).get("ms_per_scene"),
                          conv_mfma_busy=(s.get("conv") or {}).get("mfma_busy_gather_once"),
+                         conv_mfma_executed_over_algorithmic=((s.get("conv") or {}).get("mfma_count") or {}).get("executed_over_algorithmic"),
                          roofline=_roof(s.get("roofline")), cpu_baseline=_cpu(s.get("cpu_baseline"), sample=False))
     for k in ("through_plugin", "nchw_input", "f32_conv", "St", "A", "train_S"):
         if result.get(k):
