@@ -943,6 +943,15 @@ def emit(result, detail_path=""):
     sys.stdout.flush()
 
 
+def _released(tag):
+    """after a block: collect reference cycles (plans <-> tensors, graphs), hand the cached blocks back, say what is still held"""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
+    log(f"{tag}: {torch.cuda.memory_allocated() / 2 ** 30:.1f} GiB still allocated")
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1024,7 +1033,7 @@ def main():
     Ms_full = main_block["M_selected"]
     main_layout = wl.layout
     del wl
-    torch.cuda.empty_cache()
+    _released('block')
 
     if args.through_plugin:
         result["config"]["driver"] = ("registered RayMarching detector: model(return_loss=False, **data) per scene, "
@@ -1044,7 +1053,7 @@ def main():
         import shutil
         shutil.rmtree(wlp.save_dir, ignore_errors=True)
         del wlp
-        torch.cuda.empty_cache()
+        _released('block')
     if not args.no_secondary:
         # ---- the same workload with exact-fp32 MFMA convolutions (every rank takes part: the windows hold collectives)
         wl32, b32 = measure(args.workload, device, rank, world, args, barrier, precision="f32")
@@ -1054,7 +1063,7 @@ def main():
         # first-class: the same workload at the reference's own arithmetic (exact fp32 products in the sparse convolutions)
         result["value_f32_conv"] = b32["value"]
         del wl32
-        torch.cuda.empty_cache()
+        _released('block')
         if main_layout == "channels_last":
             # ---- the same workload with the maps handed over NCHW (the reference's layout): layout pass inside the timed path
             wln, bn = measure(args.workload, device, rank, world, args, barrier, layout="nchw")
@@ -1063,7 +1072,7 @@ def main():
             result["nchw_input"]["note"] = ("feature maps resident as NCHW [V,C,H,W]: cnrma_nchw_to_nhwc_march_f32 (layout pass + march in "
                                             "one launch) runs per scene inside the timed region")
             del wln
-            torch.cuda.empty_cache()
+            _released('block')
         if args.workload != "S":
             wls, bs = measure("S", device, rank, world, args, barrier)
             if rank == 0 and not args.no_profile:
@@ -1074,7 +1083,7 @@ def main():
                 bs["cpu_baseline"] = cpu_baseline("S", bs["M_selected"], 32)
             result["S"] = bs
             del wls
-            torch.cuda.empty_cache()
+            _released('block')
     if not args.no_secondary and not args.through_plugin and args.workload != "St":
         # ---- ScanNet TEST shape (ray_marching_scannet.py:16,19: 50 views, grid 256 x 256 x 96): numbers only
         wlt, bt = measure("St", device, rank, world, args, barrier)
@@ -1082,7 +1091,7 @@ def main():
                                             "plan_violations", "graph_nodes_per_scene", "M_rows", "M_selected", "M_unique", "level_rows", "head_rows")}
         result["St"]["workload"] = "St: ScanNet test shape, V=50, C=32, 120x160 maps (stride 4), grid 256x256x96 (ray_marching_scannet.py:16,19)"
         del wlt
-        torch.cuda.empty_cache()
+        _released('block')
     if not args.no_secondary and not args.through_plugin:
         # ---- BASELINE configs[2]: the ARKitScenes detector (ray_marching_arkit.py: 17 classes, 8 regression outputs, yaw decode)
         # built from its shipped model section and driven through the plugin API at its own shape (40 views, 192 x 192 x 80)
@@ -1104,7 +1113,7 @@ def main():
                 raise                                                    # the windows hold collectives: no rank may skip them alone
             log(f"A block failed: {e!r}")
             result["A"] = None
-        torch.cuda.empty_cache()
+        _released('block')
     if rank == 0 and world == 1 and not args.no_secondary and not args.through_plugin:
         log("training step at the ScanNet shape (bf16 autocast)")
         try:
@@ -1113,7 +1122,7 @@ def main():
         except Exception as e:                                           # noqa: BLE001 -- a secondary block must not cost the line
             log(f"train_S failed: {e!r}")
             result["train_S"] = None
-        torch.cuda.empty_cache()
+        _released('block')
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         name = args.workload if args.workload in ("NS", "S", "St") else "tiny"
         log("cpu baseline (oracle on the host cores)")

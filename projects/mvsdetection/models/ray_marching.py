@@ -460,10 +460,16 @@ class RayMarching(MultiViewBase):
 
     @staticmethod
     def _writer_loop(q, ref):
+        import queue
         from cnrma_amd import _lib, pipeline
         stream = None
         while True:
-            item = q.get()
+            try:
+                item = q.get(timeout=5.0)
+            except queue.Empty:
+                if ref() is None:                                # the detector is gone: so is this thread
+                    return
+                continue
             if item is None:
                 return
             try:
@@ -486,6 +492,10 @@ class RayMarching(MultiViewBase):
                 item["status"], item["error"] = "error", e
             finally:
                 item["finished"].set()
+                # nothing of a finished scene -- its static buffers, the detector itself -- may outlive it in this frame: the
+                # thread blocks in q.get() between scenes, and a name still bound here kept the last detector and its graphs
+                # (tens of GB at the north-star shape) alive after `del model` (round 6: bench.py's resident memory)
+                item = out = model = b = s = None
 
     def _drain(self, ctx, i):
         """the slot's previous scene has left its static buffers (its file is written) -- or, if it outgrew the size plan,

@@ -290,6 +290,41 @@ def test_shipped_config_takes_the_graph_path_unmodified(device, tmp_path):
     assert tuple(model.volume.shape)[:2] == (1, 8) and model.points_detection[0].shape[1] == 3 + 8
 
 
+def test_a_deleted_detector_frees_its_graphs(device, tmp_path):
+    """the result-writer thread blocks in q.get() between scenes: nothing of a finished scene -- its slot's static buffers, the
+    detector itself -- may stay bound in that frame (round 6: a deleted detector kept ~70 GB of graphs alive at the north-star
+    shape).  After `del model` the module, its slots and their device memory are gone; the thread ends by itself."""
+    import gc
+    import threading
+    import weakref
+    from cnrma_amd import synth
+    dims = synth.SHAPES["tiny"][4]
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    model = _model(tmp_path, dims, device, max_points=500000)
+    scenes = _tiny_scenes(device, 6)
+    with torch.no_grad():
+        for d in scenes:
+            model(return_loss=False, **d)
+    model.flush()
+    ctx = next(iter(model._static.values()))
+    assert ctx["built"]
+    m_ref, s_ref = weakref.ref(model), weakref.ref(ctx["slots"][0])
+    writer = model._writer[1]
+    held = torch.cuda.memory_allocated() - base
+    assert writer.is_alive() and held > 0
+    del model, ctx, scenes, d
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert m_ref() is None and s_ref() is None
+    # what stays are the process-wide grow-only scratch buffers of cnrma_amd.sparse / rma (workspaces per stream, counters, bounds)
+    left = torch.cuda.memory_allocated() - base
+    assert left <= 64 << 20 and left < 0.5 * held, (left / 2 ** 20, held / 2 ** 20)
+    writer.join(timeout=12.0)                                  # it polls for the detector's death every 5 s
+    assert not writer.is_alive() and not [t for t in threading.enumerate() if t is writer]
+
+
 def test_graphs_never_replay_stale_weights(device, tmp_path):
     """captured graphs hold raw pointers to prepared weight images.  train() / eval() toggles,
     load_state_dict() and in-place weight updates after the capture must all lead to results of the CURRENT weights"""
