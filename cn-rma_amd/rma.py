@@ -111,6 +111,8 @@ def _dense_workspace(dev, st):
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), st)
     ws = _DENSE_WS.get(key)
     if ws is None:
+        if len(_DENSE_WS) >= 64:                  # streams come and go; their handles are all this table knows of them
+            _DENSE_WS.pop(next(iter(_DENSE_WS)))
         ws = torch.zeros(256, dtype=torch.int32, device=dev)
         _DENSE_WS[key] = ws
     return ws

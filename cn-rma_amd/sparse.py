@@ -473,6 +473,21 @@ def fold_bn(bn, bias=None):
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2}
 
 _WS = {}
+_WS_STREAMS = 12      # scratch buffers kept: the streams of a process come and go (every scene slot / detector has its own), their
+                      # raw handles are all this table knows of them -- the least recently used entries are dropped (round 6: ~1 GB
+                      # per detector ever built stayed allocated).  Dropping is safe: the caching allocator hands a freed block
+                      # back to the stream it was allocated on, in stream order.
+
+
+def _lru_get(table, key, make, limit=_WS_STREAMS):
+    """table[key] (moved to the most-recent end), created by make() when absent; the oldest entries beyond `limit` are dropped"""
+    buf = table.pop(key, None)
+    if buf is None:
+        buf = make()
+    table[key] = buf
+    while len(table) > limit:
+        table.pop(next(iter(table)))
+    return buf
 
 
 def _workspace(nbytes, device):
@@ -481,11 +496,10 @@ def _workspace(nbytes, device):
     if P.static():
         return P.current().workspace(nbytes, device)
     key = (device, stream())
-    buf = _WS.get(key)
+    buf = _WS.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _WS[key] = buf
-    return buf
+    return _lru_get(_WS, key, lambda: buf)
 
 
 _COUNTER_WORDS = 16384
@@ -503,10 +517,7 @@ def _tile_counters(device):
     if P.static():
         return P.current().counters(device, _COUNTER_WORDS)
     key = (device, stream())
-    buf = _COUNTERS.get(key)
-    if buf is None:
-        buf = _COUNTERS[key] = torch.zeros(_COUNTER_WORDS, dtype=torch.int32, device=device)
-    return buf
+    return _lru_get(_COUNTERS, key, lambda: torch.zeros(_COUNTER_WORDS, dtype=torch.int32, device=device))
 
 
 # "f16x3":  22-bit operands on the fp16 matrix cores: a 2^s = h + m (two fp16 pieces, power-of-two scale from the tensor's
